@@ -1,0 +1,166 @@
+/*
+ * tgn_pointops.h -- C ABI of libtgn_pointops.so, the MI355X (gfx950) implementation of
+ * ToothGroupNetwork's point-cloud sampling / grouping hot path.
+ *
+ * Plain pointers and sizes only (device pointers unless stated), no torch types.  The host
+ * side (toothgroupnetwork_amd/_lib.py) binds these with ctypes and passes tensor.data_ptr()
+ * and the current HIP stream.
+ *
+ * Section 1 re-exports, name for name and argument for argument, the `extern "C"` launchers the
+ * reference's pybind layer binds (limhoyeon/ToothGroupNetwork, external_libs/pointops/src):
+ * a maintainer can link the reference's *_cuda.cpp wrappers against this library unchanged.
+ * They run on the stream set with tgn_set_default_stream() (the reference uses the null
+ * stream, e.g. sampling_cuda_kernel.cu:136) and report errors through tgn_last_error().
+ *
+ * Section 2 holds the stream-aware forms of the same operators (trailing stream, int status)
+ * and Section 3 the operators the reference composes out of torch kernels
+ * (external_libs/pointnet2_utils/pointnet2_utils.py) that are single HIP kernels here.
+ *
+ * All functions are thread-safe as long as callers own their buffers; scratch is caller-provided.
+ * Status: 0 = ok, non-zero = error (tgn_last_error() gives the text).  Layouts are row-major
+ * contiguous fp32 / int32 exactly as the reference's kernels expect.
+ */
+#ifndef TGN_POINTOPS_H
+#define TGN_POINTOPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *tgn_stream_t; /* a hipStream_t; NULL = the null stream */
+
+#define TGN_OK 0
+#define TGN_ERR_INVALID_ARGUMENT 1
+#define TGN_ERR_LAUNCH 2
+#define TGN_ERR_UNSUPPORTED 3
+
+/* flags of tgn_furthestsampling* */
+#define TGN_FPS_FMA 1         /* d = fma(dz,dz,fma(dy,dy,dx*dx)): nvcc's contraction of sampling_cuda_kernel.cu:54 */
+#define TGN_FPS_LOCAL_INDEX 2 /* write indices relative to the cloud's first point (pointnet2_utils.py:96) */
+#define TGN_FPS_INDEX64 4     /* idx is int64_t* instead of int32_t* */
+#define TGN_FPS_TREE_TIES 8   /* equal distances resolved like the CUDA kernel's shared-memory tree (:5-10,64-123) */
+#define TGN_FPS_CUDA_COMPAT (TGN_FPS_FMA | TGN_FPS_TREE_TIES)
+
+const char *tgn_version(void);
+const char *tgn_last_error(void);
+void tgn_set_default_stream(tgn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 1. The reference's C ABI, verbatim (each line cites the declaration it replaces).
+ * ---------------------------------------------------------------------------------------- */
+/* sampling/sampling_cuda_kernel.h:13 ; n = max points per cloud ; tmp (n_total) pre-filled 1e10 */
+void furthestsampling_cuda_launcher(int b, int n, const float *xyz, const int *offset, const int *new_offset,
+                                    float *tmp, int *idx);
+/* knnquery/knnquery_cuda_kernel.h:13 ; dist2 = squared distances, ascending */
+void knnquery_cuda_launcher(int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
+                            const int *new_offset, int *idx, float *dist2);
+/* grouping/grouping_cuda_kernel.h:14-15 */
+void grouping_forward_cuda_launcher(int m, int nsample, int c, const float *input, const int *idx, float *output);
+void grouping_backward_cuda_launcher(int m, int nsample, int c, const float *grad_output, const int *idx,
+                                     float *grad_input);
+/* interpolation/interpolation_cuda_kernel.h:14-15 ; output / grad_input pre-zeroed, accumulated into */
+void interpolation_forward_cuda_launcher(int n, int c, int k, const float *input, const int *idx,
+                                         const float *weight, float *output);
+void interpolation_backward_cuda_launcher(int n, int c, int k, const float *grad_output, const int *idx,
+                                          const float *weight, float *grad_input);
+/* subtraction/subtraction_cuda_kernel.h:14-15 */
+void subtraction_forward_cuda_launcher(int n, int nsample, int c, const float *input1, const float *input2,
+                                       const int *idx, float *output);
+void subtraction_backward_cuda_launcher(int n, int nsample, int c, const int *idx, const float *grad_output,
+                                        float *grad_input1, float *grad_input2);
+/* aggregation/aggregation_cuda_kernel.h:14-15 */
+void aggregation_forward_cuda_launcher(int n, int nsample, int c, int w_c, const float *input,
+                                       const float *position, const float *weight, const int *idx, float *output);
+void aggregation_backward_cuda_launcher(int n, int nsample, int c, int w_c, const float *input,
+                                        const float *position, const float *weight, const int *idx,
+                                        const float *grad_output, float *grad_input, float *grad_position,
+                                        float *grad_weight);
+
+/* ------------------------------------------------------------------------------------------
+ * 2. Stream-aware forms of the same operators.
+ * ---------------------------------------------------------------------------------------- */
+/*
+ * Farthest point sampling over b packed clouds (pointops.py:10-27).  n_max = largest cloud.
+ * tmp may be NULL unless a cloud exceeds tgn_fps_resident_capacity() points (then it must hold
+ * offset[b-1] floats; contents on entry are ignored).  new_xyz (m,3) is optional (NULL to skip): the
+ * sampled coordinates, i.e. xyz[idx] (pointnet2_utils.py:276 / blocks.py:70).
+ */
+int tgn_furthestsampling(int b, int n_max, const float *xyz, const int *offset, const int *new_offset,
+                         float *tmp, void *idx, float *new_xyz, int flags, tgn_stream_t stream);
+/* Dense batch (B,N,3) -> (B,S): the offsets of pointnet2_utils.py:87-96 are implicit. */
+int tgn_furthestsampling_dense(int B, int N, int S, const float *xyz, float *tmp, void *idx, float *new_xyz,
+                               int flags, tgn_stream_t stream);
+int tgn_fps_resident_capacity(void);
+
+/* kNN (pointops.py:30-45): b segments; idx (m,nsample) int32; dist2 (m,nsample) squared, ascending. */
+int tgn_knnquery(int b, int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
+                 const int *new_offset, int *idx, float *dist2, tgn_stream_t stream);
+
+int tgn_grouping_forward(int m, int nsample, int c, const float *input, const int *idx, float *output,
+                         tgn_stream_t stream);
+int tgn_grouping_backward(int m, int nsample, int c, const float *grad_output, const int *idx, float *grad_input,
+                          tgn_stream_t stream);
+int tgn_interpolation_forward(int n, int c, int k, const float *input, const int *idx, const float *weight,
+                              float *output, tgn_stream_t stream);
+int tgn_interpolation_backward(int n, int c, int k, const float *grad_output, const int *idx, const float *weight,
+                               float *grad_input, tgn_stream_t stream);
+int tgn_subtraction_forward(int n, int nsample, int c, const float *input1, const float *input2, const int *idx,
+                            float *output, tgn_stream_t stream);
+int tgn_subtraction_backward(int n, int nsample, int c, const int *idx, const float *grad_output,
+                             float *grad_input1, float *grad_input2, tgn_stream_t stream);
+int tgn_aggregation_forward(int n, int nsample, int c, int w_c, const float *input, const float *position,
+                            const float *weight, const int *idx, float *output, tgn_stream_t stream);
+int tgn_aggregation_backward(int n, int nsample, int c, int w_c, const float *input, const float *position,
+                             const float *weight, const int *idx, const float *grad_output, float *grad_input,
+                             float *grad_position, float *grad_weight, tgn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 3. pointnet2_utils operators as single kernels (dense (B,N,*) layout).
+ * ---------------------------------------------------------------------------------------- */
+/* square_distance (pointnet2_utils.py:20-41) for 3-D points: src (B,N,3), dst (B,M,3) -> out (B,N,M). */
+int tgn_square_distance(int B, int N, int M, const float *src, const float *dst, float *out, tgn_stream_t stream);
+/*
+ * query_ball_point (pointnet2_utils.py:120-144): first nsample indices in ascending index order with
+ * square_distance(new_xyz, xyz) <= r2 (expanded-form arithmetic of pointnet2_utils.py:20-41), padded
+ * with the first hit; a row without any hit is filled with N.  idx: (B,S,nsample) int32 or int64.
+ * workspace: tgn_ball_query_workspace_bytes(B,N,S) bytes of device scratch (may be NULL if 0).
+ */
+size_t tgn_ball_query_workspace_bytes(int B, int N, int S);
+int tgn_ball_query(int B, int N, int S, int nsample, float r2, const float *xyz, const float *new_xyz, void *idx,
+                   int idx_is_int64, void *workspace, size_t workspace_bytes, tgn_stream_t stream);
+/*
+ * Grouping of sample_and_group (pointnet2_utils.py:162-169, xyz_first=1: [xyz[idx]-new_xyz, points[idx]])
+ * and of PointNetSetAbstractionMsg (pointnet2_utils.py:281-285, xyz_first=0: [points[idx], xyz[idx]-new_xyz]).
+ * points (B,N,D) may be NULL (D ignored).  out: (B,S,K,3+D).
+ */
+int tgn_group_points(int B, int N, int S, int K, int D, const float *xyz, const float *new_xyz, const float *points,
+                     const void *idx, int idx_is_int64, int xyz_first, float *out, tgn_stream_t stream);
+/* index_points (pointnet2_utils.py:44-61): out[b,j,:] = points[b, idx[b,j], :], idx flattened to (B,M). */
+int tgn_gather_points(int B, int N, int M, int C, const float *points, const void *idx, int idx_is_int64, float *out,
+                      tgn_stream_t stream);
+/* backward of tgn_gather_points / tgn_group_points feature part: grad_points[b, idx[b,j], :] += grad_out[b,j,:] */
+int tgn_scatter_add_points(int B, int N, int M, int C, const float *grad_out, const void *idx, int idx_is_int64,
+                           float *grad_points, tgn_stream_t stream);
+/*
+ * three nearest support points (pointnet2_utils.py:333-335): xyz1 (B,N,3) queries, xyz2 (B,S,3) support;
+ * dist (B,N,3) expanded-form squared distances ascending by (dist, index); idx int32 or int64.
+ */
+int tgn_three_nn(int B, int N, int S, const float *xyz1, const float *xyz2, float *dist, void *idx, int idx_is_int64,
+                 tgn_stream_t stream);
+/* inverse-distance weighted sum (pointnet2_utils.py:337-340); weight (B,N,3) is also written if non-NULL. */
+int tgn_three_interpolate(int B, int N, int S, int C, const float *points2, const float *dist, const void *idx,
+                          int idx_is_int64, float *out, float *weight, tgn_stream_t stream);
+/*
+ * tgn_group_points / tgn_gather_points skip rows whose index is outside [0,N) (the reference's advanced
+ * indexing would raise there, e.g. an empty ball yields index N) and latch a device-side flag.  This
+ * returns 1 and clears the flag if that happened since the last call; it synchronises `stream`.
+ */
+int tgn_take_index_error(tgn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGN_POINTOPS_H */

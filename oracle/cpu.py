@@ -66,8 +66,9 @@ def opt_n_threads(n):
 def furthestsampling(xyz, offset, new_offset, mode=0, block_size=0):
     """pointops.furthestsampling (pointops.py:10-27): xyz (n,3), cumulative offsets -> idx (m,) int32.
 
+    mode bit 0 = FMA-chain arithmetic, bit 1 = shared-memory-tree tie order of sampling_cuda_kernel.cu.
     mode 0: canonical (torch-CPU arithmetic of pointnet2_utils.py:103-118, start index 0);
-    mode 1: "cuda-compat" (FMA chain + shared-memory tree tie order of sampling_cuda_kernel.cu)."""
+    mode 3: "cuda-compat"; mode 2: the reference source without contraction (== oracle/_ref)."""
     xyz, offset, new_offset = _f32(xyz), _i32(offset), _i32(new_offset)
     b = offset.shape[0]
     m = int(new_offset[-1]) if b else 0

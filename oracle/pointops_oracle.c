@@ -77,7 +77,7 @@ static inline float min_nn(float d, float t) { return (d < t) ? d : t; }
  * and first-index tie-break of U:103-118.
  */
 static void fps_segment_canonical(const float *xyz, int start_n, int end_n, int start_m, int end_m,
-                                  float *tmp, int *idx) {
+                                  float *tmp, int *idx, int use_fma) {
     if (end_m <= start_m) return;
     idx[start_m] = start_n;
     int old = start_n;
@@ -86,7 +86,8 @@ static void fps_segment_canonical(const float *xyz, int start_n, int end_n, int 
         int besti = start_n;
         float best = -1.0f;
         for (int k = start_n; k < end_n; k++) {
-            float d = fps_dist_canonical(x1, y1, z1, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2]);
+            float d = use_fma ? fps_dist_fma(x1, y1, z1, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2])
+                              : fps_dist_canonical(x1, y1, z1, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2]);
             float d2 = min_nn(d, tmp[k]);
             tmp[k] = d2;
             if (d2 > best) { best = d2; besti = k; }
@@ -102,7 +103,7 @@ static void fps_segment_canonical(const float *xyz, int start_n, int end_n, int 
  * (:64-123) where __update (:5-10) keeps the LOWER slot on ties.
  */
 static void fps_segment_cuda_compat(const float *xyz, int start_n, int end_n, int start_m, int end_m,
-                                    float *tmp, int *idx, int block_size, int old0) {
+                                    float *tmp, int *idx, int block_size, int old0, int use_fma) {
     if (end_m <= start_m) return;
     float *dists = (float *)malloc(sizeof(float) * (size_t)block_size);
     int *dists_i = (int *)malloc(sizeof(int) * (size_t)block_size);
@@ -114,7 +115,8 @@ static void fps_segment_cuda_compat(const float *xyz, int start_n, int end_n, in
             int besti = start_n;
             float best = -1.0f;
             for (int k = start_n + tid; k < end_n; k += block_size) {
-                float d = fps_dist_fma(x1, y1, z1, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2]);
+                float d = use_fma ? fps_dist_fma(x1, y1, z1, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2])
+                                  : fps_dist_canonical(x1, y1, z1, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2]);
                 float d2 = min_nn(d, tmp[k]);
                 tmp[k] = d2;
                 besti = d2 > best ? k : besti;
@@ -141,8 +143,11 @@ static void fps_segment_cuda_compat(const float *xyz, int start_n, int end_n, in
 /*
  * pointops.furthestsampling (PY:10-27 -> sampling_cuda.cpp:8-16 -> sampling_cuda_kernel.cu:14-171).
  * xyz (n,3) packed, offset/new_offset (b) cumulative ends, idx (new_offset[b-1]) out.
- * mode 0 = canonical (torch-CPU arithmetic, first-index ties), 1 = cuda-compat.
- * block_size: only for mode 1; 0 -> opt_n_threads(n_max) like the reference launcher.
+ * mode bit 0: arithmetic -- 0 = unfused ((dx*dx)+(dy*dy))+(dz*dz), 1 = FMA chain (nvcc-style contraction);
+ * mode bit 1: tie order -- 0 = first index, 2 = the reference's shared-memory tree.
+ *   mode 0 = canonical (torch-CPU semantics); mode 3 = "cuda-compat"; mode 2 = the reference source
+ *   compiled without contraction (what oracle/_ref is, see oracle/Makefile).
+ * block_size: only with the tree; 0 -> opt_n_threads(n_max) like the reference launcher.
  * Clouds are independent; with OpenMP they are spread over the host cores.
  */
 ORACLE_API int oracle_furthestsampling(int b, const float *xyz, const int *offset, const int *new_offset,
@@ -154,7 +159,7 @@ ORACLE_API int oracle_furthestsampling(int b, const float *xyz, const int *offse
         int c = offset[i] - offset[i - 1];
         if (c > n_max) n_max = c;
     }
-    if (mode == 1 && block_size <= 0) block_size = oracle_opt_n_threads(n_max);
+    if ((mode & 2) && block_size <= 0) block_size = oracle_opt_n_threads(n_max);
     float *tmp = (float *)malloc(sizeof(float) * (size_t)(n_total > 0 ? n_total : 1));
     for (int i = 0; i < n_total; i++) tmp[i] = 1e10f; /* PY:22 */
 #pragma omp parallel for schedule(dynamic, 1)
@@ -163,11 +168,11 @@ ORACLE_API int oracle_furthestsampling(int b, const float *xyz, const int *offse
         int end_n = offset[bid];
         int start_m = bid == 0 ? 0 : new_offset[bid - 1];
         int end_m = new_offset[bid];
-        if (mode == 0)
-            fps_segment_canonical(xyz, start_n, end_n, start_m, end_m, tmp, idx);
+        if (!(mode & 2))
+            fps_segment_canonical(xyz, start_n, end_n, start_m, end_m, tmp, idx, mode & 1);
         else
             fps_segment_cuda_compat(xyz, start_n, end_n, start_m, end_m, tmp, idx, block_size,
-                                    bid == 0 ? 0 : offset[bid - 1]);
+                                    bid == 0 ? 0 : offset[bid - 1], mode & 1);
     }
     free(tmp);
     return 0;

@@ -210,7 +210,8 @@ def main():
     offset = np.array([1500, 2200, 2200 + 236], dtype=np.int32)
     new_offset = np.array([375, 550, 609], dtype=np.int32)
     fidx = O.furthestsampling(pxyz, offset, new_offset)
-    fidx_cc = O.furthestsampling(pxyz, offset, new_offset, mode=1)
+    fidx_cc = O.furthestsampling(pxyz, offset, new_offset, mode=3)
+    reg["p_fps_idx_tree"] = O.furthestsampling(pxyz, offset, new_offset, mode=2)
     reg["p_xyz"], reg["p_offset"], reg["p_new_offset"] = pxyz, offset, new_offset
     reg["p_fps_idx"], reg["p_fps_idx_cudacompat"] = fidx, fidx_cc
     q = pxyz[fidx.astype(np.int64)]

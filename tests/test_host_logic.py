@@ -1,0 +1,94 @@
+"""CPU: host-side logic -- sharding arithmetic, drop-in import layout, module/state_dict compatibility."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, REPO
+from toothgroupnetwork_amd import sharding
+
+
+@pytest.mark.parametrize("n,world", [(0, 1), (1, 8), (7, 8), (8, 8), (9, 8), (1800, 8), (1801, 4), (5, 2)])
+def test_shard_partition(n, world):
+    for mode in ("contiguous", "round_robin"):
+        parts = [sharding.shard_indices(n, r, world, mode) for r in range(world)]
+        flat = sorted(i for p in parts for i in p)
+        assert flat == list(range(n))
+        sizes = [len(p) for p in parts]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_range(4, 4, 4)
+    with pytest.raises(ValueError):
+        sharding.shard_indices(4, 0, 2, "nope")
+
+
+def test_gather_metrics_single_process():
+    m = sharding.gather_metrics([1.0, 2.0, 3.0])
+    assert m.shape == (1, 3) and m.dtype == torch.float64
+    res = sharding.run_sharded(list(range(10)), lambda i: {"sum": i, "sq": i * i}, 0, 1)
+    assert res["count"] == 10 and res["sum"] == 45 and res["sq"] == 285
+
+
+def test_dropin_modules_share_parameter_names_with_reference_state_dict():
+    """state_dicts written by the reference's modules load into ours (same names and shapes)."""
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    sd = torch.load(os.path.join(GOLDEN, "module_weights.pt"))
+    sa = U.PointNetSetAbstractionMsg(128, [0.1, 0.2], [8, 16], 6, [[16, 24], [16, 32]])
+    ssg = U.PointNetSetAbstraction(64, 0.2, 16, 6 + 3, [16, 32], False)
+    fp = U.PointNetFeaturePropagation(56 + 6, [32, 16])
+    sa.load_state_dict(sd["sa"], strict=True)
+    ssg.load_state_dict(sd["ssg"], strict=True)
+    fp.load_state_dict(sd["fp"], strict=True)
+
+
+def test_public_api_surface():
+    from external_libs.pointnet2_utils import pointnet2_utils as U
+    from external_libs.pointops.functions import pointops as P
+    import pointops_cuda
+    for n in ["furthestsampling", "knnquery", "grouping", "queryandgroup", "subtraction", "aggregation",
+              "interpolation", "interpolation2", "FurthestSampling", "KNNQuery", "Grouping", "Subtraction",
+              "Aggregation", "Interpolation"]:
+        assert hasattr(P, n), n
+    for n in ["timeit", "pc_normalize", "square_distance", "index_points", "farthest_point_sample",
+              "farthest_point_sample_np", "query_ball_point", "sample_and_group", "sample_and_group_all",
+              "PointNetSetAbstraction", "PointNetSetAbstractionMsg", "PointNetFeaturePropagation"]:
+        assert hasattr(U, n), n
+    for n in ["knnquery_cuda", "furthestsampling_cuda", "grouping_forward_cuda", "grouping_backward_cuda",
+              "interpolation_forward_cuda", "interpolation_backward_cuda", "subtraction_forward_cuda",
+              "subtraction_backward_cuda", "aggregation_forward_cuda", "aggregation_backward_cuda"]:
+        assert hasattr(pointops_cuda, n), n  # pointops_api.cpp:13-22
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="reference checkout not present")
+def test_reference_models_import_our_operators_unchanged():
+    """sys.path = [repo, reference]: the reference's model files resolve external_libs.* to THIS repo's ops."""
+    code = (
+        "import sys; sys.dont_write_bytecode=True; sys.path[:0]=[%r, '/root/reference']\n"
+        "import models.modules.pointnet_pp as m\n"
+        "import toothgroupnetwork_amd.pointnet2_utils as U\n"
+        "assert m.PointNetSetAbstractionMsg is U.PointNetSetAbstractionMsg\n"
+        "net = m.get_model()\n"
+        "assert type(net.sa1) is U.PointNetSetAbstractionMsg and type(net.fp1) is U.PointNetFeaturePropagation\n"
+        "import external_libs.scheduler.scheduler_factory as sf\n"
+        "assert sf.__file__.startswith('/root/reference')\n"
+        "from external_libs.pointops.functions import pointops\n"
+        "import toothgroupnetwork_amd.pointops as P\n"
+        "assert pointops.queryandgroup is P.queryandgroup\n"
+        "print('ok')\n" % REPO)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp",
+                         env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_synthetic_scans_have_the_documented_density():
+    from toothgroupnetwork_amd import synth
+    pts = synth.arch_cloud(24000, seed=0)
+    assert pts.shape == (24000, 6) and pts.dtype == np.float32
+    assert np.abs(pts[:, :3]).max() <= 1.2
+    np.testing.assert_allclose(np.linalg.norm(pts[:, 3:], axis=1), 1.0, atol=1e-4)
+    d = ((pts[:200, None, :3] - pts[None, :, :3]) ** 2).sum(-1)
+    per_ball = (d <= 0.05 ** 2).sum(1).mean()
+    assert 20 <= per_ball <= 90, per_ball  # r=0.05 balls hold a few dozen points

@@ -1,0 +1,358 @@
+// fps.hip -- farthest point sampling for gfx950.
+//
+// Replaces pointops.furthestsampling (external_libs/pointops/functions/pointops.py:10-27 ->
+// src/sampling/sampling_cuda_kernel.cu:14-171) and the dense adaptor farthest_point_sample
+// (external_libs/pointnet2_utils/pointnet2_utils.py:64-98).
+//
+// Design (DESIGN.md "FPS"): one workgroup per cloud.  The cloud's coordinates and its running
+// minimum distance live in VGPRs for the whole kernel (P points per lane, statically indexed),
+// so an iteration touches no HBM at all: the reference re-streams 20 B per point per iteration.
+// Each iteration is: P fused update/argmax steps per lane -> 64-lane DPP max on a packed
+// (distance bits, ~tie key) 64-bit word -> one LDS slot per wave -> ONE barrier -> 16-lane DPP
+// max -> the winner's coordinates are fetched with a wave-uniform load.
+//
+// The packed key makes the argmax a plain unsigned max: distances are non-negative floats, whose
+// bit patterns order like unsigned integers; the low word is (0xFFFFFFFF - tie_key) so the
+// smallest tie key wins among equal distances.
+//   canonical mode : tie_key = point index (first index wins, torch-CPU semantics of
+//                    pointnet2_utils.py:103-118) and d = ((dx*dx)+(dy*dy))+(dz*dz), no fusion.
+//   TGN_FPS_TREE_TIES: tie_key orders points the way the reference's shared-memory tree does
+//                    (sampling_cuda_kernel.cu:5-10,64-123: lower slot wins => bit-reversed thread id,
+//                    then lowest index within a thread).
+//   TGN_FPS_FMA    : d = fma(dz,dz,fma(dy,dy,dx*dx)), the contraction nvcc applies to :54.
+//   Both together = "cuda-compat"; TREE_TIES alone = the reference source compiled without contraction,
+//   which is what oracle/_ref is and what the GPU tests pin this kernel against.
+#include "tgn_common.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+namespace tgn {
+
+struct FpsArgs {
+    const float *xyz;
+    const int *offset;      // nullptr => dense batch: cloud i = [i*n_uniform, (i+1)*n_uniform)
+    const int *new_offset;
+    int n_uniform, m_uniform;
+    void *idx;
+    float *new_xyz;         // optional (m,3)
+    float *tmp;             // only used by the streaming kernel
+    int flags;
+    int ref_log2_block;     // log2 of the reference's block size (cuda-compat tie order)
+};
+
+__device__ __forceinline__ void fps_segment(const FpsArgs &a, int bid, int &start_n, int &n, int &start_m, int &m) {
+    if (a.offset) {
+        start_n = bid ? a.offset[bid - 1] : 0;
+        n = a.offset[bid] - start_n;
+        start_m = bid ? a.new_offset[bid - 1] : 0;
+        m = a.new_offset[bid] - start_m;
+    } else {
+        start_n = bid * a.n_uniform;
+        n = a.n_uniform;
+        start_m = bid * a.m_uniform;
+        m = a.m_uniform;
+    }
+}
+
+__device__ __forceinline__ void fps_emit(const FpsArgs &a, int row, int start_n, int k_local, float x, float y,
+                                         float z) {
+    long long v = (a.flags & TGN_FPS_LOCAL_INDEX) ? (long long)k_local : (long long)start_n + k_local;
+    if (a.flags & TGN_FPS_INDEX64)
+        ((long long *)a.idx)[row] = v;
+    else
+        ((int *)a.idx)[row] = (int)v;
+    if (a.new_xyz) {
+        a.new_xyz[(size_t)row * 3 + 0] = x;
+        a.new_xyz[(size_t)row * 3 + 1] = y;
+        a.new_xyz[(size_t)row * 3 + 2] = z;
+    }
+}
+
+// cuda-compat tie order: (bit-reversed reference thread id, position within that thread).
+__device__ __forceinline__ unsigned compat_key(int k, int log2bs) {
+    unsigned t = (unsigned)k & ((1u << log2bs) - 1u);
+    unsigned r = log2bs ? (__brev(t) >> (32 - log2bs)) : 0u;
+    return (r << 21) | ((unsigned)k >> log2bs);
+}
+__device__ __forceinline__ int compat_index(unsigned key, int log2bs) {
+    unsigned r = key >> 21;
+    unsigned t = log2bs ? (__brev(r) >> (32 - log2bs)) : 0u;
+    return (int)(((key & 0x1FFFFFu) << log2bs) | t);
+}
+
+__device__ __forceinline__ unsigned long long fps_pack(float best, unsigned key) {
+    // best < 0 <=> this lane saw no real point: 0 loses against every real candidate
+    return best < 0.0f ? 0ull : pack64(__float_as_uint(best), 0xFFFFFFFFu - key);
+}
+
+// Block-wide max of the packed keys; one barrier; result uniform in every wave.
+template <int NW>
+__device__ __forceinline__ unsigned long long fps_block_max(unsigned long long pk, unsigned long long (*slots)[NW],
+                                                            int parity, int wave, int lane) {
+    unsigned long long wmax = wave_max_u64(pk);
+    if constexpr (NW == 1) {
+        return wmax;
+    } else {
+        if (lane == 0) slots[parity][wave] = wmax;
+        __syncthreads();
+        unsigned long long v = lane < NW ? slots[parity][lane] : 0ull;
+        return row0_max_u64(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Register-resident kernel: n <= NT*P.
+// ---------------------------------------------------------------------------------------------
+template <int NT, int P, int MODE>
+__global__ __launch_bounds__(NT) void fps_resident_kernel(FpsArgs a) {
+    constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0;
+    constexpr int NW = NT / kWave;
+    __shared__ unsigned long long slots[2][NW];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid / kWave;
+    int start_n, n, start_m, m;
+    fps_segment(a, blockIdx.x, start_n, n, start_m, m);
+    if (m <= 0) return;
+    const float *__restrict__ base = a.xyz + (size_t)start_n * 3;
+
+    float x[P], y[P], z[P], d[P];
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+        const int k = s * NT + tid;
+        const bool valid = k < n;
+        x[s] = valid ? base[(size_t)k * 3 + 0] : 0.0f;
+        y[s] = valid ? base[(size_t)k * 3 + 1] : 0.0f;
+        z[s] = valid ? base[(size_t)k * 3 + 2] : 0.0f;
+        d[s] = valid ? 1e10f : -1.0f;  // pointops.py:22 ; padding can never win (real distances are >= 0)
+    }
+
+    float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+    if (n > 0) {
+        qx = base[0];
+        qy = base[1];
+        qz = base[2];
+    }
+    if (tid == 0) fps_emit(a, start_m, start_n, 0, qx, qy, qz);  // sampling_cuda_kernel.cu:39
+
+    for (int j = 1; j < m; ++j) {
+        float best = -1.0f;
+        unsigned bkey = 0;
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+            const float dx = x[s] - qx, dy = y[s] - qy, dz = z[s] - qz;
+            const float dd = FMA ? dist_direct_fma(dx, dy, dz) : dist_direct_nofma(dx, dy, dz);
+            const float nd = vmin_f32(dd, d[s]);  // min(d, tmp[k]) sampling_cuda_kernel.cu:55
+            d[s] = nd;
+            if constexpr (TREE) {
+                const unsigned key = compat_key(s * NT + tid, a.ref_log2_block);
+                const bool take = nd > best || (nd == best && key < bkey);
+                best = take ? nd : best;
+                bkey = take ? key : bkey;
+            } else {
+                // ascending s == ascending point index within the lane; strict '>' keeps the first
+                const bool take = nd > best;
+                best = take ? nd : best;
+                bkey = take ? (unsigned)s : bkey;
+            }
+        }
+        if constexpr (!TREE) bkey = bkey * NT + tid;
+        const unsigned long long bmax = fps_block_max<NW>(fps_pack(best, bkey), slots, j & 1, wave, lane);
+        const unsigned key = 0xFFFFFFFFu - (unsigned)bmax;
+        int k = bmax == 0ull ? 0 : (TREE ? compat_index(key, a.ref_log2_block) : (int)key);
+        k = __builtin_amdgcn_readfirstlane(k);
+        if (n > 0) {
+            qx = base[(size_t)k * 3 + 0];
+            qy = base[(size_t)k * 3 + 1];
+            qz = base[(size_t)k * 3 + 2];
+        }
+        if (tid == 0) fps_emit(a, start_m + j, start_n, k, qx, qy, qz);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Streaming fallback for clouds larger than the register file of one CU: coordinates and the
+// running minimum are re-read from memory (L2 / Infinity Cache resident) every iteration, as the
+// reference does, but with the wave-reduced argmax and one barrier per iteration.
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(1024) void fps_streaming_kernel(FpsArgs a) {
+    constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0;
+    constexpr int NT = 1024, NW = NT / kWave;
+    __shared__ unsigned long long slots[2][NW];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid / kWave;
+    int start_n, n, start_m, m;
+    fps_segment(a, blockIdx.x, start_n, n, start_m, m);
+    if (m <= 0) return;
+    const float *__restrict__ base = a.xyz + (size_t)start_n * 3;
+    float *__restrict__ tmp = a.tmp + start_n;
+    for (int k = tid; k < n; k += NT) tmp[k] = 1e10f;
+
+    float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+    if (n > 0) {
+        qx = base[0];
+        qy = base[1];
+        qz = base[2];
+    }
+    if (tid == 0) fps_emit(a, start_m, start_n, 0, qx, qy, qz);
+
+    for (int j = 1; j < m; ++j) {
+        float best = -1.0f;
+        unsigned bkey = 0;
+        for (int k = tid; k < n; k += NT) {
+            const float dx = base[(size_t)k * 3 + 0] - qx, dy = base[(size_t)k * 3 + 1] - qy,
+                        dz = base[(size_t)k * 3 + 2] - qz;
+            const float dd = FMA ? dist_direct_fma(dx, dy, dz) : dist_direct_nofma(dx, dy, dz);
+            const float nd = vmin_f32(dd, tmp[k]);
+            tmp[k] = nd;
+            const unsigned key = TREE ? compat_key(k, a.ref_log2_block) : (unsigned)k;
+            const bool take = nd > best || (TREE && nd == best && key < bkey);
+            best = take ? nd : best;
+            bkey = take ? key : bkey;
+        }
+        const unsigned long long bmax = fps_block_max<NW>(fps_pack(best, bkey), slots, j & 1, wave, lane);
+        const unsigned key = 0xFFFFFFFFu - (unsigned)bmax;
+        int k = bmax == 0ull ? 0 : (TREE ? compat_index(key, a.ref_log2_block) : (int)key);
+        k = __builtin_amdgcn_readfirstlane(k);
+        if (n > 0) {
+            qx = base[(size_t)k * 3 + 0];
+            qy = base[(size_t)k * 3 + 1];
+            qz = base[(size_t)k * 3 + 2];
+        }
+        if (tid == 0) fps_emit(a, start_m + j, start_n, k, qx, qy, qz);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side: pick the (threads, points-per-lane) shape whose capacity covers the largest cloud.
+// ---------------------------------------------------------------------------------------------
+struct FpsConfig {
+    int nt, p;
+};
+
+// Ordered by capacity.  Small clouds use few waves (no cross-wave hand-off at NT=64).
+#define TGN_FPS_CONFIGS(X) \
+    X(64, 1) X(64, 2) X(64, 4) X(64, 8) X(64, 16) X(256, 8) X(256, 16) X(512, 16) X(512, 24) X(512, 32) \
+    X(1024, 24) X(512, 48) X(512, 56)
+
+static const FpsConfig kConfigs[] = {
+#define X(NT_, P_) {NT_, P_},
+    TGN_FPS_CONFIGS(X)
+#undef X
+};
+constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
+
+static int fps_capacity() {
+    int c = 0;
+    for (int i = 0; i < kNumConfigs; ++i) c = kConfigs[i].nt * kConfigs[i].p > c ? kConfigs[i].nt * kConfigs[i].p : c;
+    return c;
+}
+
+static bool fps_pick(int n_max, FpsConfig &out) {
+    // experiments: TGN_FPS_CONFIG="NT,P" forces an instantiated shape when it is large enough
+    if (const char *e = getenv("TGN_FPS_CONFIG")) {
+        int nt = 0, p = 0;
+        if (sscanf(e, "%d,%d", &nt, &p) == 2)
+            for (int i = 0; i < kNumConfigs; ++i)
+                if (kConfigs[i].nt == nt && kConfigs[i].p == p && nt * p >= n_max) {
+                    out = kConfigs[i];
+                    return true;
+                }
+    }
+    int best = -1;
+    for (int i = 0; i < kNumConfigs; ++i) {
+        const int cap = kConfigs[i].nt * kConfigs[i].p;
+        if (cap >= n_max && (best < 0 || cap < kConfigs[best].nt * kConfigs[best].p)) best = i;
+    }
+    if (best < 0) return false;
+    out = kConfigs[best];
+    return true;
+}
+
+template <int MODE>
+static int fps_launch(int b, int n_max, const FpsArgs &a, hipStream_t stream) {
+    FpsConfig cfg;
+    if (fps_pick(n_max, cfg)) {
+#define X(NT_, P_)                                                                                      \
+    if (cfg.nt == NT_ && cfg.p == P_) {                                                                 \
+        hipLaunchKernelGGL((fps_resident_kernel<NT_, P_, MODE>), dim3(b), dim3(NT_), 0, stream, a);   \
+        return check_launch("fps_resident_kernel");                                                     \
+    }
+        TGN_FPS_CONFIGS(X)
+#undef X
+    }
+    if (!a.tmp) {
+        set_error("tgn_furthestsampling: cloud of %d points exceeds the resident capacity (%d) and tmp is NULL",
+                  n_max, fps_capacity());
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    hipLaunchKernelGGL((fps_streaming_kernel<MODE>), dim3(b), dim3(1024), 0, stream, a);
+    return check_launch("fps_streaming_kernel");
+}
+
+static int ilog2_floor(int v) {
+    int l = 0;
+    while ((1 << (l + 1)) <= v) ++l;
+    return l;
+}
+
+// cuda_utils.h:11-14 opt_n_threads: largest power of two <= n, clamped to [1,1024]
+static int ref_log2_block(int n_max) {
+    if (n_max < 1) return 0;
+    int l = ilog2_floor(n_max);
+    return l > 10 ? 10 : l;
+}
+
+static int fps_dispatch(int b, int n_max, FpsArgs a, hipStream_t stream) {
+    if (b <= 0) return TGN_OK;
+    if (!a.xyz || !a.idx) {
+        set_error("tgn_furthestsampling: null xyz/idx");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    if (n_max < 0) {
+        set_error("tgn_furthestsampling: negative n_max");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    a.ref_log2_block = ref_log2_block(n_max);
+    switch (a.flags & (TGN_FPS_FMA | TGN_FPS_TREE_TIES)) {
+        case 0: return fps_launch<0>(b, n_max, a, stream);
+        case TGN_FPS_FMA: return fps_launch<1>(b, n_max, a, stream);
+        case TGN_FPS_TREE_TIES: return fps_launch<2>(b, n_max, a, stream);
+        default: return fps_launch<3>(b, n_max, a, stream);
+    }
+}
+
+}  // namespace tgn
+
+using namespace tgn;
+
+TGN_API int tgn_fps_resident_capacity(void) { return fps_capacity(); }
+
+TGN_API int tgn_furthestsampling(int b, int n_max, const float *xyz, const int *offset, const int *new_offset,
+                                 float *tmp, void *idx, float *new_xyz, int flags, tgn_stream_t stream) {
+    if (b > 0 && (!offset || !new_offset)) {
+        set_error("tgn_furthestsampling: null offsets");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    FpsArgs a{xyz, offset, new_offset, 0, 0, idx, new_xyz, tmp, flags, 0};
+    return fps_dispatch(b, n_max, a, (hipStream_t)stream);
+}
+
+TGN_API int tgn_furthestsampling_dense(int B, int N, int S, const float *xyz, float *tmp, void *idx, float *new_xyz,
+                                       int flags, tgn_stream_t stream) {
+    if (N < 0 || S < 0) {
+        set_error("tgn_furthestsampling_dense: negative size");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    FpsArgs a{xyz, nullptr, nullptr, N, S, idx, new_xyz, tmp, flags, 0};
+    return fps_dispatch(B, N, a, (hipStream_t)stream);
+}
+
+// Reference ABI (sampling_cuda_kernel.h:13): global int32 indices, canonical arithmetic, default stream.
+TGN_API void furthestsampling_cuda_launcher(int b, int n, const float *xyz, const int *offset, const int *new_offset,
+                                            float *tmp, int *idx) {
+    (void)tgn_furthestsampling(b, n, xyz, offset, new_offset, tmp, idx, nullptr, 0, (tgn_stream_t)default_stream());
+}

@@ -1,0 +1,482 @@
+// gather.hip -- the gather / scatter family (HBM-bound kernels, gfx950).
+//
+//   grouping     fwd/bwd  grouping_cuda_kernel.cu:5-25
+//   interpolation fwd/bwd interpolation_cuda_kernel.cu:5-33
+//   subtraction  fwd/bwd  subtraction_cuda_kernel.cu:5-30
+//   aggregation  fwd/bwd  aggregation_cuda_kernel.cu:5-39
+//   group_points          sample_and_group (pointnet2_utils.py:162-169) / SetAbstractionMsg (:281-285)
+//   gather_points         index_points (pointnet2_utils.py:44-61)
+//   three_interpolate     PointNetFeaturePropagation (pointnet2_utils.py:337-340)
+//
+// The reference uses one thread per output ELEMENT with two integer divisions each; here a block is a
+// (rows x channel-lanes) tile: the gather index is read once per row, lanes run along the contiguous
+// channel axis (coalesced row reads and writes), and there is no per-element division.
+#include "tgn_common.h"
+
+namespace tgn {
+
+struct RowShape {
+    int cx_log2;  // lanes along the channel axis = 1 << cx_log2 (<= 64)
+    int rows_per_block;
+    unsigned blocks;
+};
+
+static RowShape row_shape(long long rows, int c) {
+    int l = 0;
+    while ((1 << l) < c && l < 6) ++l;
+    RowShape s;
+    s.cx_log2 = l;
+    s.rows_per_block = 256 >> l;
+    long long blocks = (rows + s.rows_per_block - 1) / s.rows_per_block;
+    const long long cap = 256LL * 32;  // grid-stride beyond 32 blocks per CU
+    s.blocks = (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+    return s;
+}
+
+#define TGN_ROW_LOOP(rows)                                                                          \
+    const int cx = 1 << cx_log2;                                                                    \
+    const int tx = threadIdx.x & (cx - 1);                                                          \
+    const int ty = threadIdx.x >> cx_log2;                                                          \
+    const int ry = blockDim.x >> cx_log2;                                                           \
+    for (long long r = (long long)blockIdx.x * ry + ty; r < (rows); r += (long long)gridDim.x * ry)
+
+// ---- grouping ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grouping_fwd_kernel(long long rows, int c, int cx_log2,
+                                                            const float *__restrict__ input,
+                                                            const int *__restrict__ idx, float *__restrict__ output) {
+    TGN_ROW_LOOP(rows) {
+        const float *src = input + (size_t)idx[r] * c;
+        float *dst = output + (size_t)r * c;
+        for (int ci = tx; ci < c; ci += cx) dst[ci] = src[ci];
+    }
+}
+
+__global__ __launch_bounds__(256) void grouping_bwd_kernel(long long rows, int c, int cx_log2,
+                                                            const float *__restrict__ grad_output,
+                                                            const int *__restrict__ idx, float *__restrict__ grad_input) {
+    TGN_ROW_LOOP(rows) {
+        float *dst = grad_input + (size_t)idx[r] * c;
+        const float *src = grad_output + (size_t)r * c;
+        for (int ci = tx; ci < c; ci += cx) atomicAdd(dst + ci, src[ci]);
+    }
+}
+
+// ---- interpolation (weighted gather-sum over k neighbours) --------------------------------------
+__global__ __launch_bounds__(256) void interpolation_fwd_kernel(long long rows, int c, int k, int cx_log2,
+                                                                 const float *__restrict__ input,
+                                                                 const int *__restrict__ idx,
+                                                                 const float *__restrict__ weight,
+                                                                 float *__restrict__ output) {
+    TGN_ROW_LOOP(rows) {
+        float *dst = output + (size_t)r * c;
+        for (int ci = tx; ci < c; ci += cx) {
+            float acc = dst[ci];  // the reference accumulates into the (pre-zeroed) output
+            for (int i = 0; i < k; ++i) acc += input[(size_t)idx[r * k + i] * c + ci] * weight[r * k + i];
+            dst[ci] = acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void interpolation_bwd_kernel(long long rows, int c, int k, int cx_log2,
+                                                                 const float *__restrict__ grad_output,
+                                                                 const int *__restrict__ idx,
+                                                                 const float *__restrict__ weight,
+                                                                 float *__restrict__ grad_input) {
+    TGN_ROW_LOOP(rows) {
+        const float *src = grad_output + (size_t)r * c;
+        for (int i = 0; i < k; ++i) {
+            float *dst = grad_input + (size_t)idx[r * k + i] * c;
+            const float w = weight[r * k + i];
+            for (int ci = tx; ci < c; ci += cx) atomicAdd(dst + ci, src[ci] * w);
+        }
+    }
+}
+
+// ---- subtraction --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void subtraction_fwd_kernel(long long rows, int nsample, int c, int cx_log2,
+                                                               const float *__restrict__ input1,
+                                                               const float *__restrict__ input2,
+                                                               const int *__restrict__ idx, float *__restrict__ output) {
+    TGN_ROW_LOOP(rows) {  // r = n_idx * nsample + j
+        const float *a = input1 + (size_t)(r / nsample) * c;
+        const float *b = input2 + (size_t)idx[r] * c;
+        float *dst = output + (size_t)r * c;
+        for (int ci = tx; ci < c; ci += cx) dst[ci] = a[ci] - b[ci];
+    }
+}
+
+__global__ __launch_bounds__(256) void subtraction_bwd_kernel(long long rows, int nsample, int c, int cx_log2,
+                                                               const int *__restrict__ idx,
+                                                               const float *__restrict__ grad_output,
+                                                               float *__restrict__ grad_input1,
+                                                               float *__restrict__ grad_input2) {
+    TGN_ROW_LOOP(rows) {
+        float *g1 = grad_input1 + (size_t)(r / nsample) * c;
+        float *g2 = grad_input2 + (size_t)idx[r] * c;
+        const float *src = grad_output + (size_t)r * c;
+        for (int ci = tx; ci < c; ci += cx) {
+            const float g = src[ci];
+            atomicAdd(g1 + ci, g);
+            atomicAdd(g2 + ci, -g);
+        }
+    }
+}
+
+// ---- aggregation --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void aggregation_fwd_kernel(long long rows, int nsample, int c, int w_c,
+                                                               int cx_log2, const float *__restrict__ input,
+                                                               const float *__restrict__ position,
+                                                               const float *__restrict__ weight,
+                                                               const int *__restrict__ idx, float *__restrict__ output) {
+    TGN_ROW_LOOP(rows) {  // r = n_idx
+        float *dst = output + (size_t)r * c;
+        for (int ci = tx; ci < c; ci += cx) {
+            const int wci = ci % w_c;
+            float acc = dst[ci];
+            for (int j = 0; j < nsample; ++j) {
+                const size_t ii = (size_t)r * nsample + j;
+                acc += (input[(size_t)idx[ii] * c + ci] + position[ii * c + ci]) * weight[ii * w_c + wci];
+            }
+            dst[ci] = acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void aggregation_bwd_kernel(long long rows, int nsample, int c, int w_c,
+                                                               int cx_log2, const float *__restrict__ input,
+                                                               const float *__restrict__ position,
+                                                               const float *__restrict__ weight,
+                                                               const int *__restrict__ idx,
+                                                               const float *__restrict__ grad_output,
+                                                               float *__restrict__ grad_input,
+                                                               float *__restrict__ grad_position,
+                                                               float *__restrict__ grad_weight) {
+    TGN_ROW_LOOP(rows) {
+        for (int ci = tx; ci < c; ci += cx) {
+            const int wci = ci % w_c;
+            const float go = grad_output[(size_t)r * c + ci];
+            for (int j = 0; j < nsample; ++j) {
+                const size_t ii = (size_t)r * nsample + j;
+                const float w = weight[ii * w_c + wci];
+                const size_t in_i = (size_t)idx[ii] * c + ci;
+                atomicAdd(grad_input + in_i, go * w);
+                grad_position[ii * c + ci] = go * w;
+                atomicAdd(grad_weight + ii * w_c + wci, go * (input[in_i] + position[ii * c + ci]));
+            }
+        }
+    }
+}
+
+// ---- pointnet2_utils composites -------------------------------------------------------------------
+template <typename IdxT>
+__global__ __launch_bounds__(256) void group_points_kernel(long long rows, int N, int S, int K, int D, int cx_log2,
+                                                            const float *__restrict__ xyz,
+                                                            const float *__restrict__ new_xyz,
+                                                            const float *__restrict__ points,
+                                                            const IdxT *__restrict__ idx, int xyz_first,
+                                                            float *__restrict__ out, int *__restrict__ err) {
+    const int C = 3 + D;
+    const int xo = xyz_first ? 0 : D;
+    const int fo = xyz_first ? 3 : 0;
+    TGN_ROW_LOOP(rows) {  // r = (b*S + s)*K + j
+        const long long q = r / K;
+        const int b = (int)(q / S);
+        const long long k = (long long)idx[r];
+        if (k < 0 || k >= N) {  // empty ball -> index N: the reference's advanced indexing raises
+            if (tx == 0) atomicOr(err, 1);
+            continue;
+        }
+        const float *p = xyz + ((size_t)b * N + k) * 3;
+        const float *cq = new_xyz + (size_t)q * 3;
+        const float *f = points + ((size_t)b * N + k) * D;
+        float *dst = out + (size_t)r * C;
+        for (int ci = tx; ci < C; ci += cx) {
+            const int cx3 = ci - xo;
+            float v;
+            if (cx3 >= 0 && cx3 < 3)
+                v = p[cx3] - cq[cx3];
+            else
+                v = f[ci - fo];
+            dst[ci] = v;
+        }
+    }
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void gather_points_kernel(long long rows, int N, int M, int C, int cx_log2,
+                                                             const float *__restrict__ points,
+                                                             const IdxT *__restrict__ idx, float *__restrict__ out,
+                                                             int *__restrict__ err) {
+    TGN_ROW_LOOP(rows) {  // r = b*M + j
+        const int b = (int)(r / M);
+        const long long k = (long long)idx[r];
+        if (k < 0 || k >= N) {
+            if (tx == 0) atomicOr(err, 1);
+            continue;
+        }
+        const float *src = points + ((size_t)b * N + k) * C;
+        float *dst = out + (size_t)r * C;
+        for (int ci = tx; ci < C; ci += cx) dst[ci] = src[ci];
+    }
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void scatter_add_points_kernel(long long rows, int N, int M, int C, int cx_log2,
+                                                                  const float *__restrict__ grad_out,
+                                                                  const IdxT *__restrict__ idx,
+                                                                  float *__restrict__ grad_points) {
+    TGN_ROW_LOOP(rows) {
+        const int b = (int)(r / M);
+        const long long k = (long long)idx[r];
+        if (k < 0 || k >= N) continue;
+        float *dst = grad_points + ((size_t)b * N + k) * C;
+        const float *src = grad_out + (size_t)r * C;
+        for (int ci = tx; ci < C; ci += cx) atomicAdd(dst + ci, src[ci]);
+    }
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void three_interpolate_kernel(long long rows, int N, int S, int C, int cx_log2,
+                                                                 const float *__restrict__ points2,
+                                                                 const float *__restrict__ dist,
+                                                                 const IdxT *__restrict__ idx, float *__restrict__ out,
+                                                                 float *__restrict__ weight) {
+    TGN_ROW_LOOP(rows) {  // r = b*N + n
+        const int b = (int)(r / N);
+        // pointnet2_utils.py:337-339: 1/(d + 1e-8), normalised by the row sum
+        const float r0 = 1.0f / (dist[r * 3 + 0] + 1e-8f);
+        const float r1 = 1.0f / (dist[r * 3 + 1] + 1e-8f);
+        const float r2 = 1.0f / (dist[r * 3 + 2] + 1e-8f);
+        const float norm = (r0 + r1) + r2;
+        const float w0 = r0 / norm, w1 = r1 / norm, w2 = r2 / norm;
+        if (weight && tx == 0) {
+            weight[r * 3 + 0] = w0;
+            weight[r * 3 + 1] = w1;
+            weight[r * 3 + 2] = w2;
+        }
+        const float *f0 = points2 + ((size_t)b * S + (long long)idx[r * 3 + 0]) * C;
+        const float *f1 = points2 + ((size_t)b * S + (long long)idx[r * 3 + 1]) * C;
+        const float *f2 = points2 + ((size_t)b * S + (long long)idx[r * 3 + 2]) * C;
+        float *dst = out + (size_t)r * C;
+        for (int ci = tx; ci < C; ci += cx)
+            dst[ci] = ((f0[ci] * w0) + (f1[ci] * w1)) + (f2[ci] * w2);
+    }
+}
+
+// device-side error word for out-of-range gather indices (async; checked by tgn_take_index_error)
+static int *index_error_word() {
+    static int *w = nullptr;
+    if (!w) {
+        if (hipMalloc((void **)&w, sizeof(int)) != hipSuccess) return nullptr;
+        (void)hipMemset(w, 0, sizeof(int));
+    }
+    return w;
+}
+
+}  // namespace tgn
+
+using namespace tgn;
+
+TGN_API int tgn_grouping_forward(int m, int nsample, int c, const float *input, const int *idx, float *output,
+                                 tgn_stream_t stream) {
+    const long long rows = (long long)m * nsample;
+    if (rows <= 0 || c <= 0) return TGN_OK;
+    const RowShape s = row_shape(rows, c);
+    hipLaunchKernelGGL(grouping_fwd_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, c, s.cx_log2, input,
+                       idx, output);
+    return check_launch("grouping_fwd_kernel");
+}
+
+TGN_API int tgn_grouping_backward(int m, int nsample, int c, const float *grad_output, const int *idx,
+                                  float *grad_input, tgn_stream_t stream) {
+    const long long rows = (long long)m * nsample;
+    if (rows <= 0 || c <= 0) return TGN_OK;
+    const RowShape s = row_shape(rows, c);
+    hipLaunchKernelGGL(grouping_bwd_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, c, s.cx_log2,
+                       grad_output, idx, grad_input);
+    return check_launch("grouping_bwd_kernel");
+}
+
+TGN_API int tgn_interpolation_forward(int n, int c, int k, const float *input, const int *idx, const float *weight,
+                                      float *output, tgn_stream_t stream) {
+    if (n <= 0 || c <= 0) return TGN_OK;
+    const RowShape s = row_shape(n, c);
+    hipLaunchKernelGGL(interpolation_fwd_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, c, k,
+                       s.cx_log2, input, idx, weight, output);
+    return check_launch("interpolation_fwd_kernel");
+}
+
+TGN_API int tgn_interpolation_backward(int n, int c, int k, const float *grad_output, const int *idx,
+                                       const float *weight, float *grad_input, tgn_stream_t stream) {
+    if (n <= 0 || c <= 0) return TGN_OK;
+    const RowShape s = row_shape(n, c);
+    hipLaunchKernelGGL(interpolation_bwd_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, c, k,
+                       s.cx_log2, grad_output, idx, weight, grad_input);
+    return check_launch("interpolation_bwd_kernel");
+}
+
+TGN_API int tgn_subtraction_forward(int n, int nsample, int c, const float *input1, const float *input2,
+                                    const int *idx, float *output, tgn_stream_t stream) {
+    const long long rows = (long long)n * nsample;
+    if (rows <= 0 || c <= 0) return TGN_OK;
+    const RowShape s = row_shape(rows, c);
+    hipLaunchKernelGGL(subtraction_fwd_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, nsample, c,
+                       s.cx_log2, input1, input2, idx, output);
+    return check_launch("subtraction_fwd_kernel");
+}
+
+TGN_API int tgn_subtraction_backward(int n, int nsample, int c, const int *idx, const float *grad_output,
+                                     float *grad_input1, float *grad_input2, tgn_stream_t stream) {
+    const long long rows = (long long)n * nsample;
+    if (rows <= 0 || c <= 0) return TGN_OK;
+    const RowShape s = row_shape(rows, c);
+    hipLaunchKernelGGL(subtraction_bwd_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, nsample, c,
+                       s.cx_log2, idx, grad_output, grad_input1, grad_input2);
+    return check_launch("subtraction_bwd_kernel");
+}
+
+TGN_API int tgn_aggregation_forward(int n, int nsample, int c, int w_c, const float *input, const float *position,
+                                    const float *weight, const int *idx, float *output, tgn_stream_t stream) {
+    if (n <= 0 || c <= 0) return TGN_OK;
+    if (w_c <= 0) {
+        set_error("tgn_aggregation_forward: w_c must be positive");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    const RowShape s = row_shape(n, c);
+    hipLaunchKernelGGL(aggregation_fwd_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, nsample,
+                       c, w_c, s.cx_log2, input, position, weight, idx, output);
+    return check_launch("aggregation_fwd_kernel");
+}
+
+TGN_API int tgn_aggregation_backward(int n, int nsample, int c, int w_c, const float *input, const float *position,
+                                     const float *weight, const int *idx, const float *grad_output,
+                                     float *grad_input, float *grad_position, float *grad_weight,
+                                     tgn_stream_t stream) {
+    if (n <= 0 || c <= 0) return TGN_OK;
+    if (w_c <= 0) {
+        set_error("tgn_aggregation_backward: w_c must be positive");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    const RowShape s = row_shape(n, c);
+    hipLaunchKernelGGL(aggregation_bwd_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, nsample,
+                       c, w_c, s.cx_log2, input, position, weight, idx, grad_output, grad_input, grad_position,
+                       grad_weight);
+    return check_launch("aggregation_bwd_kernel");
+}
+
+TGN_API int tgn_group_points(int B, int N, int S, int K, int D, const float *xyz, const float *new_xyz,
+                             const float *points, const void *idx, int idx_is_int64, int xyz_first, float *out,
+                             tgn_stream_t stream) {
+    const long long rows = (long long)B * S * K;
+    if (rows <= 0) return TGN_OK;
+    if (!xyz || !new_xyz || !idx || !out) {
+        set_error("tgn_group_points: null pointer");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    if (!points) D = 0;
+    int *err = index_error_word();
+    const RowShape s = row_shape(rows, 3 + D);
+    if (idx_is_int64)
+        hipLaunchKernelGGL((group_points_kernel<long long>), dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, N,
+                           S, K, D, s.cx_log2, xyz, new_xyz, points ? points : xyz, (const long long *)idx, xyz_first,
+                           out, err);
+    else
+        hipLaunchKernelGGL((group_points_kernel<int>), dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, N, S, K,
+                           D, s.cx_log2, xyz, new_xyz, points ? points : xyz, (const int *)idx, xyz_first, out, err);
+    return check_launch("group_points_kernel");
+}
+
+TGN_API int tgn_gather_points(int B, int N, int M, int C, const float *points, const void *idx, int idx_is_int64,
+                              float *out, tgn_stream_t stream) {
+    const long long rows = (long long)B * M;
+    if (rows <= 0 || C <= 0) return TGN_OK;
+    int *err = index_error_word();
+    const RowShape s = row_shape(rows, C);
+    if (idx_is_int64)
+        hipLaunchKernelGGL((gather_points_kernel<long long>), dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, N,
+                           M, C, s.cx_log2, points, (const long long *)idx, out, err);
+    else
+        hipLaunchKernelGGL((gather_points_kernel<int>), dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, N, M, C,
+                           s.cx_log2, points, (const int *)idx, out, err);
+    return check_launch("gather_points_kernel");
+}
+
+TGN_API int tgn_scatter_add_points(int B, int N, int M, int C, const float *grad_out, const void *idx,
+                                   int idx_is_int64, float *grad_points, tgn_stream_t stream) {
+    const long long rows = (long long)B * M;
+    if (rows <= 0 || C <= 0) return TGN_OK;
+    const RowShape s = row_shape(rows, C);
+    if (idx_is_int64)
+        hipLaunchKernelGGL((scatter_add_points_kernel<long long>), dim3(s.blocks), dim3(256), 0, (hipStream_t)stream,
+                           rows, N, M, C, s.cx_log2, grad_out, (const long long *)idx, grad_points);
+    else
+        hipLaunchKernelGGL((scatter_add_points_kernel<int>), dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, N,
+                           M, C, s.cx_log2, grad_out, (const int *)idx, grad_points);
+    return check_launch("scatter_add_points_kernel");
+}
+
+TGN_API int tgn_three_interpolate(int B, int N, int S, int C, const float *points2, const float *dist,
+                                  const void *idx, int idx_is_int64, float *out, float *weight, tgn_stream_t stream) {
+    const long long rows = (long long)B * N;
+    if (rows <= 0 || C <= 0) return TGN_OK;
+    const RowShape s = row_shape(rows, C);
+    if (idx_is_int64)
+        hipLaunchKernelGGL((three_interpolate_kernel<long long>), dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows,
+                           N, S, C, s.cx_log2, points2, dist, (const long long *)idx, out, weight);
+    else
+        hipLaunchKernelGGL((three_interpolate_kernel<int>), dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, N, S,
+                           C, s.cx_log2, points2, dist, (const int *)idx, out, weight);
+    return check_launch("three_interpolate_kernel");
+}
+
+// Returns 1 (and clears the flag) if any gather since the last call saw an out-of-range index.
+// Synchronises the stream: the host wrapper calls it only where the reference itself would raise.
+extern "C" __attribute__((visibility("default"))) int tgn_take_index_error(tgn_stream_t stream) {
+    int *w = index_error_word();
+    if (!w) return 0;
+    int h = 0;
+    if (hipMemcpyAsync(&h, w, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return 0;
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    if (h) (void)hipMemsetAsync(w, 0, sizeof(int), (hipStream_t)stream);
+    return h;
+}
+
+// ---- reference ABI (default stream, void) ---------------------------------------------------------
+TGN_API void grouping_forward_cuda_launcher(int m, int nsample, int c, const float *input, const int *idx,
+                                            float *output) {
+    (void)tgn_grouping_forward(m, nsample, c, input, idx, output, (tgn_stream_t)default_stream());
+}
+TGN_API void grouping_backward_cuda_launcher(int m, int nsample, int c, const float *grad_output, const int *idx,
+                                             float *grad_input) {
+    (void)tgn_grouping_backward(m, nsample, c, grad_output, idx, grad_input, (tgn_stream_t)default_stream());
+}
+TGN_API void interpolation_forward_cuda_launcher(int n, int c, int k, const float *input, const int *idx,
+                                                 const float *weight, float *output) {
+    (void)tgn_interpolation_forward(n, c, k, input, idx, weight, output, (tgn_stream_t)default_stream());
+}
+TGN_API void interpolation_backward_cuda_launcher(int n, int c, int k, const float *grad_output, const int *idx,
+                                                  const float *weight, float *grad_input) {
+    (void)tgn_interpolation_backward(n, c, k, grad_output, idx, weight, grad_input, (tgn_stream_t)default_stream());
+}
+TGN_API void subtraction_forward_cuda_launcher(int n, int nsample, int c, const float *input1, const float *input2,
+                                               const int *idx, float *output) {
+    (void)tgn_subtraction_forward(n, nsample, c, input1, input2, idx, output, (tgn_stream_t)default_stream());
+}
+TGN_API void subtraction_backward_cuda_launcher(int n, int nsample, int c, const int *idx, const float *grad_output,
+                                                float *grad_input1, float *grad_input2) {
+    (void)tgn_subtraction_backward(n, nsample, c, idx, grad_output, grad_input1, grad_input2,
+                                   (tgn_stream_t)default_stream());
+}
+TGN_API void aggregation_forward_cuda_launcher(int n, int nsample, int c, int w_c, const float *input,
+                                               const float *position, const float *weight, const int *idx,
+                                               float *output) {
+    (void)tgn_aggregation_forward(n, nsample, c, w_c, input, position, weight, idx, output,
+                                  (tgn_stream_t)default_stream());
+}
+TGN_API void aggregation_backward_cuda_launcher(int n, int nsample, int c, int w_c, const float *input,
+                                                const float *position, const float *weight, const int *idx,
+                                                const float *grad_output, float *grad_input, float *grad_position,
+                                                float *grad_weight) {
+    (void)tgn_aggregation_backward(n, nsample, c, w_c, input, position, weight, idx, grad_output, grad_input,
+                                   grad_position, grad_weight, (tgn_stream_t)default_stream());
+}

@@ -1,0 +1,327 @@
+// neighbors.hip -- neighbour searches: ball query, kNN, three_nn (gfx950).
+//
+// ball query : pointnet2_utils.query_ball_point (pointnet2_utils.py:120-144).  The reference builds a
+//              (B,S,N) int64 matrix, masks it and SORTS it over N; here a wave scans the cloud in index
+//              order, 64 candidates per step, and compacts hits with ballot + mbcnt, stopping at nsample.
+// kNN        : pointops.knnquery (pointops.py:30-45 -> knnquery_cuda_kernel.cu:65-108), heap semantics
+//              preserved exactly (insertion history decides the order of equal distances).
+// three_nn   : the square_distance + full sort + [:3] of PointNetFeaturePropagation
+//              (pointnet2_utils.py:333-335) as a running top-3 by (distance, index).
+#include "tgn_common.h"
+
+namespace tgn {
+
+// ---------------------------------------------------------------------------------------------
+// Ball query, brute force in index order.  One wave per query.
+// ---------------------------------------------------------------------------------------------
+template <typename IdxT>
+__global__ __launch_bounds__(256) void ball_query_scan_kernel(int B, int N, int S, int K, float r2,
+                                                               const float *__restrict__ xyz,
+                                                               const float *__restrict__ new_xyz,
+                                                               IdxT *__restrict__ out) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = threadIdx.x / kWave;
+    const long long total = (long long)B * S;
+    for (long long q = (long long)blockIdx.x * (blockDim.x / kWave) + wave_in_block; q < total;
+         q += (long long)gridDim.x * (blockDim.x / kWave)) {
+        const int b = (int)(q / S);
+        const float cx = new_xyz[q * 3 + 0], cy = new_xyz[q * 3 + 1], cz = new_xyz[q * 3 + 2];
+        const float s1 = sumsq3(cx, cy, cz);
+        const float *__restrict__ pts = xyz + (size_t)b * N * 3;
+        IdxT *__restrict__ row = out + q * K;
+        int cnt = 0;
+        int first = N;
+        for (int basek = 0; basek < N && cnt < K; basek += kWave) {
+            const int k = basek + lane;
+            bool hit = false;
+            if (k < N) {
+                const float px = pts[(size_t)k * 3 + 0], py = pts[(size_t)k * 3 + 1], pz = pts[(size_t)k * 3 + 2];
+                const float d = sqdist_expanded(cx, cy, cz, s1, px, py, pz, sumsq3(px, py, pz));
+                hit = !(d > r2);  // reference masks `sqrdists > radius**2` (pointnet2_utils.py:135)
+            }
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                const int pos = cnt + mbcnt(mask);
+                if (hit && pos < K) row[pos] = (IdxT)k;
+                if (cnt == 0) first = basek + __builtin_ctzll(mask);
+                cnt += __popcll(mask);
+            }
+        }
+        if (cnt > K) cnt = K;
+        for (int j = cnt + lane; j < K; j += kWave) row[j] = (IdxT)first;  // pad with the first hit (:138-141)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kNN, exact heap semantics.  One thread per query; the heap lives in LDS (column per thread) so the
+// data-dependent sift never touches scratch memory.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void knn_reheap(float *hd, int *hi, int stride, int k) {
+    // knnquery_cuda_kernel.cu:21-36
+    int root = 0;
+    int child = 1;
+    while (child < k) {
+        if (child + 1 < k && hd[(child + 1) * stride] > hd[child * stride]) child++;
+        if (hd[root * stride] > hd[child * stride]) return;
+        const float td = hd[root * stride];
+        hd[root * stride] = hd[child * stride];
+        hd[child * stride] = td;
+        const int ti = hi[root * stride];
+        hi[root * stride] = hi[child * stride];
+        hi[child * stride] = ti;
+        root = child;
+        child = root * 2 + 1;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void knn_heap_kernel(int b, int m, int nsample, const float *__restrict__ xyz,
+                                                       const float *__restrict__ new_xyz,
+                                                       const int *__restrict__ offset,
+                                                       const int *__restrict__ new_offset, int *__restrict__ idx,
+                                                       float *__restrict__ dist2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *hd = (float *)smem + threadIdx.x;
+    int *hi = (int *)smem + (size_t)nsample * NT + threadIdx.x;
+    const int pt = blockIdx.x * NT + threadIdx.x;
+    if (pt >= m) return;
+    int bt = 0;  // get_bt_idx, knnquery_cuda_kernel.cu:51-62 (bounded by b here)
+    while (bt < b - 1 && !(pt < new_offset[bt])) ++bt;
+    const int start = bt == 0 ? 0 : offset[bt - 1];
+    const int end = offset[bt];
+    const float qx = new_xyz[(size_t)pt * 3 + 0], qy = new_xyz[(size_t)pt * 3 + 1], qz = new_xyz[(size_t)pt * 3 + 2];
+    for (int i = 0; i < nsample; ++i) {
+        hd[i * NT] = 1e10f;
+        hi[i * NT] = start;
+    }
+    float root = 1e10f;
+    for (int i = start; i < end; ++i) {
+        const float x = xyz[(size_t)i * 3 + 0], y = xyz[(size_t)i * 3 + 1], z = xyz[(size_t)i * 3 + 2];
+        const float ex = qx - x, ey = qy - y, ez = qz - z;
+        const float d2 = dist_direct_nofma(ex, ey, ez);  // knnquery_cuda_kernel.cu:96
+        if (d2 < root) {
+            hd[0] = d2;
+            hi[0] = i;
+            knn_reheap(hd, hi, NT, nsample);
+            root = hd[0];
+        }
+    }
+    // heap_sort, knnquery_cuda_kernel.cu:39-48
+    for (int i = nsample - 1; i > 0; --i) {
+        const float td = hd[0];
+        hd[0] = hd[i * NT];
+        hd[i * NT] = td;
+        const int ti = hi[0];
+        hi[0] = hi[i * NT];
+        hi[i * NT] = ti;
+        knn_reheap(hd, hi, NT, i);
+    }
+    for (int i = 0; i < nsample; ++i) {
+        idx[(size_t)pt * nsample + i] = hi[i * NT];
+        dist2[(size_t)pt * nsample + i] = hd[i * NT];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// three_nn.  One thread per query; support points staged through LDS as (x,y,z,|p|^2).
+// ---------------------------------------------------------------------------------------------
+constexpr int kTnnTile = 1024;
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void three_nn_kernel(int B, int N, int S, const float *__restrict__ xyz1,
+                                                        const float *__restrict__ xyz2, float *__restrict__ dist,
+                                                        IdxT *__restrict__ idx) {
+    __shared__ float4 tile[kTnnTile];
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = q < N;
+    float cx = 0.f, cy = 0.f, cz = 0.f, s1 = 0.f;
+    if (active) {
+        const float *c = xyz1 + ((size_t)b * N + q) * 3;
+        cx = c[0];
+        cy = c[1];
+        cz = c[2];
+        s1 = sumsq3(cx, cy, cz);
+    }
+    float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
+    int i0 = 0, i1 = 0, i2 = 0;
+    for (int t0 = 0; t0 < S; t0 += kTnnTile) {
+        const int cnt = min(kTnnTile, S - t0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const float *p = xyz2 + ((size_t)b * S + t0 + i) * 3;
+            const float px = p[0], py = p[1], pz = p[2];
+            tile[i] = make_float4(px, py, pz, sumsq3(px, py, pz));
+        }
+        __syncthreads();
+        if (active) {
+            for (int i = 0; i < cnt; ++i) {
+                const float4 p = tile[i];
+                const float d = sqdist_expanded(cx, cy, cz, s1, p.x, p.y, p.z, p.w);
+                // strict '<' in ascending index order keeps the earlier index on ties
+                if (d < d2) {
+                    const int k = t0 + i;
+                    if (d < d1) {
+                        d2 = d1;
+                        i2 = i1;
+                        if (d < d0) {
+                            d1 = d0;
+                            i1 = i0;
+                            d0 = d;
+                            i0 = k;
+                        } else {
+                            d1 = d;
+                            i1 = k;
+                        }
+                    } else {
+                        d2 = d;
+                        i2 = k;
+                    }
+                }
+            }
+        }
+    }
+    if (active) {
+        const size_t o = ((size_t)b * N + q) * 3;
+        dist[o + 0] = d0;
+        dist[o + 1] = d1;
+        dist[o + 2] = d2;
+        idx[o + 0] = (IdxT)i0;
+        idx[o + 1] = (IdxT)i1;
+        idx[o + 2] = (IdxT)i2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// square_distance (pointnet2_utils.py:20-41), C = 3.  HBM-bound on the (B,N,M) store: a thread owns
+// one dst column for kSqdRows src rows, so every store instruction writes 256 contiguous bytes per wave.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSqdRows = 16;
+
+__global__ __launch_bounds__(256) void square_distance_kernel(int N, int M, const float *__restrict__ src,
+                                                               const float *__restrict__ dst, float *__restrict__ out) {
+    __shared__ float4 rows[kSqdRows];
+    const int b = blockIdx.z;
+    const int i0 = blockIdx.y * kSqdRows;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x < kSqdRows && i0 + threadIdx.x < N) {
+        const float *s = src + ((size_t)b * N + i0 + threadIdx.x) * 3;
+        rows[threadIdx.x] = make_float4(s[0], s[1], s[2], sumsq3(s[0], s[1], s[2]));
+    }
+    __syncthreads();
+    if (j >= M) return;
+    const float *d = dst + ((size_t)b * M + j) * 3;
+    const float dx = d[0], dy = d[1], dz = d[2];
+    const float s2 = sumsq3(dx, dy, dz);
+    const int cnt = min(kSqdRows, N - i0);
+    for (int r = 0; r < cnt; ++r) {
+        const float4 s = rows[r];
+        out[((size_t)b * N + i0 + r) * M + j] = sqdist_expanded(s.x, s.y, s.z, s.w, dx, dy, dz, s2);
+    }
+}
+
+}  // namespace tgn
+
+using namespace tgn;
+
+TGN_API int tgn_square_distance(int B, int N, int M, const float *src, const float *dst, float *out,
+                                tgn_stream_t stream) {
+    if (B <= 0 || N <= 0 || M <= 0) return TGN_OK;
+    if (!src || !dst || !out) {
+        set_error("tgn_square_distance: null pointer");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    if (B > 65535 || (N + kSqdRows - 1) / kSqdRows > 65535) {
+        set_error("tgn_square_distance: shape exceeds the launch grid");
+        return TGN_ERR_UNSUPPORTED;
+    }
+    dim3 grid((M + 255) / 256, (N + kSqdRows - 1) / kSqdRows, B);
+    hipLaunchKernelGGL(square_distance_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, M, src, dst, out);
+    return check_launch("square_distance_kernel");
+}
+
+TGN_API size_t tgn_ball_query_workspace_bytes(int B, int N, int S) {
+    (void)B;
+    (void)N;
+    (void)S;
+    return 0;
+}
+
+TGN_API int tgn_ball_query(int B, int N, int S, int nsample, float r2, const float *xyz, const float *new_xyz,
+                           void *idx, int idx_is_int64, void *workspace, size_t workspace_bytes,
+                           tgn_stream_t stream) {
+    (void)workspace;
+    (void)workspace_bytes;
+    if (B < 0 || N < 0 || S < 0 || nsample < 0) {
+        set_error("tgn_ball_query: negative size");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    const long long total = (long long)B * S;
+    if (total == 0 || nsample == 0) return TGN_OK;
+    if (!xyz || !new_xyz || !idx) {
+        set_error("tgn_ball_query: null pointer");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    const int waves_per_block = 4;
+    long long blocks = (total + waves_per_block - 1) / waves_per_block;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    if (idx_is_int64)
+        hipLaunchKernelGGL((ball_query_scan_kernel<long long>), dim3((unsigned)blocks), dim3(256), 0,
+                           (hipStream_t)stream, B, N, S, nsample, r2, xyz, new_xyz, (long long *)idx);
+    else
+        hipLaunchKernelGGL((ball_query_scan_kernel<int>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           B, N, S, nsample, r2, xyz, new_xyz, (int *)idx);
+    return check_launch("ball_query_scan_kernel");
+}
+
+TGN_API int tgn_knnquery(int b, int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
+                         const int *new_offset, int *idx, float *dist2, tgn_stream_t stream) {
+    if (m <= 0 || nsample <= 0) return TGN_OK;
+    if (b <= 0 || !xyz || !new_xyz || !offset || !new_offset || !idx || !dist2) {
+        set_error("tgn_knnquery: bad argument");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    // heap columns in LDS: nsample * 8 B per thread; keep a block under 64 KiB
+    if (nsample <= 32) {
+        constexpr int NT = 256;
+        hipLaunchKernelGGL((knn_heap_kernel<NT>), dim3((m + NT - 1) / NT), dim3(NT), (size_t)nsample * NT * 8,
+                           (hipStream_t)stream, b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2);
+    } else if (nsample <= 64) {
+        constexpr int NT = 128;
+        hipLaunchKernelGGL((knn_heap_kernel<NT>), dim3((m + NT - 1) / NT), dim3(NT), (size_t)nsample * NT * 8,
+                           (hipStream_t)stream, b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2);
+    } else if (nsample <= 128) {
+        constexpr int NT = 64;
+        hipLaunchKernelGGL((knn_heap_kernel<NT>), dim3((m + NT - 1) / NT), dim3(NT), (size_t)nsample * NT * 8,
+                           (hipStream_t)stream, b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2);
+    } else {
+        set_error("tgn_knnquery: nsample %d > 128 unsupported (the reference's limit is 100)", nsample);
+        return TGN_ERR_UNSUPPORTED;
+    }
+    return check_launch("knn_heap_kernel");
+}
+
+// Reference ABI (knnquery_cuda_kernel.h:13) has no segment count: like the reference's get_bt_idx the
+// search simply walks new_offset until it finds the query's segment, so pass "unbounded".
+TGN_API void knnquery_cuda_launcher(int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
+                                    const int *new_offset, int *idx, float *dist2) {
+    (void)tgn_knnquery(1 << 30, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2,
+                       (tgn_stream_t)default_stream());
+}
+
+TGN_API int tgn_three_nn(int B, int N, int S, const float *xyz1, const float *xyz2, float *dist, void *idx,
+                         int idx_is_int64, tgn_stream_t stream) {
+    if (B <= 0 || N <= 0) return TGN_OK;
+    if (S < 0 || !xyz1 || !xyz2 || !dist || !idx) {
+        set_error("tgn_three_nn: bad argument");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    dim3 grid((N + 255) / 256, B);
+    if (idx_is_int64)
+        hipLaunchKernelGGL((three_nn_kernel<long long>), grid, dim3(256), 0, (hipStream_t)stream, B, N, S, xyz1, xyz2,
+                           dist, (long long *)idx);
+    else
+        hipLaunchKernelGGL((three_nn_kernel<int>), grid, dim3(256), 0, (hipStream_t)stream, B, N, S, xyz1, xyz2, dist,
+                           (int *)idx);
+    return check_launch("three_nn_kernel");
+}

@@ -1,0 +1,525 @@
+"""MI355X implementation of the reference's ``external_libs/pointnet2_utils/pointnet2_utils.py``.
+
+Every public name of the reference module (pointnet2_utils.py:8-352) is provided with the same
+signature, layouts (dense ``(B, N, C)`` / channel-first modules) and dtypes (int64 indices), so
+``models/modules/pointnet_pp.py``, ``tsg_centroid_module.py``, ``tsg_seg_module.py``, ``tsegnet.py``,
+``tgn_loss.py`` and ``tsg_loss.py`` import it unchanged.
+
+What differs is how the work is done: FPS, ball query, the gather+centre+concat of grouping, three_nn
+and three_interpolate are single HIP kernels (include/tgn_pointops.h section 3) instead of chains of
+torch kernels that materialise (B,S,N) matrices and sort them.  The shared MLPs stay nn.Conv/BatchNorm
+layers with the reference's parameter names, so state_dicts are interchangeable.
+"""
+from time import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import as_int, check, lib, ptr, require_cuda, stream
+
+_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd = torch.amp.custom_bwd(device_type="cuda")
+
+
+def timeit(tag, t):
+    print("{}: {}s".format(tag, time() - t))
+    return time()
+
+
+def pc_normalize(pc):
+    centroid = np.mean(pc, axis=0)
+    pc = pc - centroid
+    m = np.max(np.sqrt(np.sum(pc ** 2, axis=1)))
+    pc = pc / m
+    return pc
+
+
+def _f32c(t):
+    t = t if t.dtype == torch.float32 else t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# square_distance
+# ---------------------------------------------------------------------------------------------
+class _SquareDistance3(Function):
+    """square_distance for 3-D points with the reference's exact (torch-CPU) arithmetic:
+    dot = fma(z1,z2,fma(y1,y2,x1*x2)); d = ((-2*dot) + |src|^2) + |dst|^2   (pointnet2_utils.py:20-41)."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, src, dst):
+        src, dst = _f32c(src), _f32c(dst)
+        B, N, _ = src.shape
+        M = dst.shape[1]
+        out = torch.empty(B, N, M, dtype=torch.float32, device=src.device)
+        check(lib().tgn_square_distance(B, N, M, ptr(src), ptr(dst), ptr(out), stream()), "square_distance")
+        ctx.save_for_backward(src, dst)
+        return out
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, g):
+        src, dst = ctx.saved_tensors
+        g = g.float()
+        g_src = g_dst = None
+        if ctx.needs_input_grad[0]:
+            g_src = 2.0 * (src * g.sum(-1, keepdim=True) - torch.matmul(g, dst))
+        if ctx.needs_input_grad[1]:
+            g_dst = 2.0 * (dst * g.sum(-2).unsqueeze(-1) - torch.matmul(g.transpose(1, 2), src))
+        return g_src, g_dst
+
+
+def square_distance(src, dst):
+    """
+    Calculate squared Euclidean distance between each two points.
+    Input:
+        src: source points, [B, N, C]
+        dst: target points, [B, M, C]
+    Output:
+        dist: per-point square distance, [B, N, M]
+    """
+    require_cuda(src, dst)
+    if src.shape[-1] == 3 and dst.shape[-1] == 3:
+        return _SquareDistance3.apply(src, dst)
+    # C != 3 never occurs in the reference models; same formula, generic C (pointnet2_utils.py:38-41)
+    B, N, _ = src.shape
+    _, M, _ = dst.shape
+    dist = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+    dist += torch.sum(src ** 2, -1).view(B, N, 1)
+    dist += torch.sum(dst ** 2, -1).view(B, 1, M)
+    return dist
+
+
+# ---------------------------------------------------------------------------------------------
+# index_points
+# ---------------------------------------------------------------------------------------------
+class _IndexPoints(Function):
+    @staticmethod
+    @_fwd
+    def forward(ctx, points, idx):
+        B, N, C = points.shape
+        M = idx.numel() // B if B else 0
+        out = torch.empty(tuple(idx.shape) + (C,), dtype=torch.float32, device=points.device)
+        check(lib().tgn_gather_points(B, N, M, C, ptr(points), ptr(idx), int(idx.dtype == torch.int64), ptr(out),
+                                      stream()), "gather_points")
+        ctx.shape = (B, N, M, C)
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        B, N, M, C = ctx.shape
+        g = g.contiguous().float()
+        grad = torch.zeros(B, N, C, dtype=torch.float32, device=g.device)
+        check(lib().tgn_scatter_add_points(B, N, M, C, ptr(g), ptr(idx), int(idx.dtype == torch.int64), ptr(grad),
+                                           stream()), "scatter_add_points")
+        return grad, None
+
+
+def index_points(points, idx):
+    """
+    Input:
+        points: input points data, [B, N, C]
+        idx: sample index data, [B, S] (or [B, S, K])
+    Return:
+        new_points:, indexed points data, [B, S, C] (or [B, S, K, C])
+    """
+    require_cuda(points, idx)
+    if idx.dtype not in (torch.int64, torch.int32):
+        idx = idx.long()
+    points = _f32c(points)
+    out = _IndexPoints.apply(points, idx.contiguous())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# farthest point sampling
+# ---------------------------------------------------------------------------------------------
+def _fps_dense(xyz, npoint, want_coords=False, cuda_compat=False):
+    require_cuda(xyz)
+    npoint = as_int(npoint)
+    xyz = _f32c(xyz.detach())
+    B, N, _ = xyz.shape
+    idx = torch.empty(B, npoint, dtype=torch.int64, device=xyz.device)
+    new_xyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=xyz.device) if want_coords else None
+    tmp = None
+    if N > lib().tgn_fps_resident_capacity():
+        tmp = torch.empty(B * N, dtype=torch.float32, device=xyz.device)
+    flags = _lib.FPS_LOCAL_INDEX | _lib.FPS_INDEX64 | (_lib.FPS_CUDA_COMPAT if cuda_compat else 0)
+    check(lib().tgn_furthestsampling_dense(B, N, npoint, ptr(xyz), ptr(tmp), ptr(idx), ptr(new_xyz), flags, stream()),
+          "tgn_furthestsampling_dense")
+    return idx, new_xyz
+
+
+def farthest_point_sample(xyz, npoint):
+    """
+    Input:
+        xyz: pointcloud data, [B, N, 3]
+        npoint: number of samples
+    Return:
+        centroids: sampled pointcloud index, [B, npoint]  (int64, local to each cloud; first sample = point 0
+        as in the CUDA kernel the reference calls, pointnet2_utils.py:87-98 / sampling_cuda_kernel.cu:39)
+    """
+    return _fps_dense(xyz, npoint)[0]
+
+
+def farthest_point_sample_np(xyz, npoint):
+    """numpy in / numpy out variant with a RANDOM first sample (pointnet2_utils.py:103-118).
+
+    The random start is drawn with torch.randint like the reference; the cloud is then rotated so that
+    the start sits at index 0, sampled on the GPU, and the indices are mapped back."""
+    xyz_t = torch.from_numpy(np.ascontiguousarray(xyz, dtype=np.float32))
+    B, N, _ = xyz_t.shape
+    farthest = torch.randint(0, N, (B,), dtype=torch.long)
+    dev = torch.device("cuda")
+    ar = torch.arange(N).unsqueeze(0)
+    perm = (ar + farthest.unsqueeze(1)) % N  # perm[b, 0] = start
+    rolled = torch.gather(xyz_t, 1, perm.unsqueeze(-1).expand(B, N, 3)).to(dev)
+    idx = farthest_point_sample(rolled, npoint).cpu()
+    # NOTE: ties are broken by lowest ROTATED index; identical to the reference whenever distances are distinct.
+    return torch.gather(perm, 1, idx).numpy()
+
+
+# ---------------------------------------------------------------------------------------------
+# ball query and grouping
+# ---------------------------------------------------------------------------------------------
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    if nbytes == 0:
+        return None
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    """
+    Input:
+        radius: local region radius
+        nsample: max sample number in local region
+        xyz: all points, [B, N, 3]
+        new_xyz: query points, [B, S, 3]
+    Return:
+        group_idx: grouped points index, [B, S, nsample]  (int64; first nsample hits in index order,
+        padded with the first hit -- pointnet2_utils.py:120-144)
+    """
+    require_cuda(xyz, new_xyz)
+    nsample = as_int(nsample)
+    xyz, new_xyz = _f32c(xyz.detach()), _f32c(new_xyz.detach())
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    # `sqrdists > radius ** 2`: python evaluates radius**2 in double, torch compares in fp32
+    r2 = float(torch.tensor(float(radius) ** 2, dtype=torch.float32).item())
+    group_idx = torch.empty(B, S, nsample, dtype=torch.int64, device=xyz.device)
+    nbytes = int(lib().tgn_ball_query_workspace_bytes(B, N, S))
+    ws = _workspace(nbytes, xyz.device)
+    check(lib().tgn_ball_query(B, N, S, nsample, r2, ptr(xyz), ptr(new_xyz), ptr(group_idx), 1, ptr(ws), nbytes,
+                               stream()), "tgn_ball_query")
+    return group_idx
+
+
+class _GroupPoints(Function):
+    """out[b,s,k,:] = concat(xyz[b,idx]-new_xyz[b,s], points[b,idx]) (xyz_first) or the Msg order
+    (points first) -- pointnet2_utils.py:162-169 / 281-285 -- in one kernel."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, xyz, new_xyz, points, idx, xyz_first):
+        B, N, _ = xyz.shape
+        _, S, K = idx.shape
+        D = 0 if points is None else points.shape[2]
+        out = torch.empty(B, S, K, 3 + D, dtype=torch.float32, device=xyz.device)
+        check(lib().tgn_group_points(B, N, S, K, D, ptr(xyz), ptr(new_xyz), ptr(points), ptr(idx),
+                                     int(idx.dtype == torch.int64), int(xyz_first), ptr(out), stream()),
+              "group_points")
+        ctx.dims = (B, N, S, K, D, bool(xyz_first))
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        B, N, S, K, D, xyz_first = ctx.dims
+        g = g.contiguous().float()
+        g_rel = (g[..., :3] if xyz_first else g[..., D:]).contiguous()
+        is64 = int(idx.dtype == torch.int64)
+        g_xyz = g_new = g_pts = None
+        if ctx.needs_input_grad[0]:
+            g_xyz = torch.zeros(B, N, 3, dtype=torch.float32, device=g.device)
+            check(lib().tgn_scatter_add_points(B, N, S * K, 3, ptr(g_rel), ptr(idx), is64, ptr(g_xyz), stream()),
+                  "scatter_add_points")
+        if ctx.needs_input_grad[1]:
+            g_new = -g_rel.sum(2)
+        if D and ctx.needs_input_grad[2]:
+            g_f = (g[..., 3:] if xyz_first else g[..., :D]).contiguous()
+            g_pts = torch.zeros(B, N, D, dtype=torch.float32, device=g.device)
+            check(lib().tgn_scatter_add_points(B, N, S * K, D, ptr(g_f), ptr(idx), is64, ptr(g_pts), stream()),
+                  "scatter_add_points")
+        return g_xyz, g_new, g_pts, None, None
+
+
+def group_points(xyz, new_xyz, points, idx, xyz_first=True):
+    """Fused gather + centre + concat. Raises IndexError where the reference's indexing would
+    (an empty ball yields index N, pointnet2_utils.py:136-141)."""
+    require_cuda(xyz, new_xyz, idx)
+    out = _GroupPoints.apply(_f32c(xyz), _f32c(new_xyz), None if points is None else _f32c(points),
+                             idx.contiguous(), bool(xyz_first))
+    return out
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False):
+    """
+    Input:
+        npoint, radius, nsample
+        xyz: input points position data, [B, N, 3]
+        points: input points data, [B, N, D]
+    Return:
+        new_xyz: sampled points position data, [B, npoint, 3]
+        new_points: sampled points data, [B, npoint, nsample, 3+D]   ([rel_xyz, feat] order, :168)
+    """
+    fps_idx = farthest_point_sample(xyz, npoint)  # [B, npoint]
+    new_xyz = index_points(xyz, fps_idx)
+    idx = query_ball_point(radius, nsample, xyz, new_xyz)
+    new_points = group_points(xyz, new_xyz, points, idx, xyz_first=True)
+    if returnfps:
+        grouped_xyz = index_points(xyz, idx)
+        return new_xyz, new_points, grouped_xyz, fps_idx
+    return new_xyz, new_points
+
+
+def sample_and_group_all(xyz, points):
+    """
+    Input:
+        xyz: input points position data, [B, N, 3]
+        points: input points data, [B, N, D]
+    Return:
+        new_xyz: sampled points position data, [B, 1, 3]
+        new_points: sampled points data, [B, 1, N, 3+D]
+    """
+    device = xyz.device
+    B, N, C = xyz.shape
+    new_xyz = torch.zeros(B, 1, C).to(device)
+    grouped_xyz = xyz.view(B, 1, N, C)
+    if points is not None:
+        new_points = torch.cat([grouped_xyz, points.view(B, 1, N, -1)], dim=-1)
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points
+
+
+# ---------------------------------------------------------------------------------------------
+# three_nn / three_interpolate
+# ---------------------------------------------------------------------------------------------
+def three_nn(xyz1, xyz2):
+    """3 nearest points of xyz2 (B,S,3) for every point of xyz1 (B,N,3): (dist (B,N,3) squared,
+    expanded form, ascending by (dist, index); idx (B,N,3) int64) -- pointnet2_utils.py:333-335."""
+    require_cuda(xyz1, xyz2)
+    xyz1, xyz2 = _f32c(xyz1.detach()), _f32c(xyz2.detach())
+    B, N, _ = xyz1.shape
+    S = xyz2.shape[1]
+    dist = torch.empty(B, N, 3, dtype=torch.float32, device=xyz1.device)
+    idx = torch.empty(B, N, 3, dtype=torch.int64, device=xyz1.device)
+    check(lib().tgn_three_nn(B, N, S, ptr(xyz1), ptr(xyz2), ptr(dist), ptr(idx), 1, stream()), "three_nn")
+    return dist, idx
+
+
+class _ThreeInterpolate(Function):
+    @staticmethod
+    @_fwd
+    def forward(ctx, points2, dist, idx):
+        B, S, C = points2.shape
+        N = dist.shape[1]
+        out = torch.empty(B, N, C, dtype=torch.float32, device=points2.device)
+        weight = torch.empty(B, N, 3, dtype=torch.float32, device=points2.device)
+        check(lib().tgn_three_interpolate(B, N, S, C, ptr(points2), ptr(dist), ptr(idx), 1, ptr(out), ptr(weight),
+                                          stream()), "three_interpolate")
+        ctx.dims = (B, N, S, C)
+        ctx.save_for_backward(idx, weight)
+        return out
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, g):
+        idx, weight = ctx.saved_tensors
+        B, N, S, C = ctx.dims
+        g = g.contiguous().float()
+        # global row indices into the flattened (B*S, C) support features
+        gidx = (idx + (torch.arange(B, device=idx.device, dtype=idx.dtype) * S).view(B, 1, 1)).to(torch.int32)
+        grad = torch.zeros(B * S, C, dtype=torch.float32, device=g.device)
+        check(lib().tgn_interpolation_backward(B * N, C, 3, ptr(g), ptr(gidx.contiguous()), ptr(weight), ptr(grad),
+                                               stream()), "interpolation bwd")
+        return grad.view(B, S, C), None, None
+
+
+def three_interpolate(points2, dist, idx):
+    """inverse-(squared)-distance weighted sum of the 3 neighbours (pointnet2_utils.py:337-340) -> (B,N,C)."""
+    require_cuda(points2, dist, idx)
+    return _ThreeInterpolate.apply(_f32c(points2), dist.contiguous(), idx.contiguous())
+
+
+# ---------------------------------------------------------------------------------------------
+# modules (constructor signatures and parameter names of pointnet2_utils.py:198-352)
+# ---------------------------------------------------------------------------------------------
+class PointNetSetAbstraction(nn.Module):
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all):
+        super(PointNetSetAbstraction, self).__init__()
+        self.npoint = npoint
+        self.radius = radius
+        self.nsample = nsample
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv2d(last_channel, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(out_channel))
+            last_channel = out_channel
+        self.group_all = group_all
+
+    def forward(self, xyz, points):
+        """
+        Input:
+            xyz: input points position data, [B, C, N]
+            points: input points data, [B, D, N]
+        Return:
+            new_xyz: sampled points position data, [B, C, S]
+            new_points_concat: sample points feature data, [B, D', S]
+        """
+        xyz = xyz.permute(0, 2, 1)
+        if points is not None:
+            points = points.permute(0, 2, 1)
+        if self.group_all:
+            new_xyz, new_points = sample_and_group_all(xyz, points)
+        else:
+            new_xyz, new_points = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points)
+        new_points = new_points.permute(0, 3, 2, 1)  # [B, C+D, nsample, npoint]
+        for i, conv in enumerate(self.mlp_convs):
+            bn = self.mlp_bns[i]
+            new_points = F.relu(bn(conv(new_points)))
+        new_points = torch.max(new_points, 2)[0]
+        new_xyz = new_xyz.permute(0, 2, 1)
+        return new_xyz, new_points
+
+
+class PointNetSetAbstractionMsg(nn.Module):
+    def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp_list):
+        super(PointNetSetAbstractionMsg, self).__init__()
+        self.npoint = npoint
+        self.radius_list = radius_list
+        self.nsample_list = nsample_list
+        self.conv_blocks = nn.ModuleList()
+        self.bn_blocks = nn.ModuleList()
+        for i in range(len(mlp_list)):
+            convs = nn.ModuleList()
+            bns = nn.ModuleList()
+            last_channel = in_channel + 3
+            for out_channel in mlp_list[i]:
+                convs.append(nn.Conv2d(last_channel, out_channel, 1))
+                bns.append(nn.BatchNorm2d(out_channel))
+                last_channel = out_channel
+            self.conv_blocks.append(convs)
+            self.bn_blocks.append(bns)
+
+    def forward(self, xyz, points):
+        """
+        Input:
+            xyz: input points position data, [B, C, N]
+            points: input points data, [B, D, N]
+        Return:
+            new_xyz: sampled points position data, [B, C, S]
+            new_points_concat: sample points feature data, [B, D', S]
+        """
+        xyz = xyz.permute(0, 2, 1)
+        if points is not None:
+            points = points.permute(0, 2, 1)
+        S = self.npoint
+        # one FPS launch yields both the indices and the sampled coordinates (:276)
+        if xyz.requires_grad:
+            new_xyz = index_points(xyz, farthest_point_sample(xyz, S))
+        else:
+            _, new_xyz = _fps_dense(xyz, S, want_coords=True)
+        xyz_c = _f32c(xyz)
+        points_c = None if points is None else _f32c(points)
+        new_points_list = []
+        for i, radius in enumerate(self.radius_list):
+            K = self.nsample_list[i]
+            group_idx = query_ball_point(radius, K, xyz_c, new_xyz)
+            grouped_points = group_points(xyz_c, new_xyz, points_c, group_idx, xyz_first=False)  # [feat, rel_xyz] (:285)
+            grouped_points = grouped_points.permute(0, 3, 2, 1)  # [B, D, K, S]
+            for j in range(len(self.conv_blocks[i])):
+                conv = self.conv_blocks[i][j]
+                bn = self.bn_blocks[i][j]
+                grouped_points = F.relu(bn(conv(grouped_points)))
+            new_points = torch.max(grouped_points, 2)[0]  # [B, D', S]
+            new_points_list.append(new_points)
+        new_xyz = new_xyz.permute(0, 2, 1)
+        new_points_concat = torch.cat(new_points_list, dim=1)
+        return new_xyz, new_points_concat
+
+
+class PointNetFeaturePropagation(nn.Module):
+    def __init__(self, in_channel, mlp):
+        super(PointNetFeaturePropagation, self).__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv1d(last_channel, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(out_channel))
+            last_channel = out_channel
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        """
+        Input:
+            xyz1: input points position data, [B, C, N]
+            xyz2: sampled input points position data, [B, C, S]
+            points1: input points data, [B, D, N]
+            points2: input points data, [B, D, S]
+        Return:
+            new_points: upsampled points data, [B, D', N]
+        """
+        xyz1 = xyz1.permute(0, 2, 1)
+        xyz2 = xyz2.permute(0, 2, 1)
+        points2 = points2.permute(0, 2, 1)
+        B, N, C = xyz1.shape
+        _, S, _ = xyz2.shape
+
+        if S == 1:
+            interpolated_points = points2.repeat(1, N, 1)
+        elif xyz1.requires_grad or xyz2.requires_grad:
+            # differentiable coordinates (never the case in the reference models): same maths in torch so
+            # that the interpolation weights carry gradient as they would in the reference (:333-340)
+            dists = square_distance(xyz1, xyz2)
+            dists, idx = dists.sort(dim=-1)
+            dists, idx = dists[:, :, :3], idx[:, :, :3]
+            dist_recip = 1.0 / (dists + 1e-8)
+            norm = torch.sum(dist_recip, dim=2, keepdim=True)
+            weight = dist_recip / norm
+            interpolated_points = torch.sum(index_points(points2, idx) * weight.view(B, N, 3, 1), dim=2)
+        else:
+            dist, idx = three_nn(xyz1, xyz2)
+            interpolated_points = three_interpolate(points2, dist, idx)
+
+        if points1 is not None:
+            points1 = points1.permute(0, 2, 1)
+            new_points = torch.cat([points1, interpolated_points], dim=-1)
+        else:
+            new_points = interpolated_points
+
+        new_points = new_points.permute(0, 2, 1)
+        for i, conv in enumerate(self.mlp_convs):
+            bn = self.mlp_bns[i]
+            new_points = F.relu(bn(conv(new_points)))
+        return new_points

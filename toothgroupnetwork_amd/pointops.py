@@ -1,0 +1,390 @@
+"""MI355X implementation of the reference's ``external_libs/pointops/functions/pointops.py``.
+
+Same public names, positional arguments, return layouts and dtypes as the reference operators
+(limhoyeon/ToothGroupNetwork, pointops.py:10-216), so ``models/modules/cbl_point_transformer/*``
+and ``gen_utils.fps`` import it unchanged through ``external_libs/pointops/functions/pointops.py``.
+
+Layout conventions of the reference ("packed batch"): xyz (n,3) fp32, features (n,c) fp32,
+``offset`` (b) int32 cumulative end of every cloud.  Everything runs through the C ABI of
+libtgn_pointops.so on the current HIP stream; there is no CPU path.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import as_int, check, lib, ptr, require_cuda, stream
+
+_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd = torch.amp.custom_bwd(device_type="cuda")
+
+
+def _i32(t):
+    return t if t.dtype == torch.int32 else t.to(torch.int32)
+
+
+def _offsets_host(offset):
+    """Offsets are device tensors in the reference API; the output size depends on their values, so one
+    device->host copy per call is inherent (the reference syncs b+1 times, pointops.py:18-21)."""
+    return [int(v) for v in offset.detach().cpu().tolist()]
+
+
+def _max_segment(off_h):
+    n_max, prev = 0, 0
+    for v in off_h:
+        n_max = max(n_max, v - prev)
+        prev = v
+    return n_max
+
+
+def fps_with_coords(xyz, offset, new_offset, cuda_compat=False):
+    """furthestsampling that also returns the sampled coordinates xyz[idx] straight from the kernel
+    (what blocks.py:69-70 computes with a second gather).  Returns (idx int32 (m,), new_xyz (m,3))."""
+    require_cuda(xyz, offset, new_offset)
+    assert xyz.is_contiguous()
+    xyz = xyz.float() if xyz.dtype != torch.float32 else xyz
+    offset, new_offset = _i32(offset).contiguous(), _i32(new_offset).contiguous()
+    both = _offsets_host(torch.cat([offset.reshape(-1), new_offset.reshape(-1)]))  # one device->host copy
+    off_h, noff_h = both[:offset.numel()], both[offset.numel():]
+    b = offset.shape[0]
+    if b == 0:
+        return (torch.zeros(0, dtype=torch.int32, device=xyz.device),
+                torch.zeros(0, 3, dtype=torch.float32, device=xyz.device))
+    n_max = _max_segment(off_h)
+    m = noff_h[-1]
+    idx = torch.empty(m, dtype=torch.int32, device=xyz.device)
+    new_xyz = torch.empty(m, 3, dtype=torch.float32, device=xyz.device)
+    tmp = None
+    if n_max > lib().tgn_fps_resident_capacity():
+        tmp = torch.empty(xyz.shape[0], dtype=torch.float32, device=xyz.device)
+    flags = _lib.FPS_CUDA_COMPAT if cuda_compat else 0
+    check(lib().tgn_furthestsampling(b, n_max, ptr(xyz), ptr(offset), ptr(new_offset), ptr(tmp), ptr(idx),
+                                     ptr(new_xyz), flags, stream()), "tgn_furthestsampling")
+    return idx, new_xyz
+
+
+class FurthestSampling(Function):
+    @staticmethod
+    def forward(ctx, xyz, offset, new_offset):
+        """
+        input: xyz: (n, 3), offset: (b), new_offset: (b)
+        output: idx: (m)            [reference: pointops.py:10-24]
+        """
+        idx, _ = fps_with_coords(xyz, offset, new_offset)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, grad):
+        return None, None, None
+
+
+furthestsampling = FurthestSampling.apply
+
+
+def _knn_raw(nsample, xyz, new_xyz, offset, new_offset):
+    nsample = as_int(nsample)
+    if new_xyz is None:
+        new_xyz = xyz
+    require_cuda(xyz, new_xyz, offset, new_offset)
+    assert xyz.is_contiguous() and new_xyz.is_contiguous()
+    xyz = xyz.float() if xyz.dtype != torch.float32 else xyz
+    new_xyz = new_xyz.float() if new_xyz.dtype != torch.float32 else new_xyz
+    offset, new_offset = _i32(offset).contiguous(), _i32(new_offset).contiguous()
+    m = new_xyz.shape[0]
+    idx = torch.empty(m, nsample, dtype=torch.int32, device=xyz.device)
+    dist2 = torch.empty(m, nsample, dtype=torch.float32, device=xyz.device)
+    check(lib().tgn_knnquery(offset.shape[0], m, nsample, ptr(xyz), ptr(new_xyz), ptr(offset), ptr(new_offset),
+                             ptr(idx), ptr(dist2), stream()), "tgn_knnquery")
+    return idx, dist2
+
+
+class KNNQuery(Function):
+    @staticmethod
+    def forward(ctx, nsample, xyz, new_xyz, offset, new_offset):
+        """
+        input: xyz: (n, 3), new_xyz: (m, 3), offset: (b), new_offset: (b)
+        output: idx: (m, nsample), dist: (m, nsample)  (sqrt of the squared distances) [pointops.py:30-43]
+        """
+        idx, dist2 = _knn_raw(nsample, xyz, new_xyz, offset, new_offset)
+        dist = torch.sqrt(dist2)
+        ctx.mark_non_differentiable(idx, dist)
+        return idx, dist
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return None, None, None, None, None
+
+
+knnquery = KNNQuery.apply
+
+
+class Grouping(Function):
+    @staticmethod
+    @_fwd
+    def forward(ctx, input, idx):
+        """
+        input: input: (n, c), idx : (m, nsample)
+        output: (m, nsample, c)     [pointops.py:48-61]
+        """
+        require_cuda(input, idx)
+        assert input.is_contiguous() and idx.is_contiguous()
+        idx = _i32(idx)
+        m, nsample, n, c = idx.shape[0], idx.shape[1], input.shape[0], input.shape[1]
+        output = torch.empty(m, nsample, c, dtype=torch.float32, device=input.device)
+        check(lib().tgn_grouping_forward(m, nsample, c, ptr(input), ptr(idx), ptr(output), stream()), "grouping fwd")
+        ctx.n = n
+        ctx.save_for_backward(idx)
+        return output
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad_output):
+        """
+        input: grad_out: (m, nsample, c)
+        output: (n, c), None        [pointops.py:63-74]
+        """
+        n = ctx.n
+        idx, = ctx.saved_tensors
+        grad_output = grad_output.contiguous().float()
+        m, nsample, c = grad_output.shape
+        grad_input = torch.zeros(n, c, dtype=torch.float32, device=grad_output.device)
+        check(lib().tgn_grouping_backward(m, nsample, c, ptr(grad_output), ptr(idx), ptr(grad_input), stream()),
+              "grouping bwd")
+        return grad_input, None
+
+
+grouping = Grouping.apply
+
+
+class _QueryGroup(Function):
+    """gather + centre + concat of queryandgroup as ONE kernel per tensor (pointops.py:89-100).
+
+    The reference materialises xyz[idx], subtracts, gathers feat[idx] and concatenates (4 tensors);
+    here the (m, nsample, 3+c) result is written once.  Gradients flow to xyz, new_xyz and feat exactly
+    as torch autograd would give for the reference's fancy indexing."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, xyz, new_xyz, feat, idx, use_xyz):
+        m, nsample = idx.shape
+        n, c = feat.shape
+        ctx.n, ctx.use_xyz = n, use_xyz
+        ctx.save_for_backward(idx)
+        if not use_xyz:
+            out = torch.empty(m, nsample, c, dtype=torch.float32, device=feat.device)
+            check(lib().tgn_grouping_forward(m, nsample, c, ptr(feat), ptr(idx), ptr(out), stream()), "grouping fwd")
+            return out
+        out = torch.empty(m, nsample, 3 + c, dtype=torch.float32, device=feat.device)
+        # packed layout == dense layout with B=1: rows of new_xyz are the S "centres", K = nsample
+        check(lib().tgn_group_points(1, n, m, nsample, c, ptr(xyz), ptr(new_xyz), ptr(feat), ptr(idx), 0, 1,
+                                     ptr(out), stream()), "group_points")
+        return out
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad_out):
+        idx, = ctx.saved_tensors
+        m, nsample = idx.shape
+        n = ctx.n
+        grad_out = grad_out.contiguous().float()
+        g_xyz = g_new = None
+        if ctx.use_xyz:
+            g_rel = grad_out[:, :, :3].contiguous()
+            g_feat = grad_out[:, :, 3:].contiguous()
+            if ctx.needs_input_grad[0]:
+                g_xyz = torch.zeros(n, 3, dtype=torch.float32, device=grad_out.device)
+                check(lib().tgn_grouping_backward(m, nsample, 3, ptr(g_rel), ptr(idx), ptr(g_xyz), stream()),
+                      "grouping bwd")
+            if ctx.needs_input_grad[1]:
+                g_new = -g_rel.sum(1)
+        else:
+            g_feat = grad_out
+        c = g_feat.shape[2]
+        g_in = torch.zeros(n, c, dtype=torch.float32, device=grad_out.device)
+        check(lib().tgn_grouping_backward(m, nsample, c, ptr(g_feat), ptr(idx), ptr(g_in), stream()), "grouping bwd")
+        return g_xyz, g_new, g_in, None, None
+
+
+def queryandgroup(nsample, xyz, new_xyz, feat, idx, offset, new_offset, use_xyz=True):
+    """
+    input: xyz: (n, 3), new_xyz: (m, 3), feat: (n, c), idx: (m, nsample), offset: (b), new_offset: (b)
+    output: new_feat: (m, nsample, 3+c) if use_xyz else (m, nsample, c)     [pointops.py:79-100]
+    """
+    nsample = as_int(nsample)
+    if new_xyz is None:
+        new_xyz = xyz
+    require_cuda(xyz, new_xyz, feat)
+    assert xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()
+    if idx is None:
+        idx, _ = knnquery(nsample, xyz, new_xyz, offset, new_offset)  # (m, nsample)
+    idx = _i32(idx).contiguous()
+    return _QueryGroup.apply(xyz, new_xyz, feat, idx, bool(use_xyz))
+
+
+class Subtraction(Function):
+    @staticmethod
+    @_fwd
+    def forward(ctx, input1, input2, idx):
+        """
+        input: input1: (n, c), input2: (n, c), idx: (n, nsample)
+        output:  (n, nsample, c)    [pointops.py:103-116]
+        """
+        require_cuda(input1, input2, idx)
+        assert input1.is_contiguous() and input2.is_contiguous()
+        idx = _i32(idx).contiguous()
+        n, c = input1.shape
+        nsample = idx.shape[-1]
+        output = torch.empty(n, nsample, c, dtype=torch.float32, device=input1.device)
+        check(lib().tgn_subtraction_forward(n, nsample, c, ptr(input1), ptr(input2), ptr(idx), ptr(output), stream()),
+              "subtraction fwd")
+        ctx.n2 = input2.shape[0]
+        ctx.save_for_backward(idx)
+        return output
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad_output):
+        """
+        input: grad_out: (n, nsample, c)
+        output: grad_input1: (n, c), grad_input2: (n, c)    [pointops.py:118-128]
+        """
+        idx, = ctx.saved_tensors
+        grad_output = grad_output.contiguous().float()
+        n, nsample, c = grad_output.shape
+        grad_input1 = torch.zeros(n, c, dtype=torch.float32, device=grad_output.device)
+        grad_input2 = torch.zeros(ctx.n2, c, dtype=torch.float32, device=grad_output.device)
+        check(lib().tgn_subtraction_backward(n, nsample, c, ptr(idx), ptr(grad_output), ptr(grad_input1),
+                                             ptr(grad_input2), stream()), "subtraction bwd")
+        return grad_input1, grad_input2, None
+
+
+subtraction = Subtraction.apply
+
+
+class Aggregation(Function):
+    @staticmethod
+    @_fwd
+    def forward(ctx, input, position, weight, idx):
+        """
+        input: input: (n, c), position: (n, nsample, c), weight : (n, nsample, c'), idx: (n, nsample)
+        output: (n, c)              [pointops.py:133-146]
+        """
+        require_cuda(input, position, weight, idx)
+        assert input.is_contiguous() and position.is_contiguous() and weight.is_contiguous()
+        idx = _i32(idx).contiguous()
+        n, nsample, c = position.shape
+        w_c = weight.shape[-1]
+        output = torch.zeros(n, c, dtype=torch.float32, device=input.device)
+        check(lib().tgn_aggregation_forward(n, nsample, c, w_c, ptr(input), ptr(position), ptr(weight), ptr(idx),
+                                            ptr(output), stream()), "aggregation fwd")
+        ctx.save_for_backward(input, position, weight, idx)
+        return output
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad_output):
+        """
+        input: grad_out: (n, c)
+        output: grad_input: (n, c), grad_position: (n, nsample, c), grad_weight : (n, nsample, c')  [pointops.py:148-159]
+        """
+        input, position, weight, idx = ctx.saved_tensors
+        grad_output = grad_output.contiguous().float()
+        n, nsample, c = position.shape
+        w_c = weight.shape[-1]
+        grad_input = torch.zeros(input.shape[0], c, dtype=torch.float32, device=grad_output.device)
+        grad_position = torch.zeros(n, nsample, c, dtype=torch.float32, device=grad_output.device)
+        grad_weight = torch.zeros(n, nsample, w_c, dtype=torch.float32, device=grad_output.device)
+        check(lib().tgn_aggregation_backward(n, nsample, c, w_c, ptr(input), ptr(position), ptr(weight), ptr(idx),
+                                             ptr(grad_output), ptr(grad_input), ptr(grad_position),
+                                             ptr(grad_weight), stream()), "aggregation bwd")
+        return grad_input, grad_position, grad_weight, None
+
+
+aggregation = Aggregation.apply
+
+
+def _inverse_distance_weights(dist):
+    dist_recip = 1.0 / (dist + 1e-8)
+    norm = torch.sum(dist_recip, dim=1, keepdim=True)
+    return dist_recip / norm
+
+
+class _WeightedGather(Function):
+    """out[n,:] = sum_i feat[idx[n,i],:] * weight[n,i]  -- the loop of pointops.py:177-179 / the native
+    interpolation kernel (interpolation_cuda_kernel.cu:5-18) with its atomic backward (:20-33)."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, feat, idx, weight):
+        n, k = idx.shape
+        m, c = feat.shape
+        output = torch.zeros(n, c, dtype=torch.float32, device=feat.device)
+        check(lib().tgn_interpolation_forward(n, c, k, ptr(feat), ptr(idx), ptr(weight), ptr(output), stream()),
+              "interpolation fwd")
+        ctx.m = m
+        ctx.save_for_backward(idx, weight)
+        return output
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad_output):
+        idx, weight = ctx.saved_tensors
+        grad_output = grad_output.contiguous().float()
+        n, c = grad_output.shape
+        k = idx.shape[1]
+        grad_input = torch.zeros(ctx.m, c, dtype=torch.float32, device=grad_output.device)
+        check(lib().tgn_interpolation_backward(n, c, k, ptr(grad_output), ptr(idx), ptr(weight), ptr(grad_input),
+                                               stream()), "interpolation bwd")
+        return grad_input, None, None
+
+
+def interpolation(xyz, new_xyz, feat, offset, new_offset, k=3):
+    """
+    input: xyz: (m, 3), new_xyz: (n, 3), feat: (m, c), offset: (b), new_offset: (b)
+    output: (n, c)                  [pointops.py:164-180; weights detached as there]
+    """
+    require_cuda(xyz, new_xyz, feat)
+    assert xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()
+    k = as_int(k)
+    idx, dist = knnquery(k, xyz, new_xyz, offset, new_offset)  # (n, k), (n, k)
+    weight = _inverse_distance_weights(dist).detach().contiguous()
+    return _WeightedGather.apply(feat, idx, weight)
+
+
+class Interpolation(Function):
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, input, offset, new_offset, k=3):
+        """
+        input: xyz: (m, 3), new_xyz: (n, 3), input: (m, c), offset: (b), new_offset: (b)
+        output: (n, c)              [pointops.py:183-201]
+        """
+        require_cuda(xyz, new_xyz, input)
+        assert xyz.is_contiguous() and new_xyz.is_contiguous() and input.is_contiguous()
+        k = as_int(k)
+        idx, dist2 = _knn_raw(k, xyz, new_xyz, offset, new_offset)
+        weight = _inverse_distance_weights(torch.sqrt(dist2)).contiguous()
+        input = input.float()
+        n, c, m = new_xyz.shape[0], input.shape[1], input.shape[0]
+        output = torch.zeros(n, c, dtype=torch.float32, device=input.device)
+        check(lib().tgn_interpolation_forward(n, c, k, ptr(input), ptr(idx), ptr(weight), ptr(output), stream()),
+              "interpolation fwd")
+        ctx.m, ctx.k = m, k
+        ctx.save_for_backward(idx, weight)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        """
+        output: None, None, grad_input (m, c), None, None, None     [pointops.py:203-214]
+        """
+        m, k = ctx.m, ctx.k
+        idx, weight = ctx.saved_tensors
+        grad_output = grad_output.contiguous().float()
+        n, c = grad_output.shape
+        grad_input = torch.zeros(m, c, dtype=torch.float32, device=grad_output.device)
+        check(lib().tgn_interpolation_backward(n, c, k, ptr(grad_output), ptr(idx), ptr(weight), ptr(grad_input),
+                                               stream()), "interpolation bwd")
+        return None, None, grad_input, None, None, None
+
+
+interpolation2 = Interpolation.apply

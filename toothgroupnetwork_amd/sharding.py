@@ -1,0 +1,108 @@
+"""Multi-GPU execution of the hot path: independent meshes shard across ranks, nothing is exchanged
+while computing, and ONE small collective gathers per-rank counters at the end.
+
+The reference has no distributed code at all (single process, batch 1: runner.py:28-37,
+preprocess_data.py:35 is a serial loop over scans).  On an 8-GPU MI355X node the natural unit of
+parallelism is the mesh: one process per GPU (``torch.distributed``, backend "nccl" == RCCL over xGMI),
+rank r works on ``shard_indices(n_items, r, world)``, and the per-rank metric vectors (mesh count,
+seconds, checksums, loss sums -- LossMeter fields, loss_meter.py:9-20) are combined with a single
+``all_gather_into_tensor`` of a <= 1 KB fp64 vector, which is latency-bound on any fabric.
+On CPU (tests) the same code runs over the gloo backend.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous split: ranks < n_items % world get one extra item. Returns (start, stop)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    base, rem = divmod(int(n_items), world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def shard_indices(n_items, rank, world, mode="contiguous"):
+    """Indices of the items rank `rank` owns. 'round_robin' balances sorted-by-size lists."""
+    if mode == "contiguous":
+        s, e = shard_range(n_items, rank, world)
+        return list(range(s, e))
+    if mode == "round_robin":
+        if world <= 0 or not (0 <= rank < world):
+            raise ValueError(f"bad rank/world {rank}/{world}")
+        return list(range(rank, int(n_items), world))
+    raise ValueError(f"unknown shard mode {mode!r}")
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from the torchrun environment (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).
+    Returns (rank, local_rank, world, device).  world == 1 needs no process group."""
+    rank, local_rank, world = env_rank_world()
+    use_cuda = torch.cuda.is_available()
+    if use_cuda:
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+        device = torch.device("cuda", torch.cuda.current_device())
+    else:
+        device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if use_cuda else "gloo"  # "nccl" is RCCL on ROCm
+        kwargs = {}
+        if use_cuda and backend == "nccl":
+            kwargs["device_id"] = device
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+    return rank, local_rank, world, device
+
+
+def gather_metrics(vec, device=None):
+    """All ranks contribute a 1-D fp64 vector of equal length; every rank receives the (world, k) matrix.
+    This is the only collective of a sharded run."""
+    vec = torch.as_tensor(vec, dtype=torch.float64)
+    if device is not None:
+        vec = vec.to(device)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return vec.reshape(1, -1)
+    world = dist.get_world_size()
+    out = torch.empty(world * vec.numel(), dtype=torch.float64, device=vec.device)
+    dist.all_gather_into_tensor(out, vec.contiguous())
+    return out.reshape(world, -1)
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device=None):
+    """Max of a python float over ranks (bench timing)."""
+    m = gather_metrics([float(value)], device=device)
+    return float(m.max().item())
+
+
+def run_sharded(items, fn, rank, world, mode="contiguous", device=None):
+    """Apply fn(item) -> dict of floats to this rank's shard; gather {key: sum over all ranks} plus counts.
+    Keys must be identical on every rank (fixed metric schema)."""
+    mine = shard_indices(len(items), rank, world, mode)
+    sums = {}
+    for i in mine:
+        res = fn(items[i]) or {}
+        for k, v in res.items():
+            sums[k] = sums.get(k, 0.0) + float(v)
+    keys = sorted(sums.keys())
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, keys)
+        keys = sorted(set().union(*[set(k) for k in gathered]))
+    vec = [float(len(mine))] + [sums.get(k, 0.0) for k in keys]
+    mat = gather_metrics(vec, device=device)
+    total = mat.sum(0).cpu().tolist()
+    return {"count": int(round(total[0])), **{k: total[1 + j] for j, k in enumerate(keys)},
+            "per_rank_count": [int(round(c)) for c in mat[:, 0].cpu().tolist()]}
