@@ -1,0 +1,180 @@
+"""GPU (-m gpu): the nn.Module layer (set abstraction / feature propagation) against outputs of the
+REFERENCE's modules computed on CPU with the same weights (tests/golden/make_golden.py), plus the
+preprocess resampler and full-size, size-independent properties at BASELINE.json's shapes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from toothgroupnetwork_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.fixture(scope="module")
+def weights():
+    return torch.load(os.path.join(GOLDEN, "module_weights.pt"))
+
+
+def test_set_abstraction_msg_matches_reference_module(dev, golden, weights):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    sa = U.PointNetSetAbstractionMsg(128, [0.1, 0.2], [8, 16], 6, [[16, 24], [16, 32]]).to(dev).eval()
+    sa.load_state_dict(weights["sa"])
+    with torch.no_grad():
+        new_xyz, feat = sa(T(golden["mod_xyz_cf"], dev), T(golden["mod_pts_cf"], dev))
+    assert np.array_equal(new_xyz.cpu().numpy(), golden["mod_sa_xyz"])       # FPS indices identical -> same centres
+    np.testing.assert_allclose(feat.cpu().numpy(), golden["mod_sa_feat"], rtol=1e-4, atol=1e-4)  # conv on GPU vs CPU BLAS
+
+
+def test_set_abstraction_ssg_and_feature_propagation_match_reference_modules(dev, golden, weights):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    ssg = U.PointNetSetAbstraction(64, 0.2, 16, 9, [16, 32], False).to(dev).eval()
+    ssg.load_state_dict(weights["ssg"])
+    fp = U.PointNetFeaturePropagation(62, [32, 16]).to(dev).eval()
+    fp.load_state_dict(weights["fp"])
+    xyz, pts = T(golden["mod_xyz_cf"], dev), T(golden["mod_pts_cf"], dev)
+    with torch.no_grad():
+        nx, nf = ssg(xyz, pts)
+        out = fp(xyz, T(golden["mod_sa_xyz"], dev), pts, T(golden["mod_sa_feat"], dev))
+    assert np.array_equal(nx.cpu().numpy(), golden["mod_ssg_xyz"])
+    np.testing.assert_allclose(nf.cpu().numpy(), golden["mod_ssg_feat"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(out.cpu().numpy(), golden["mod_fp_out"], rtol=1e-4, atol=1e-4)
+
+
+def test_modules_train_step_runs_and_gradients_flow(dev):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    torch.manual_seed(0)
+    sa = U.PointNetSetAbstractionMsg(64, [0.2, 0.4], [8, 16], 6, [[8, 16], [8, 16]]).to(dev)
+    fp = U.PointNetFeaturePropagation(32 + 6, [16]).to(dev)
+    pts = T(synth.scan_batch(2, 1024, "arch", 3).transpose(0, 2, 1), dev).requires_grad_()
+    xyz = pts[:, :3, :].detach()
+    nx, nf = sa(xyz, pts)
+    out = fp(xyz, nx, pts, nf)
+    out.square().mean().backward()
+    assert pts.grad is not None and torch.isfinite(pts.grad).all() and pts.grad.abs().sum() > 0
+    assert all(p.grad is not None for p in sa.parameters())
+    # bf16 autocast (BASELINE config 3): index kernels stay fp32, module output dtype follows autocast
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        nx2, nf2 = sa(xyz, pts.detach())
+    assert torch.equal(nx2, nx) and nf2.dtype in (torch.bfloat16, torch.float32)
+
+
+def test_resample_fps_and_batched_preprocess(dev, oracle):
+    from toothgroupnetwork_amd import resample
+    meshes = [synth.arch_cloud(n, seed=s)[:, :6].astype(np.float64) for s, n in enumerate([5000, 7300, 6100])]
+    singles = [resample.fps(m, 2000) for m in meshes]
+    for m, idx in zip(meshes, singles):
+        assert idx.dtype == np.int32 and idx.shape == (2000,)
+        assert np.array_equal(idx, oracle.furthestsampling(m[:, :3].astype(np.float32), [m.shape[0]], [2000]))
+    batched = resample.fps_batch(meshes, 2000)
+    for a, b in zip(singles, batched):
+        assert np.array_equal(a, b)
+    out = resample.resample_pcd([meshes[0], meshes[0][:, :1]], 2000, "fps")
+    assert out[0].shape == (2000, 6) and np.array_equal(out[0], meshes[0][singles[0]])
+    with pytest.raises(ValueError):
+        resample.fps(meshes[0][:100], 200)
+
+
+def test_farthest_point_sample_np_random_start(dev):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    xyz = np.stack([synth.uniform_cloud(500, 1), synth.uniform_cloud(500, 2)])
+    torch.manual_seed(5)
+    idx = U.farthest_point_sample_np(xyz, 50)
+    assert idx.shape == (2, 50) and idx.dtype == np.int64
+    torch.manual_seed(5)
+    starts = torch.randint(0, 500, (2,)).numpy()
+    assert np.array_equal(idx[:, 0], starts)
+    for b in range(2):  # a valid FPS sequence from that start
+        d = np.full(500, np.inf)
+        for j in range(1, 50):
+            d = np.minimum(d, ((xyz[b] - xyz[b, idx[b, j - 1]]) ** 2).sum(1))
+            assert d[idx[b, j]] >= d.max() * (1 - 1e-5)
+
+
+# ------------------------------------------------------------- full size (BASELINE.json shapes)
+def test_full_size_shape_a_properties(dev, oracle):
+    """24 000-point scans, npoint=[4096,1024,256], nsample=32, radii [0.05,0.1,0.2]: properties that do not
+    need the (slow) CPU oracle at full size, plus an exact oracle check of level 1 on one scan."""
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    scans = synth.scan_batch(3, 24000, "arch", seed=20)
+    xyz = T(scans[:, :, :3], dev)
+    pts = T(scans, dev)
+    npoints, radii, K = [4096, 1024, 256], [0.05, 0.1, 0.2], 32
+    cur_xyz, cur_pts = xyz, pts
+    for lvl, (S, r) in enumerate(zip(npoints, radii)):
+        fidx = U.farthest_point_sample(cur_xyz, S)
+        f = fidx.cpu().numpy()
+        assert (f[:, 0] == 0).all()
+        for b in range(f.shape[0]):
+            assert len(np.unique(f[b])) == S                       # distinct points: no index twice
+        new_xyz = U.index_points(cur_xyz, fidx)
+        # FPS min-distance sequence is non-increasing (defining property of farthest point sampling)
+        cx = new_xyz[0].double().cpu().numpy()
+        dmin = np.full(cur_xyz.shape[1], np.inf)
+        allx = cur_xyz[0].double().cpu().numpy()
+        prev = np.inf
+        for j in range(1, 200):
+            dmin = np.minimum(dmin, ((allx - cx[j - 1]) ** 2).sum(1))
+            cur = dmin[f[0, j]]
+            assert cur <= prev * (1 + 1e-6) and cur >= dmin.max() * (1 - 1e-5)
+            prev = cur
+        gidx = U.query_ball_point(r, K, cur_xyz, new_xyz)
+        g = gidx.cpu().numpy()
+        N = cur_xyz.shape[1]
+        assert g.min() >= 0 and g.max() < N
+        # rows are ascending until the padding starts, and padding repeats the first hit
+        d = np.diff(g, axis=2)
+        asc = d > 0
+        pad = g[:, :, 1:] == g[:, :, :1]
+        assert (asc | pad).all()
+        # every returned index is inside the ball (expanded-form distance, fp32 threshold)
+        gx = U.index_points(cur_xyz, gidx)
+        q = new_xyz.unsqueeze(2)
+        dot = torch.addcmul(torch.addcmul(q[..., 0] * gx[..., 0], q[..., 1], gx[..., 1]), q[..., 2], gx[..., 2])
+        dist = (gx.double() - q.double()).pow(2).sum(-1)
+        assert (dist <= r * r * (1 + 1e-3) + 1e-5).all()
+        # the centre itself is always a member (distance ~0) -> first hit <= centre index
+        assert (g[:, :, 0] <= f).all()
+        grouped = U.group_points(cur_xyz, new_xyz, cur_pts, gidx, xyz_first=True)
+        assert grouped.shape == (3, S, K, 3 + cur_pts.shape[2])
+        # idempotence / consistency: grouped == gather - centre, recomputed with plain torch indexing
+        bi = torch.arange(3, device=dev).view(3, 1, 1)
+        assert torch.equal(grouped[..., :3], cur_xyz[bi, gidx] - new_xyz.unsqueeze(2))
+        assert torch.equal(grouped[..., 3:], cur_pts[bi, gidx])
+        if lvl == 0:
+            o_f = oracle.farthest_point_sample(scans[:1, :, :3], S)
+            assert np.array_equal(f[:1], o_f)
+            o_g = oracle.query_ball_point(r, K, scans[:1, :, :3], new_xyz[:1].cpu().numpy())
+            assert np.array_equal(g[:1], o_g)
+        D_next = [128, 512, 0][lvl]
+        cur_xyz = new_xyz.contiguous()
+        if D_next:
+            cur_pts = torch.randn(3, S, D_next, device=dev)
+
+
+def test_full_size_knn_and_three_nn_properties(dev):
+    from toothgroupnetwork_amd import pointnet2_utils as U, pointops as P
+    xyz_np = synth.arch_cloud(24000, 31, False)
+    xyz = T(xyz_np, dev)
+    off = torch.tensor([24000], dtype=torch.int32, device=dev)
+    idx, dist = P.knnquery(36, xyz, xyz, off, off)           # PT enc1 shape (24000, 24000, 36)
+    assert (idx[:, 0] == torch.arange(24000, device=dev)).float().mean() > 0.999   # self is the nearest
+    assert (dist[:, 1:] >= dist[:, :-1]).all()               # ascending
+    e = xyz.unsqueeze(1) - xyz[idx.long()]
+    d2 = (e[..., 0] * e[..., 0] + e[..., 1] * e[..., 1]) + e[..., 2] * e[..., 2]
+    assert torch.equal(torch.sqrt(d2), dist)                  # returned distance belongs to returned index
+    # k-th distance is a true k-th smallest on a sample of queries
+    sub = torch.arange(0, 24000, 480, device=dev)
+    full = ((xyz[sub].unsqueeze(1) - xyz.unsqueeze(0)) ** 2)
+    full = (full[..., 0] + full[..., 1]) + full[..., 2]
+    kth = full.sort(1)[0][:, 35]
+    assert torch.equal(torch.sqrt(kth), dist[sub, 35])
+    sup = xyz[::24].contiguous().unsqueeze(0)                 # 1000 support points
+    d, i = U.three_nn(xyz.unsqueeze(0), sup)
+    assert (d[..., 1:] >= d[..., :-1]).all() and i.max() < 1000

@@ -1,0 +1,457 @@
+"""GPU (-m gpu): HIP kernels, called through the C ABI, against
+  (1) the committed golden fixtures produced by the reference's own torch functions,
+  (2) the CPU oracle on the same seeded inputs,
+  (3) the reference's own *_cuda_kernel.cu compiled for gfx950 (oracle/_ref), when present.
+Indices are compared bit-exactly; fp32 features within 1e-5 (they are copies/differences: expect 0)."""
+import numpy as np
+import pytest
+import torch
+
+from toothgroupnetwork_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t if dtype is None else t.to(dtype)
+
+
+# ------------------------------------------------------------------------------------------- FPS
+def test_fps_dense_matches_golden(dev, golden):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    for k in ("arch", "uniform", "lattice"):
+        xyz = T(golden[f"fps_{k}_xyz"], dev)
+        ref = golden[f"fps_{k}_idx"].astype(np.int64)
+        got = U.farthest_point_sample(xyz, ref.shape[1])
+        assert got.dtype == torch.int64 and tuple(got.shape) == ref.shape
+        assert np.array_equal(got.cpu().numpy(), ref), k
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 2), (63, 10), (64, 64), (65, 30), (1000, 256), (1024, 256), (1025, 100),
+                                 (4096, 1024), (6000, 500), (12288, 300), (16385, 200), (24000, 512)])
+def test_fps_every_kernel_shape_vs_oracle(dev, oracle, n, m):
+    """One cloud per launch configuration (threads x points-per-lane), incl. exact-capacity edges."""
+    from toothgroupnetwork_amd import pointops as P
+    xyz = synth.uniform_cloud(n, seed=n)
+    off, noff = np.array([n], np.int32), np.array([m], np.int32)
+    got = P.furthestsampling(T(xyz, dev), T(off, dev), T(noff, dev))
+    assert got.dtype == torch.int32
+    assert np.array_equal(got.cpu().numpy(), oracle.furthestsampling(xyz, off, noff))
+
+
+def test_fps_packed_ragged_batch_and_modes(dev, oracle, regression):
+    from toothgroupnetwork_amd import _lib, pointops as P
+    r = regression
+    xyz, off, noff = T(r["p_xyz"], dev), T(r["p_offset"], dev), T(r["p_new_offset"], dev)
+    idx, new_xyz = P.fps_with_coords(xyz, off, noff)
+    assert np.array_equal(idx.cpu().numpy(), r["p_fps_idx"])
+    assert np.array_equal(new_xyz.cpu().numpy(), r["p_xyz"][r["p_fps_idx"].astype(np.int64)])
+    idx_cc, _ = P.fps_with_coords(xyz, off, noff, cuda_compat=True)
+    assert np.array_equal(idx_cc.cpu().numpy(), r["p_fps_idx_cudacompat"])
+    # tree tie order alone (the reference source without contraction)
+    L = _lib.lib()
+    out = torch.empty(int(r["p_new_offset"][-1]), dtype=torch.int32, device=dev)
+    n_max = int(np.diff(np.concatenate([[0], r["p_offset"]])).max())
+    _lib.check(L.tgn_furthestsampling(3, n_max, _lib.ptr(xyz), _lib.ptr(off), _lib.ptr(noff), None, _lib.ptr(out),
+                                      None, _lib.FPS_TREE_TIES, _lib.stream()))
+    assert np.array_equal(out.cpu().numpy(), r["p_fps_idx_tree"])
+
+
+def test_fps_edge_cases(dev, oracle):
+    from toothgroupnetwork_amd import pointops as P
+    # more samples than points, single point clouds, duplicated vertices, empty batch
+    xyz = np.concatenate([synth.uniform_cloud(5, 1), synth.uniform_cloud(1, 2), np.repeat(synth.uniform_cloud(3, 3), 4, 0)])
+    off = np.array([5, 6, 18], np.int32)
+    noff = np.array([9, 12, 22], np.int32)
+    got = P.furthestsampling(T(xyz, dev), T(off, dev), T(noff, dev)).cpu().numpy()
+    assert np.array_equal(got, oracle.furthestsampling(xyz, off, noff))
+    e = P.furthestsampling(torch.zeros(0, 3, device=dev), torch.zeros(0, dtype=torch.int32, device=dev),
+                           torch.zeros(0, dtype=torch.int32, device=dev))
+    assert e.numel() == 0
+    # NaN coordinates never update a distance: same sequence as the oracle
+    xyz = synth.uniform_cloud(300, 7)
+    xyz[17] = np.nan
+    o, m = np.array([300], np.int32), np.array([40], np.int32)
+    assert np.array_equal(P.furthestsampling(T(xyz, dev), T(o, dev), T(m, dev)).cpu().numpy(),
+                          oracle.furthestsampling(xyz, o, m))
+
+
+def test_fps_streaming_kernel_for_oversized_cloud(dev, oracle):
+    from toothgroupnetwork_amd import _lib, pointops as P
+    n = _lib.lib().tgn_fps_resident_capacity() + 1500
+    xyz = synth.arch_cloud(n, 5, False)
+    o, m = np.array([n], np.int32), np.array([96], np.int32)
+    got = P.furthestsampling(T(xyz, dev), T(o, dev), T(m, dev)).cpu().numpy()
+    assert np.array_equal(got, oracle.furthestsampling(xyz, o, m))
+
+
+def test_fps_vs_reference_kernel_on_this_gpu(dev, regression):
+    """The reference's sampling_cuda_kernel.cu (compiled for gfx950, no contraction) == TREE_TIES mode."""
+    from oracle import ref_gpu
+    if not ref_gpu.available():
+        pytest.skip("oracle/_ref not built")
+    from toothgroupnetwork_amd import _lib
+    cases = [(regression["p_xyz"], regression["p_offset"], regression["p_new_offset"]),
+             (synth.lattice_cloud(12, dup=100, seed=3), np.array([1828], np.int32), np.array([700], np.int32)),
+             (synth.arch_cloud(24000, 9, False), np.array([24000], np.int32), np.array([1024], np.int32))]
+    for xyz_np, off_np, noff_np in cases:
+        xyz, off, noff = T(xyz_np, dev), T(off_np, dev), T(noff_np, dev)
+        ref = ref_gpu.furthestsampling(xyz, off, noff)
+        out = torch.empty_like(ref)
+        n_max = int(np.diff(np.concatenate([[0], off_np])).max())
+        _lib.check(_lib.lib().tgn_furthestsampling(len(off_np), n_max, _lib.ptr(xyz), _lib.ptr(off), _lib.ptr(noff),
+                                                   None, _lib.ptr(out), None, _lib.FPS_TREE_TIES, _lib.stream()))
+        assert torch.equal(out, ref)
+
+
+# ------------------------------------------------------------------------------ square_distance
+def test_square_distance_matches_golden_bit_exact(dev, golden):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    got = U.square_distance(T(golden["sqd_src"], dev), T(golden["sqd_dst"], dev))
+    assert np.array_equal(got.cpu().numpy(), golden["sqd_out"])
+
+
+def test_square_distance_gradients(dev):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    a = torch.randn(2, 17, 3, device=dev, requires_grad=True)
+    b = torch.randn(2, 29, 3, device=dev, requires_grad=True)
+    g = torch.randn(2, 17, 29, device=dev)
+    U.square_distance(a, b).backward(g)
+    a2, b2 = a.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+    ((a2[:, :, None, :] - b2[:, None, :, :]) ** 2).sum(-1).backward(g)
+    torch.testing.assert_close(a.grad, a2.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(b.grad, b2.grad, rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------- ball query
+def test_ball_query_matches_golden(dev, golden):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    xyz, new_xyz = T(golden["ball_xyz"], dev), T(golden["ball_new_xyz"], dev)
+    for ri in range(4):
+        radius, ns = golden[f"ball_{ri}_cfg"]
+        got = U.query_ball_point(float(radius), int(ns), xyz, new_xyz)
+        assert got.dtype == torch.int64
+        assert np.array_equal(got.cpu().numpy(), golden[f"ball_{ri}_idx"].astype(np.int64)), radius
+
+
+@pytest.mark.parametrize("kind", ["arch", "uniform", "lattice"])
+def test_ball_query_vs_oracle(dev, oracle, kind):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    if kind == "lattice":
+        xyz = np.stack([synth.lattice_cloud(10, dup=50, seed=s) for s in (0, 1)])
+        radii = [(0.2223, 16), (0.45, 64)]  # radius on lattice spacings: boundary ties
+    else:
+        gen = (lambda s: synth.arch_cloud(5000, s, False)) if kind == "arch" else (lambda s: synth.uniform_cloud(5000, s))
+        xyz = np.stack([gen(s) for s in (0, 1, 2)])
+        radii = [(0.05, 32), (0.1, 32), (0.2, 64), (2.5, 8)]
+    q = xyz[:, ::7][:, :300]
+    for radius, ns in radii:
+        got = U.query_ball_point(radius, ns, T(xyz, dev), T(q, dev)).cpu().numpy()
+        assert np.array_equal(got, oracle.query_ball_point(radius, ns, xyz, q)), (kind, radius)
+
+
+def test_ball_query_edge_cases(dev, oracle):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    xyz = synth.uniform_cloud(130, 3)[None]
+    far = np.full((1, 3, 3), 40.0, np.float32)
+    got = U.query_ball_point(0.1, 5, T(xyz, dev), T(far, dev)).cpu().numpy()
+    assert (got == 130).all()  # no hit at all -> N, like the reference
+    # S = 0, nsample > N, N = 1
+    assert U.query_ball_point(0.1, 5, T(xyz, dev), torch.zeros(1, 0, 3, device=dev)).shape == (1, 0, 5)
+    got = U.query_ball_point(10.0, 200, T(xyz, dev), T(xyz[:, :4], dev)).cpu().numpy()
+    assert np.array_equal(got, oracle.query_ball_point(10.0, 200, xyz, xyz[:, :4]))
+    one = xyz[:, :1]
+    assert np.array_equal(U.query_ball_point(0.1, 3, T(one, dev), T(one, dev)).cpu().numpy(), np.zeros((1, 1, 3), np.int64))
+
+
+# ------------------------------------------------------------------- grouping / index_points / SA
+def test_sample_and_group_matches_golden(dev, golden):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    xyz, pts = T(golden["ball_xyz"], dev), T(golden["sag_points"], dev)
+    new_xyz, new_points = U.sample_and_group(128, 0.1, 16, xyz, pts)
+    assert np.array_equal(new_xyz.cpu().numpy(), golden["sag_new_xyz"])
+    np.testing.assert_allclose(new_points.cpu().numpy(), golden["sag_new_points"], rtol=0, atol=1e-5)
+    assert np.array_equal(new_points.cpu().numpy(), golden["sag_new_points"])  # copies and differences: exact
+    ax, ap = U.sample_and_group_all(xyz, pts)
+    assert np.array_equal(ap.cpu().numpy()[:, :, :64], golden["saga_new_points"])
+
+
+def test_group_points_orders_and_index_points(dev, oracle):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    rng = np.random.default_rng(0)
+    B, N, S, K, D = 2, 500, 40, 9, 13
+    xyz = rng.normal(size=(B, N, 3)).astype(np.float32)
+    pts = rng.normal(size=(B, N, D)).astype(np.float32)
+    new_xyz = xyz[:, :S].copy()
+    idx = rng.integers(0, N, size=(B, S, K))
+    for xyz_first in (True, False):
+        got = U.group_points(T(xyz, dev), T(new_xyz, dev), T(pts, dev), T(idx, dev), xyz_first=xyz_first)
+        assert np.array_equal(got.cpu().numpy(), oracle.group_points(xyz, new_xyz, pts, idx, xyz_first))
+    got = U.group_points(T(xyz, dev), T(new_xyz, dev), None, T(idx, dev))
+    assert np.array_equal(got.cpu().numpy(), oracle.group_points(xyz, new_xyz, None, idx))
+    for shape_idx in (idx[:, :, 0], idx):
+        got = U.index_points(T(pts, dev), T(shape_idx, dev))
+        assert np.array_equal(got.cpu().numpy(), oracle.index_points(pts, shape_idx))
+    # int32 indices are accepted too
+    got = U.index_points(T(pts, dev), T(idx.astype(np.int32), dev))
+    assert np.array_equal(got.cpu().numpy(), oracle.index_points(pts, idx))
+
+
+def test_group_points_empty_ball_is_reported(dev):
+    from toothgroupnetwork_amd import _lib, pointnet2_utils as U
+    xyz = T(synth.uniform_cloud(64, 1)[None], dev)
+    far = torch.full((1, 1, 3), 30.0, device=dev)
+    idx = U.query_ball_point(0.1, 4, xyz, far)          # all N: out of range, the reference would raise
+    U.group_points(xyz, far, None, idx)
+    assert _lib.lib().tgn_take_index_error(_lib.stream()) == 1
+    assert _lib.lib().tgn_take_index_error(_lib.stream()) == 0
+
+
+def test_grouping_autograd_matches_torch_indexing(dev):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    B, N, S, K, D = 2, 200, 16, 6, 5
+    xyz = torch.randn(B, N, 3, device=dev, requires_grad=True)
+    pts = torch.randn(B, N, D, device=dev, requires_grad=True)
+    cidx = torch.randint(0, N, (B, S), device=dev)
+    idx = torch.randint(0, N, (B, S, K), device=dev)
+    g = torch.randn(B, S, K, 3 + D, device=dev)
+    new_xyz = U.index_points(xyz, cidx)
+    U.group_points(xyz, new_xyz, pts, idx, xyz_first=True).backward(g)
+    x2, p2 = xyz.detach().clone().requires_grad_(), pts.detach().clone().requires_grad_()
+    bi = torch.arange(B, device=dev).view(B, 1, 1)
+    nx2 = x2[torch.arange(B, device=dev).view(B, 1), cidx]
+    ref = torch.cat([x2[bi, idx] - nx2.view(B, S, 1, 3), p2[bi, idx]], -1)
+    ref.backward(g)
+    torch.testing.assert_close(xyz.grad, x2.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(pts.grad, p2.grad, rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------- three_nn / interpolate
+def test_three_nn_and_interpolate_match_golden(dev, golden):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    d, i = U.three_nn(T(golden["tnn_xyz1"], dev), T(golden["tnn_xyz2"], dev))
+    assert np.array_equal(d.cpu().numpy(), golden["tnn_dist"])
+    assert np.array_equal(i.cpu().numpy(), golden["tnn_idx"].astype(np.int64))
+    out = U.three_interpolate(T(golden["tnn_feat2"], dev), d, i)
+    np.testing.assert_allclose(out.cpu().numpy(), golden["tnn_interp"], rtol=0, atol=1e-5)
+
+
+def test_three_nn_ties_and_small_support(dev, oracle):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    xyz2 = synth.lattice_cloud(6, dup=30, seed=2)[None]          # S = 246 with duplicates
+    xyz1 = synth.lattice_cloud(7, seed=3)[None]
+    d, i = U.three_nn(T(xyz1, dev), T(xyz2, dev))
+    od, oi = oracle.three_nn(xyz1, xyz2)
+    assert np.array_equal(d.cpu().numpy(), od) and np.array_equal(i.cpu().numpy(), oi)
+    big = synth.uniform_cloud(2500, 4)[None]                      # S > one LDS tile
+    d, i = U.three_nn(T(xyz1, dev), T(big, dev))
+    od, oi = oracle.three_nn(xyz1, big)
+    assert np.array_equal(d.cpu().numpy(), od) and np.array_equal(i.cpu().numpy(), oi)
+
+
+def test_three_interpolate_backward(dev):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    B, N, S, C = 2, 300, 50, 7
+    xyz1, xyz2 = torch.randn(B, N, 3, device=dev), torch.randn(B, S, 3, device=dev)
+    f = torch.randn(B, S, C, device=dev, requires_grad=True)
+    d, i = U.three_nn(xyz1, xyz2)
+    g = torch.randn(B, N, C, device=dev)
+    U.three_interpolate(f, d, i).backward(g)
+    f2 = f.detach().clone().requires_grad_()
+    w = 1.0 / (d + 1e-8)
+    w = w / w.sum(2, keepdim=True)
+    bi = torch.arange(B, device=dev).view(B, 1, 1)
+    (f2[bi, i] * w.unsqueeze(-1)).sum(2).backward(g)
+    torch.testing.assert_close(f.grad, f2.grad, rtol=1e-4, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------- kNN
+@pytest.mark.parametrize("k", [1, 3, 16, 36, 64, 100])
+def test_knn_vs_oracle_heap_order(dev, oracle, regression, k):
+    from toothgroupnetwork_amd import pointops as P
+    r = regression
+    q = r["p_xyz"][r["p_fps_idx"].astype(np.int64)]
+    idx, dist = P.knnquery(k, T(r["p_xyz"], dev), T(q, dev), T(r["p_offset"], dev), T(r["p_new_offset"], dev))
+    oi, od = oracle.knnquery(k, r["p_xyz"], q, r["p_offset"], r["p_new_offset"])
+    assert idx.dtype == torch.int32 and dist.dtype == torch.float32
+    assert np.array_equal(idx.cpu().numpy(), oi)          # includes the lattice segment: exact heap tie order
+    assert np.array_equal(dist.cpu().numpy(), od)
+    if k == 16:
+        assert np.array_equal(oi, r["p_knn_idx"])
+
+
+def test_knn_self_query_none_and_tensor_k(dev, oracle, regression):
+    from toothgroupnetwork_amd import pointops as P
+    r = regression
+    xyz, off = T(r["p_xyz"], dev), T(r["p_offset"], dev)
+    idx, dist = P.knnquery(torch.tensor(8, device=dev), xyz, None, off, off)   # 0-d CUDA tensor as k (basic_operators.py:30)
+    assert np.array_equal(idx.cpu().numpy(), r["p_knn_self_idx"])
+    assert np.array_equal(dist.cpu().numpy(), r["p_knn_self_dist"])
+
+
+def test_knn_vs_reference_kernel_on_this_gpu(dev, regression):
+    from oracle import ref_gpu
+    if not ref_gpu.available():
+        pytest.skip("oracle/_ref not built")
+    from toothgroupnetwork_amd import pointops as P
+    r = regression
+    xyz, off, noff = T(r["p_xyz"], dev), T(r["p_offset"], dev), T(r["p_new_offset"], dev)
+    q = xyz[T(r["p_fps_idx"], dev).long()].contiguous()
+    for k in (3, 24):
+        ri, rd2 = ref_gpu.knnquery(k, xyz, q, off, noff)
+        idx, d2 = P._knn_raw(k, xyz, q, off, noff)
+        assert torch.equal(idx, ri) and torch.equal(d2, rd2)
+
+
+# --------------------------------------------------------------------------- pointops gather ops
+def _rand_case(dev, n=300, m=120, ns=9, c=20, wc=5, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    feat = torch.randn(n, c, generator=g)
+    idx = torch.randint(0, n, (m, ns), generator=g, dtype=torch.int32)
+    return feat.to(dev), idx.to(dev)
+
+
+def test_grouping_fwd_bwd(dev, oracle):
+    from toothgroupnetwork_amd import pointops as P
+    feat, idx = _rand_case(dev)
+    feat.requires_grad_()
+    out = P.grouping(feat, idx)
+    assert np.array_equal(out.detach().cpu().numpy(), oracle.grouping_forward(feat.detach().cpu().numpy(), idx.cpu().numpy()))
+    g = torch.randn_like(out)
+    out.backward(g)
+    np.testing.assert_allclose(feat.grad.cpu().numpy(),
+                               oracle.grouping_backward(g.cpu().numpy(), idx.cpu().numpy(), feat.shape[0]), atol=1e-5, rtol=1e-5)
+
+
+def test_subtraction_aggregation_interpolation_fwd_bwd(dev, oracle):
+    from toothgroupnetwork_amd import pointops as P
+    n, ns, c, wc = 250, 8, 16, 4
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(n, c, generator=g).to(dev).requires_grad_()
+    b = torch.randn(n, c, generator=g).to(dev).requires_grad_()
+    idx = torch.randint(0, n, (n, ns), generator=g, dtype=torch.int32).to(dev)
+    out = P.subtraction(a, b, idx)
+    A, Bn, I = a.detach().cpu().numpy(), b.detach().cpu().numpy(), idx.cpu().numpy()
+    assert np.array_equal(out.detach().cpu().numpy(), oracle.subtraction_forward(A, Bn, I))
+    go = torch.randn_like(out)
+    out.backward(go)
+    g1, g2 = oracle.subtraction_backward(I, go.cpu().numpy())
+    np.testing.assert_allclose(a.grad.cpu().numpy(), g1, atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), g2, atol=1e-5, rtol=1e-5)
+
+    pos = torch.randn(n, ns, c, generator=g).to(dev).requires_grad_()
+    w = torch.randn(n, ns, wc, generator=g).to(dev).requires_grad_()
+    x = torch.randn(n, c, generator=g).to(dev).requires_grad_()
+    out = P.aggregation(x, pos, w, idx)
+    X, Pn, W = x.detach().cpu().numpy(), pos.detach().cpu().numpy(), w.detach().cpu().numpy()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), oracle.aggregation_forward(X, Pn, W, I), atol=1e-5, rtol=1e-5)
+    go = torch.randn_like(out)
+    out.backward(go)
+    gi, gp, gw = oracle.aggregation_backward(X, Pn, W, I, go.cpu().numpy())
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gi, atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(pos.grad.cpu().numpy(), gp, atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), gw, atol=1e-4, rtol=1e-4)
+
+
+def test_interpolation_and_queryandgroup_vs_oracle(dev, oracle, regression):
+    from toothgroupnetwork_amd import pointops as P
+    r = regression
+    xyz_np, off_np, noff_np = r["p_xyz"], r["p_offset"], r["p_new_offset"]
+    q_np = xyz_np[r["p_fps_idx"].astype(np.int64)]
+    rng = np.random.default_rng(5)
+    feat_q = rng.normal(size=(q_np.shape[0], 12)).astype(np.float32)      # features on the coarse set
+    xyz, off, noff, q = T(xyz_np, dev), T(off_np, dev), T(noff_np, dev), T(q_np, dev)
+    for k in (1, 3):
+        fq = T(feat_q, dev).requires_grad_()
+        out = P.interpolation(q, xyz, fq, noff, off, k=k)                  # coarse -> fine (blocks.py:110)
+        ref, oidx, ow = oracle.interpolation(q_np, xyz_np, feat_q, noff_np, off_np, k=k)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=1e-5, rtol=1e-5)
+        go = torch.randn_like(out)
+        out.backward(go)
+        np.testing.assert_allclose(fq.grad.cpu().numpy(), oracle.interpolation_backward(go.cpu().numpy(), oidx, ow, feat_q.shape[0]),
+                                   atol=1e-4, rtol=1e-4)
+        out2 = P.interpolation2(q, xyz, T(feat_q, dev), noff, off, k)
+        np.testing.assert_allclose(out2.cpu().numpy(), ref, atol=1e-5, rtol=1e-5)
+    feat = rng.normal(size=(xyz_np.shape[0], 10)).astype(np.float32)
+    for use_xyz in (True, False):
+        got = P.queryandgroup(16, xyz, q, T(feat, dev), None, off, noff, use_xyz=use_xyz)
+        ref = oracle.queryandgroup(16, xyz_np, q_np, feat, None, off_np, noff_np, use_xyz=use_xyz)
+        assert np.array_equal(got.cpu().numpy(), ref)
+    # gradient of queryandgroup == torch fancy indexing (what the reference relies on, pointops.py:89-95)
+    f = T(feat, dev).requires_grad_()
+    idx, _ = P.knnquery(16, xyz, q, off, noff)
+    go = torch.randn(q.shape[0], 16, 13, device=dev)
+    P.queryandgroup(16, xyz, q, f, idx, off, noff).backward(go)
+    f2 = T(feat, dev).requires_grad_()
+    torch.cat([xyz[idx.long().view(-1)].view(-1, 16, 3) - q.unsqueeze(1), f2[idx.long().view(-1)].view(-1, 16, 10)], -1).backward(go)
+    torch.testing.assert_close(f.grad, f2.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_gather_family_vs_reference_kernels_on_this_gpu(dev):
+    from oracle import ref_gpu
+    if not ref_gpu.available():
+        pytest.skip("oracle/_ref not built")
+    from toothgroupnetwork_amd import _lib
+    L, S_, p = _lib.lib(), _lib.stream, _lib.ptr
+    n, ns, c, wc = 400, 12, 32, 8
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, c, generator=g).to(dev)
+    y = torch.randn(n, c, generator=g).to(dev)
+    idx = torch.randint(0, n, (n, ns), generator=g, dtype=torch.int32).to(dev)
+    pos = torch.randn(n, ns, c, generator=g).to(dev)
+    w = torch.randn(n, ns, wc, generator=g).to(dev)
+    go3 = torch.randn(n, ns, c, generator=g).to(dev)
+    go2 = torch.randn(n, c, generator=g).to(dev)
+    out = torch.empty(n, ns, c, device=dev)
+    _lib.check(L.tgn_grouping_forward(n, ns, c, p(x), p(idx), p(out), S_()))
+    assert torch.equal(out, ref_gpu.grouping_forward(x, idx))
+    _lib.check(L.tgn_subtraction_forward(n, ns, c, p(x), p(y), p(idx), p(out), S_()))
+    assert torch.equal(out, ref_gpu.subtraction_forward(x, y, idx))
+    o2 = torch.zeros(n, c, device=dev)
+    _lib.check(L.tgn_aggregation_forward(n, ns, c, wc, p(x), p(pos), p(w), p(idx), p(o2), S_()))
+    torch.testing.assert_close(o2, ref_gpu.aggregation_forward(x, pos, w, idx), rtol=1e-5, atol=1e-5)
+    gi = torch.zeros(n, c, device=dev)
+    _lib.check(L.tgn_grouping_backward(n, ns, c, p(go3), p(idx), p(gi), S_()))
+    torch.testing.assert_close(gi, ref_gpu.grouping_backward(go3, idx, n), rtol=1e-5, atol=1e-5)
+    g1, g2 = torch.zeros(n, c, device=dev), torch.zeros(n, c, device=dev)
+    _lib.check(L.tgn_subtraction_backward(n, ns, c, p(idx), p(go3), p(g1), p(g2), S_()))
+    r1, r2 = ref_gpu.subtraction_backward(idx, go3)
+    torch.testing.assert_close(g1, r1, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(g2, r2, rtol=1e-5, atol=1e-5)
+    a, b_, c_ = torch.zeros_like(x), torch.zeros_like(pos), torch.zeros_like(w)
+    _lib.check(L.tgn_aggregation_backward(n, ns, c, wc, p(x), p(pos), p(w), p(idx), p(go2), p(a), p(b_), p(c_), S_()))
+    ra, rb, rc = ref_gpu.aggregation_backward(x, pos, w, idx, go2)
+    torch.testing.assert_close(a, ra, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(b_, rb, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(c_, rc, rtol=1e-4, atol=1e-4)
+    k = 3
+    ik = idx[:, :k].contiguous()
+    wk = torch.rand(n, k, generator=g).to(dev)
+    o3 = torch.zeros(n, c, device=dev)
+    _lib.check(L.tgn_interpolation_forward(n, c, k, p(x), p(ik), p(wk), p(o3), S_()))
+    torch.testing.assert_close(o3, ref_gpu.interpolation_forward(x, ik, wk), rtol=1e-5, atol=1e-5)
+    g3 = torch.zeros(n, c, device=dev)
+    _lib.check(L.tgn_interpolation_backward(n, c, k, p(go2), p(ik), p(wk), p(g3), S_()))
+    torch.testing.assert_close(g3, ref_gpu.interpolation_backward(go2, ik, wk, n), rtol=1e-5, atol=1e-5)
+
+
+def test_pointops_cuda_shim_runs_reference_style_code(dev, oracle):
+    """The legacy native-module API (pointops_api.cpp:13-22): caller-allocated, pre-initialised buffers."""
+    import pointops_cuda
+    xyz_np = synth.uniform_cloud(900, 2)
+    xyz = T(xyz_np, dev)
+    off = torch.tensor([900], dtype=torch.int32, device=dev)
+    noff = torch.tensor([100], dtype=torch.int32, device=dev)
+    idx = torch.zeros(100, dtype=torch.int32, device=dev)
+    tmp = torch.full((900,), 1e10, device=dev)
+    pointops_cuda.furthestsampling_cuda(1, 900, xyz, off, noff, tmp, idx)
+    assert np.array_equal(idx.cpu().numpy(), oracle.furthestsampling(xyz_np, [900], [100]))
+    kidx = torch.zeros(900, 5, dtype=torch.int32, device=dev)
+    kd2 = torch.zeros(900, 5, device=dev)
+    pointops_cuda.knnquery_cuda(900, 5, xyz, xyz, off, off, kidx, kd2)
+    oi, od = oracle.knnquery(5, xyz_np, xyz_np, [900], [900])
+    assert np.array_equal(kidx.cpu().numpy(), oi) and np.array_equal(torch.sqrt(kd2).cpu().numpy(), od)
+    out = torch.empty(900, 5, 3, device=dev)
+    pointops_cuda.grouping_forward_cuda(900, 5, 3, xyz, kidx, out)
+    assert np.array_equal(out.cpu().numpy(), xyz_np[oi])
