@@ -1,0 +1,421 @@
+// ball_query.hip -- pointnet2_utils.query_ball_point (pointnet2_utils.py:120-144) for gfx950.
+//
+// Semantics (bit-exact with the reference on the same scans): for every query, the first `nsample`
+// point indices IN ASCENDING INDEX ORDER whose expanded-form squared distance
+//     d = ((-2*fma(z1,z2,fma(y1,y2,x1*x2))) + |q|^2) + |p|^2          (pointnet2_utils.py:38-41)
+// is not greater than fp32(radius^2); short rows are padded with the first hit; a row without a
+// hit is filled with N.  The reference gets there with a (B,S,N) int64 matrix, a mask and a SORT
+// over N (786 MB of temporaries per 24k scan at S=4096); nothing of that is materialised here.
+//
+// Two kernels:
+//  * scan : one wave per query walks the cloud in index order, 64 candidates per step, compacts
+//           hits with ballot + mbcnt and stops as soon as nsample hits are found.  O(S*N), exact by
+//           construction; used for small clouds, huge radii and non-finite input.
+//  * grid : a per-cloud uniform grid (cell >= radius) is built in LDS by one workgroup per cloud
+//           (bbox reduce -> cell histogram with LDS atomics -> scan -> scatter of (x,y,z,index)
+//           records, so a cell's points are one contiguous, coalesced 16-B stream).  A query wave then
+//           visits the <= 9 contiguous runs of its 3x3x3 neighbourhood, applies the SAME expanded-form
+//           test to each candidate (the grid only prunes, it never decides), collects hits in LDS and
+//           rank-selects the nsample smallest indices.  ~100-200 candidates per query instead of N.
+//
+// Why the grid cannot change a result: a point passes the reference test only if d_fp <= r2 where
+// |d_fp - d_true| <= 1e-5 * M^2 (M = largest |coordinate|; the bound is ~2.5x the worst-case fp32
+// rounding of the expanded form), so its true distance is <= sqrt(r2 + 1e-5*M^2) =: r_eff.  Cells are
+// r_eff * 1.001 wide or wider and cell coordinates of points and queries come from the same fp32
+// expression, so such a point is at most one cell away on every axis.  Clouds containing non-finite
+// coordinates (NaN compares as "inside" in the reference) take the scan path.
+#include "tgn_common.h"
+
+namespace tgn {
+
+// ------------------------------------------------------------------------------------------------
+// scan path
+// ------------------------------------------------------------------------------------------------
+template <typename IdxT>
+__device__ __forceinline__ void ball_scan_row(int N, int K, float r2, const float *__restrict__ pts, float cx,
+                                              float cy, float cz, IdxT *__restrict__ row, int lane) {
+    const float s1 = sumsq3(cx, cy, cz);
+    int cnt = 0;
+    int first = N;
+    for (int basek = 0; basek < N && cnt < K; basek += kWave) {
+        const int k = basek + lane;
+        bool hit = false;
+        if (k < N) {
+            const float px = pts[(size_t)k * 3 + 0], py = pts[(size_t)k * 3 + 1], pz = pts[(size_t)k * 3 + 2];
+            const float d = sqdist_expanded(cx, cy, cz, s1, px, py, pz, sumsq3(px, py, pz));
+            hit = !(d > r2);  // the reference masks `sqrdists > radius**2` (pointnet2_utils.py:135)
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+            const int pos = cnt + mbcnt(mask);
+            if (hit && pos < K) row[pos] = (IdxT)k;
+            if (cnt == 0) first = basek + __builtin_ctzll(mask);
+            cnt += __popcll(mask);
+        }
+    }
+    if (cnt > K) cnt = K;
+    for (int j = cnt + lane; j < K; j += kWave) row[j] = (IdxT)first;  // pad with the first hit (:138-141)
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void ball_query_scan_kernel(int B, int N, int S, int K, float r2,
+                                                               const float *__restrict__ xyz,
+                                                               const float *__restrict__ new_xyz,
+                                                               IdxT *__restrict__ out) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wpb = blockDim.x / kWave;
+    const long long total = (long long)B * S;
+    for (long long q = (long long)blockIdx.x * wpb + threadIdx.x / kWave; q < total; q += (long long)gridDim.x * wpb) {
+        const int b = (int)(q / S);
+        ball_scan_row<IdxT>(N, K, r2, xyz + (size_t)b * N * 3, new_xyz[q * 3 + 0], new_xyz[q * 3 + 1],
+                            new_xyz[q * 3 + 2], out + q * K, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid path
+// ------------------------------------------------------------------------------------------------
+constexpr int kGridCells = 16384;   // cells per cloud (LDS histogram: 64 KiB)
+constexpr int kGridThreads = 1024;
+constexpr int kHitCap = 512;        // per-wave hit buffer (indices)
+constexpr int kGridMaxK = 256;
+
+struct GridHeader {   // one per cloud, 64 bytes
+    float lo[3];
+    float inv_h;
+    int g[3];
+    int use_scan;     // 1: this cloud must take the scan path (non-finite data, degenerate grid)
+    int pad[8];
+};
+
+__host__ __device__ inline size_t grid_cloud_bytes(int N) {
+    // header + cell_start[kGridCells+1] (padded to 16 B) + N float4 records
+    return sizeof(GridHeader) + (size_t)((kGridCells + 1 + 3) / 4 * 4) * sizeof(int) + (size_t)N * sizeof(float4);
+}
+
+__device__ __forceinline__ int cell_coord(float p, float lo, float inv_h, int g) {
+    // identical expression for points and queries; clamped to [-1, g] so far-away queries stay comparable
+    float t = (p - lo) * inv_h;
+    t = fminf(fmaxf(t, -1.0f), (float)g);
+    return (int)floorf(t);
+}
+
+__device__ __forceinline__ float wave_min_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__global__ __launch_bounds__(kGridThreads) void ball_grid_build_kernel(int N, float r2, const float *__restrict__ xyz,
+                                                                        unsigned char *__restrict__ ws) {
+    __shared__ int cnt[kGridCells];
+    __shared__ float red[7][kGridThreads / kWave];
+    __shared__ int wave_tot[kGridThreads / kWave];
+    __shared__ GridHeader hdr_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *__restrict__ pts = xyz + (size_t)b * N * 3;
+    unsigned char *base = ws + (size_t)b * grid_cloud_bytes(N);
+    GridHeader *hdr = (GridHeader *)base;
+    int *cell_start = (int *)(base + sizeof(GridHeader));
+    float4 *rec = (float4 *)(base + sizeof(GridHeader) + (size_t)((kGridCells + 1 + 3) / 4 * 4) * sizeof(int));
+
+    // 1. bounding box, largest |coordinate|, non-finite census
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float bad = 0.0f;
+    for (int k = tid; k < N; k += kGridThreads) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = pts[(size_t)k * 3 + a];
+            if (!(fabsf(v) <= 3.0e38f)) bad = 1.0f;  // NaN or inf
+            lo[a] = fminf(lo[a], v);
+            hi[a] = fmaxf(hi[a], v);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float l = wave_min_f32(lo[a]), h = wave_max_f32(hi[a]);
+        if (lane == 0) {
+            red[a][wave] = l;
+            red[3 + a][wave] = h;
+        }
+    }
+    {
+        const float bb = wave_max_f32(bad);
+        if (lane == 0) red[6][wave] = bb;
+    }
+    for (int i = tid; i < kGridCells; i += kGridThreads) cnt[i] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        GridHeader h;
+        float ext[3], m = 0.0f, any_bad = 0.0f;
+        for (int a = 0; a < 3; ++a) {
+            float l = INFINITY, u = -INFINITY;
+            for (int w = 0; w < kGridThreads / kWave; ++w) {
+                l = fminf(l, red[a][w]);
+                u = fmaxf(u, red[3 + a][w]);
+            }
+            h.lo[a] = l;
+            ext[a] = u - l;
+            m = fmaxf(m, fmaxf(fabsf(l), fabsf(u)));
+        }
+        for (int w = 0; w < kGridThreads / kWave; ++w) any_bad = fmaxf(any_bad, red[6][w]);
+        // queries may lie outside the points' box; their coordinates are bounded by the caller's data too,
+        // but to stay safe the margin uses 4*M^2 (|q| up to 2M from the box still covered)
+        const float r_eff = sqrtf(fmaxf(r2, 0.0f) + 4.0e-5f * m * m) * 1.001f + 1e-30f;
+        float hcell = r_eff;
+        int g[3];
+        for (int it = 0; it < 64; ++it) {
+            const float inv = 1.0f / hcell;
+            long long cells = 1;
+            for (int a = 0; a < 3; ++a) {
+                const float t = ext[a] * inv;   // same expression as cell_coord(hi) -> floor(t) = g-1
+                g[a] = (t < 1.0e6f) ? (int)floorf(t) + 1 : 1000001;
+                cells *= g[a];
+            }
+            if (cells <= kGridCells) break;
+            hcell *= 1.1f;
+        }
+        h.inv_h = 1.0f / hcell;
+        long long cells = 1;
+        for (int a = 0; a < 3; ++a) {
+            h.g[a] = g[a];
+            cells *= g[a];
+        }
+        // degenerate grids (everything in a handful of cells) cannot prune: the early-exit scan is better
+        h.use_scan = (any_bad > 0.0f || !(r2 >= 0.0f) || cells > kGridCells || cells < 8 || N == 0) ? 1 : 0;
+        for (int i = 0; i < 8; ++i) h.pad[i] = 0;
+        hdr_s = h;
+        *hdr = h;
+    }
+    __syncthreads();
+    const GridHeader h = hdr_s;
+    if (h.use_scan) return;
+
+    // 2. histogram
+    for (int k = tid; k < N; k += kGridThreads) {
+        const int cx = cell_coord(pts[(size_t)k * 3 + 0], h.lo[0], h.inv_h, h.g[0]);
+        const int cy = cell_coord(pts[(size_t)k * 3 + 1], h.lo[1], h.inv_h, h.g[1]);
+        const int cz = cell_coord(pts[(size_t)k * 3 + 2], h.lo[2], h.inv_h, h.g[2]);
+        atomicAdd(&cnt[(cz * h.g[1] + cy) * h.g[0] + cx], 1);
+    }
+    __syncthreads();
+    // 3. exclusive scan of the histogram: 16 cells per thread, wave scan, block scan
+    constexpr int PER = kGridCells / kGridThreads;
+    int local[PER];
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        local[i] = sum;
+        sum += cnt[tid * PER + i];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == kWave - 1) wave_tot[wave] = incl;
+    __syncthreads();
+    int wave_base = 0;
+    for (int w = 0; w < wave; ++w) wave_base += wave_tot[w];
+    const int thread_base = wave_base + incl - sum;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int v = thread_base + local[i];
+        cell_start[tid * PER + i] = v;
+        cnt[tid * PER + i] = v;  // running insert position
+    }
+    if (tid == kGridThreads - 1) cell_start[kGridCells] = thread_base + sum;
+    __syncthreads();
+    // 4. scatter (order inside a cell is arbitrary: the query kernel rank-selects by index)
+    for (int k = tid; k < N; k += kGridThreads) {
+        const float px = pts[(size_t)k * 3 + 0], py = pts[(size_t)k * 3 + 1], pz = pts[(size_t)k * 3 + 2];
+        const int cx = cell_coord(px, h.lo[0], h.inv_h, h.g[0]);
+        const int cy = cell_coord(py, h.lo[1], h.inv_h, h.g[1]);
+        const int cz = cell_coord(pz, h.lo[2], h.inv_h, h.g[2]);
+        const int pos = atomicAdd(&cnt[(cz * h.g[1] + cy) * h.g[0] + cx], 1);
+        rec[pos] = make_float4(px, py, pz, __int_as_float(k));
+    }
+}
+
+// Rank-select: entry e of buf[0..H) gets rank = #entries smaller than it (indices are distinct).
+// Entries with rank < K are written to dst[rank].  Each lane owns entries lane, lane+64, ...
+template <int OWN, typename DstT>
+__device__ __forceinline__ void rank_select_n(const int *buf, int H, int K, DstT *dst, int lane) {
+    int mine[OWN], rank[OWN];
+#pragma unroll
+    for (int o = 0; o < OWN; ++o) {
+        const int e = lane + o * kWave;
+        mine[o] = e < H ? buf[e] : 0x7FFFFFFF;
+        rank[o] = 0;
+    }
+    for (int i = 0; i < H; ++i) {
+        const int v = buf[i];  // LDS broadcast read
+#pragma unroll
+        for (int o = 0; o < OWN; ++o) rank[o] += (v < mine[o]) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 0; o < OWN; ++o) {
+        const int e = lane + o * kWave;
+        if (e < H && rank[o] < K) dst[rank[o]] = (DstT)mine[o];
+    }
+}
+
+template <typename DstT>
+__device__ __forceinline__ void rank_select(const int *buf, int H, int K, DstT *dst, int lane) {
+    if (H <= kWave)  // wave-uniform
+        rank_select_n<1, DstT>(buf, H, K, dst, lane);
+    else if (H <= 2 * kWave)
+        rank_select_n<2, DstT>(buf, H, K, dst, lane);
+    else
+        rank_select_n<kHitCap / kWave, DstT>(buf, H, K, dst, lane);
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void ball_grid_query_kernel(int B, int N, int S, int K, float r2,
+                                                               const float *__restrict__ xyz,
+                                                               const float *__restrict__ new_xyz,
+                                                               const unsigned char *__restrict__ ws,
+                                                               IdxT *__restrict__ out) {
+    __shared__ int hits_s[4][kHitCap];
+    __shared__ int keep_s[4][kGridMaxK];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = threadIdx.x / kWave;
+    int *hits = hits_s[wv];
+    int *keep = keep_s[wv];
+    const long long total = (long long)B * S;
+    const size_t cloud_bytes = grid_cloud_bytes(N);
+    for (long long q = (long long)blockIdx.x * 4 + wv; q < total; q += (long long)gridDim.x * 4) {
+        const int b = (int)(q / S);
+        const unsigned char *base = ws + (size_t)b * cloud_bytes;
+        const GridHeader *hdr = (const GridHeader *)base;
+        const float cx = new_xyz[q * 3 + 0], cy = new_xyz[q * 3 + 1], cz = new_xyz[q * 3 + 2];
+        IdxT *__restrict__ row = out + q * K;
+        const bool q_finite = fabsf(cx) <= 3.0e38f && fabsf(cy) <= 3.0e38f && fabsf(cz) <= 3.0e38f;
+        if (hdr->use_scan || !q_finite) {  // wave-uniform
+            ball_scan_row<IdxT>(N, K, r2, xyz + (size_t)b * N * 3, cx, cy, cz, row, lane);
+            continue;
+        }
+        const int *__restrict__ cell_start = (const int *)(base + sizeof(GridHeader));
+        const float4 *__restrict__ rec =
+            (const float4 *)(base + sizeof(GridHeader) + (size_t)((kGridCells + 1 + 3) / 4 * 4) * sizeof(int));
+        const int gx = hdr->g[0], gy = hdr->g[1], gz = hdr->g[2];
+        const float inv_h = hdr->inv_h;
+        const int qx = cell_coord(cx, hdr->lo[0], inv_h, gx);
+        const int qy = cell_coord(cy, hdr->lo[1], inv_h, gy);
+        const int qz = cell_coord(cz, hdr->lo[2], inv_h, gz);
+        const int x0 = max(qx - 1, 0), x1 = min(qx + 1, gx - 1);
+        // lanes 0..8: the (dy,dz) runs of up to three x-adjacent cells, contiguous in cell order
+        int rs = 0, re = 0;
+        if (lane < 9 && x0 <= x1) {
+            const int yy = qy + (lane % 3) - 1, zz = qz + (lane / 3) - 1;
+            if (yy >= 0 && yy < gy && zz >= 0 && zz < gz) {
+                const int c0 = (zz * gy + yy) * gx;
+                rs = cell_start[c0 + x0];
+                re = cell_start[c0 + x1 + 1];
+            }
+        }
+        const float s1 = sumsq3(cx, cy, cz);
+        int H = 0;       // entries in the buffer
+        int total_hits = 0;
+        for (int r = 0; r < 9; ++r) {
+            const int s = __builtin_amdgcn_readlane(rs, r), e = __builtin_amdgcn_readlane(re, r);
+            for (int j0 = s; j0 < e; j0 += kWave) {
+                const int j = j0 + lane;
+                bool hit = false;
+                int pidx = 0;
+                if (j < e) {
+                    const float4 p = rec[j];
+                    const float d = sqdist_expanded(cx, cy, cz, s1, p.x, p.y, p.z, sumsq3(p.x, p.y, p.z));
+                    hit = !(d > r2);
+                    pidx = __float_as_int(p.w);
+                }
+                const unsigned long long mask = __ballot(hit);
+                if (mask == 0) continue;
+                const int nh = __popcll(mask);
+                if (H + nh > kHitCap) {
+                    // compact: only the K smallest indices can matter
+                    rank_select<int>(hits, H, K, keep, lane);
+                    const int nk = H < K ? H : K;
+                    for (int i = lane; i < nk; i += kWave) hits[i] = keep[i];
+                    H = nk;
+                }
+                if (hit) hits[H + mbcnt(mask)] = pidx;
+                H += nh;
+                total_hits += nh;
+            }
+        }
+        if (H == 0) {
+            for (int j = lane; j < K; j += kWave) row[j] = (IdxT)N;  // no hit at all -> N (:136-141)
+            continue;
+        }
+        rank_select<IdxT>(hits, H, K, row, lane);
+        if (H < K) {
+            // first hit = smallest index in the buffer
+            int mn = 0x7FFFFFFF;
+            for (int i = lane; i < H; i += kWave) mn = min(mn, hits[i]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
+            for (int j = H + lane; j < K; j += kWave) row[j] = (IdxT)mn;
+        }
+        (void)total_hits;
+    }
+}
+
+static bool use_grid(int N, int S, int K) {
+    // the grid pays off once the per-query scan (N/64 steps) clearly exceeds a neighbourhood visit
+    return N >= 2048 && (long long)S * 8 >= N / 64 && K <= kGridMaxK;
+}
+
+}  // namespace tgn
+
+using namespace tgn;
+
+TGN_API size_t tgn_ball_query_workspace_bytes(int B, int N, int S) {
+    if (B <= 0 || N <= 0 || S <= 0) return 0;
+    return (size_t)B * grid_cloud_bytes(N);
+}
+
+TGN_API int tgn_ball_query(int B, int N, int S, int nsample, float r2, const float *xyz, const float *new_xyz,
+                           void *idx, int idx_is_int64, void *workspace, size_t workspace_bytes,
+                           tgn_stream_t stream) {
+    if (B < 0 || N < 0 || S < 0 || nsample < 0) {
+        set_error("tgn_ball_query: negative size");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    const long long total = (long long)B * S;
+    if (total == 0 || nsample == 0) return TGN_OK;
+    if (!xyz || !new_xyz || !idx) {
+        set_error("tgn_ball_query: null pointer");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    long long blocks = (total + 3) / 4;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    const bool grid = use_grid(N, S, nsample) && workspace && workspace_bytes >= (size_t)B * grid_cloud_bytes(N);
+    if (grid) {
+        hipLaunchKernelGGL(ball_grid_build_kernel, dim3(B), dim3(kGridThreads), 0, st, N, r2, xyz,
+                           (unsigned char *)workspace);
+        if (int rc = check_launch("ball_grid_build_kernel")) return rc;
+        if (idx_is_int64)
+            hipLaunchKernelGGL((ball_grid_query_kernel<long long>), dim3((unsigned)blocks), dim3(256), 0, st, B, N, S,
+                               nsample, r2, xyz, new_xyz, (const unsigned char *)workspace, (long long *)idx);
+        else
+            hipLaunchKernelGGL((ball_grid_query_kernel<int>), dim3((unsigned)blocks), dim3(256), 0, st, B, N, S, nsample,
+                               r2, xyz, new_xyz, (const unsigned char *)workspace, (int *)idx);
+        return check_launch("ball_grid_query_kernel");
+    }
+    if (idx_is_int64)
+        hipLaunchKernelGGL((ball_query_scan_kernel<long long>), dim3((unsigned)blocks), dim3(256), 0, st, B, N, S,
+                           nsample, r2, xyz, new_xyz, (long long *)idx);
+    else
+        hipLaunchKernelGGL((ball_query_scan_kernel<int>), dim3((unsigned)blocks), dim3(256), 0, st, B, N, S, nsample, r2,
+                           xyz, new_xyz, (int *)idx);
+    return check_launch("ball_query_scan_kernel");
+}

@@ -168,36 +168,73 @@ __global__ __launch_bounds__(256) void aggregation_bwd_kernel(long long rows, in
 }
 
 // ---- pointnet2_utils composites -------------------------------------------------------------------
-template <typename IdxT>
-__global__ __launch_bounds__(256) void group_points_kernel(long long rows, int N, int S, int K, int D, int cx_log2,
-                                                            const float *__restrict__ xyz,
+// group_points: one wave per query (b,s).  The wave's output, K rows of C = 3+D floats, is ONE contiguous
+// region of K*C floats, so lanes walk the flattened (k,c) space four elements at a time and store 16 B
+// each (1 KiB per wave-instruction, fully coalesced) however odd C is (9, 131, 515 at Shape A).  The
+// neighbour indices of the query sit in LDS; (k,c) of a lane's first element comes from one magic-number
+// division, the other three by increment-and-wrap.
+constexpr int kGroupMaxK = 512;
+
+template <typename IdxT, int VEC>
+__global__ __launch_bounds__(256) void group_points_kernel(long long queries, int N, int S, int K, int D,
+                                                            unsigned magicC, const float *__restrict__ xyz,
                                                             const float *__restrict__ new_xyz,
                                                             const float *__restrict__ points,
                                                             const IdxT *__restrict__ idx, int xyz_first,
                                                             float *__restrict__ out, int *__restrict__ err) {
+    __shared__ int sidx[4][kGroupMaxK];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = threadIdx.x / kWave;
     const int C = 3 + D;
-    const int xo = xyz_first ? 0 : D;
-    const int fo = xyz_first ? 3 : 0;
-    TGN_ROW_LOOP(rows) {  // r = (b*S + s)*K + j
-        const long long q = r / K;
+    const int xo = xyz_first ? 0 : D;   // first channel of the relative coordinates
+    const int fo = xyz_first ? 3 : 0;   // first channel of the features
+    const int total = K * C;
+    for (long long q = (long long)blockIdx.x * 4 + wv; q < queries; q += (long long)gridDim.x * 4) {
         const int b = (int)(q / S);
-        const long long k = (long long)idx[r];
-        if (k < 0 || k >= N) {  // empty ball -> index N: the reference's advanced indexing raises
-            if (tx == 0) atomicOr(err, 1);
-            continue;
+        const float cq0 = new_xyz[q * 3 + 0], cq1 = new_xyz[q * 3 + 1], cq2 = new_xyz[q * 3 + 2];
+        bool bad = false;
+        for (int k = lane; k < K; k += kWave) {
+            long long v = (long long)idx[q * K + k];
+            if (v < 0 || v >= N) {  // empty ball -> index N: the reference's advanced indexing raises
+                bad = true;
+                v = -1;
+            }
+            sidx[wv][k] = (int)v;
         }
-        const float *p = xyz + ((size_t)b * N + k) * 3;
-        const float *cq = new_xyz + (size_t)q * 3;
-        const float *f = points + ((size_t)b * N + k) * D;
-        float *dst = out + (size_t)r * C;
-        for (int ci = tx; ci < C; ci += cx) {
-            const int cx3 = ci - xo;
-            float v;
-            if (cx3 >= 0 && cx3 < 3)
-                v = p[cx3] - cq[cx3];
-            else
-                v = f[ci - fo];
-            dst[ci] = v;
+        if (__any(bad) && lane == 0) atomicOr(err, 1);
+        // (same wave wrote sidx: LDS ops of one wave complete in order, no barrier needed)
+        const size_t pbase = (size_t)b * N;
+        float *__restrict__ dst = out + (size_t)q * total;
+        for (int e0 = lane * VEC; e0 < total; e0 += kWave * VEC) {
+            int k = (int)__umulhi((unsigned)e0, magicC);  // e0 / C (exact for e0 < 2^32 / C)
+            int c = e0 - k * C;
+            float v[VEC];
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) {
+                float val = 0.0f;
+                if (e0 + u < total) {
+                    const int pi = sidx[wv][k];
+                    if (pi >= 0) {
+                        const int cx3 = c - xo;
+                        if (cx3 >= 0 && cx3 < 3) {
+                            const float cqv = cx3 == 0 ? cq0 : (cx3 == 1 ? cq1 : cq2);
+                            val = xyz[(pbase + pi) * 3 + cx3] - cqv;
+                        } else {
+                            val = points[(pbase + pi) * D + (c - fo)];
+                        }
+                    }
+                }
+                v[u] = val;
+                if (++c == C) {
+                    c = 0;
+                    ++k;
+                }
+            }
+            if constexpr (VEC == 4) {
+                *(float4 *)(dst + e0) = make_float4(v[0], v[1], v[2], v[3]);  // total % 4 == 0 here
+            } else {
+                dst[e0] = v[0];
+            }
         }
     }
 }
@@ -367,22 +404,33 @@ TGN_API int tgn_aggregation_backward(int n, int nsample, int c, int w_c, const f
 TGN_API int tgn_group_points(int B, int N, int S, int K, int D, const float *xyz, const float *new_xyz,
                              const float *points, const void *idx, int idx_is_int64, int xyz_first, float *out,
                              tgn_stream_t stream) {
-    const long long rows = (long long)B * S * K;
-    if (rows <= 0) return TGN_OK;
+    const long long queries = (long long)B * S;
+    if (queries <= 0 || K <= 0) return TGN_OK;
     if (!xyz || !new_xyz || !idx || !out) {
         set_error("tgn_group_points: null pointer");
         return TGN_ERR_INVALID_ARGUMENT;
     }
     if (!points) D = 0;
+    if (K > kGroupMaxK || D < 0 || (long long)K * (3 + D) >= (1LL << 31) / (3 + D)) {
+        set_error("tgn_group_points: nsample %d / channels %d out of the supported range", K, 3 + D);
+        return TGN_ERR_UNSUPPORTED;
+    }
     int *err = index_error_word();
-    const RowShape s = row_shape(rows, 3 + D);
-    if (idx_is_int64)
-        hipLaunchKernelGGL((group_points_kernel<long long>), dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, N,
-                           S, K, D, s.cx_log2, xyz, new_xyz, points ? points : xyz, (const long long *)idx, xyz_first,
-                           out, err);
-    else
-        hipLaunchKernelGGL((group_points_kernel<int>), dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, N, S, K,
-                           D, s.cx_log2, xyz, new_xyz, points ? points : xyz, (const int *)idx, xyz_first, out, err);
+    const int C = 3 + D;
+    const unsigned magicC = (unsigned)((0x100000000ULL + C - 1) / C);
+    long long blocks = (queries + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    const bool vec4 = ((long long)K * C) % 4 == 0;
+    const float *pts = points ? points : xyz;
+#define TGN_GP_LAUNCH(IT, VEC)                                                                                  \
+    hipLaunchKernelGGL((group_points_kernel<IT, VEC>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, \
+                       queries, N, S, K, D, magicC, xyz, new_xyz, pts, (const IT *)idx, xyz_first, out, err)
+    if (idx_is_int64) {
+        if (vec4) TGN_GP_LAUNCH(long long, 4); else TGN_GP_LAUNCH(long long, 1);
+    } else {
+        if (vec4) TGN_GP_LAUNCH(int, 4); else TGN_GP_LAUNCH(int, 1);
+    }
+#undef TGN_GP_LAUNCH
     return check_launch("group_points_kernel");
 }
 

@@ -1,8 +1,5 @@
-// neighbors.hip -- neighbour searches: ball query, kNN, three_nn (gfx950).
+// neighbors.hip -- neighbour searches: kNN, three_nn, square_distance (gfx950).  Ball query: ball_query.hip.
 //
-// ball query : pointnet2_utils.query_ball_point (pointnet2_utils.py:120-144).  The reference builds a
-//              (B,S,N) int64 matrix, masks it and SORTS it over N; here a wave scans the cloud in index
-//              order, 64 candidates per step, and compacts hits with ballot + mbcnt, stopping at nsample.
 // kNN        : pointops.knnquery (pointops.py:30-45 -> knnquery_cuda_kernel.cu:65-108), heap semantics
 //              preserved exactly (insertion history decides the order of equal distances).
 // three_nn   : the square_distance + full sort + [:3] of PointNetFeaturePropagation
@@ -10,47 +7,6 @@
 #include "tgn_common.h"
 
 namespace tgn {
-
-// ---------------------------------------------------------------------------------------------
-// Ball query, brute force in index order.  One wave per query.
-// ---------------------------------------------------------------------------------------------
-template <typename IdxT>
-__global__ __launch_bounds__(256) void ball_query_scan_kernel(int B, int N, int S, int K, float r2,
-                                                               const float *__restrict__ xyz,
-                                                               const float *__restrict__ new_xyz,
-                                                               IdxT *__restrict__ out) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave_in_block = threadIdx.x / kWave;
-    const long long total = (long long)B * S;
-    for (long long q = (long long)blockIdx.x * (blockDim.x / kWave) + wave_in_block; q < total;
-         q += (long long)gridDim.x * (blockDim.x / kWave)) {
-        const int b = (int)(q / S);
-        const float cx = new_xyz[q * 3 + 0], cy = new_xyz[q * 3 + 1], cz = new_xyz[q * 3 + 2];
-        const float s1 = sumsq3(cx, cy, cz);
-        const float *__restrict__ pts = xyz + (size_t)b * N * 3;
-        IdxT *__restrict__ row = out + q * K;
-        int cnt = 0;
-        int first = N;
-        for (int basek = 0; basek < N && cnt < K; basek += kWave) {
-            const int k = basek + lane;
-            bool hit = false;
-            if (k < N) {
-                const float px = pts[(size_t)k * 3 + 0], py = pts[(size_t)k * 3 + 1], pz = pts[(size_t)k * 3 + 2];
-                const float d = sqdist_expanded(cx, cy, cz, s1, px, py, pz, sumsq3(px, py, pz));
-                hit = !(d > r2);  // reference masks `sqrdists > radius**2` (pointnet2_utils.py:135)
-            }
-            const unsigned long long mask = __ballot(hit);
-            if (mask) {
-                const int pos = cnt + mbcnt(mask);
-                if (hit && pos < K) row[pos] = (IdxT)k;
-                if (cnt == 0) first = basek + __builtin_ctzll(mask);
-                cnt += __popcll(mask);
-            }
-        }
-        if (cnt > K) cnt = K;
-        for (int j = cnt + lane; j < K; j += kWave) row[j] = (IdxT)first;  // pad with the first hit (:138-141)
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // kNN, exact heap semantics.  One thread per query; the heap lives in LDS (column per thread) so the
@@ -238,40 +194,6 @@ TGN_API int tgn_square_distance(int B, int N, int M, const float *src, const flo
     dim3 grid((M + 255) / 256, (N + kSqdRows - 1) / kSqdRows, B);
     hipLaunchKernelGGL(square_distance_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, M, src, dst, out);
     return check_launch("square_distance_kernel");
-}
-
-TGN_API size_t tgn_ball_query_workspace_bytes(int B, int N, int S) {
-    (void)B;
-    (void)N;
-    (void)S;
-    return 0;
-}
-
-TGN_API int tgn_ball_query(int B, int N, int S, int nsample, float r2, const float *xyz, const float *new_xyz,
-                           void *idx, int idx_is_int64, void *workspace, size_t workspace_bytes,
-                           tgn_stream_t stream) {
-    (void)workspace;
-    (void)workspace_bytes;
-    if (B < 0 || N < 0 || S < 0 || nsample < 0) {
-        set_error("tgn_ball_query: negative size");
-        return TGN_ERR_INVALID_ARGUMENT;
-    }
-    const long long total = (long long)B * S;
-    if (total == 0 || nsample == 0) return TGN_OK;
-    if (!xyz || !new_xyz || !idx) {
-        set_error("tgn_ball_query: null pointer");
-        return TGN_ERR_INVALID_ARGUMENT;
-    }
-    const int waves_per_block = 4;
-    long long blocks = (total + waves_per_block - 1) / waves_per_block;
-    if (blocks > 256 * 64) blocks = 256 * 64;
-    if (idx_is_int64)
-        hipLaunchKernelGGL((ball_query_scan_kernel<long long>), dim3((unsigned)blocks), dim3(256), 0,
-                           (hipStream_t)stream, B, N, S, nsample, r2, xyz, new_xyz, (long long *)idx);
-    else
-        hipLaunchKernelGGL((ball_query_scan_kernel<int>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                           B, N, S, nsample, r2, xyz, new_xyz, (int *)idx);
-    return check_launch("ball_query_scan_kernel");
 }
 
 TGN_API int tgn_knnquery(int b, int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
