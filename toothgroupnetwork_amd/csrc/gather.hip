@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void aggregation_bwd_kernel(long long rows, in
 // each (1 KiB per wave-instruction, fully coalesced) however odd C is (9, 131, 515 at Shape A).  The
 // neighbour indices of the query sit in LDS; (k,c) of a lane's first element comes from one magic-number
 // division, the other three by increment-and-wrap.
-constexpr int kGroupMaxK = 512;
+constexpr int kGroupMaxK = 128;
 
 template <typename IdxT, int VEC>
 __global__ __launch_bounds__(256) void group_points_kernel(long long queries, int N, int S, int K, int D,
@@ -182,53 +182,52 @@ __global__ __launch_bounds__(256) void group_points_kernel(long long queries, in
                                                             const float *__restrict__ points,
                                                             const IdxT *__restrict__ idx, int xyz_first,
                                                             float *__restrict__ out, int *__restrict__ err) {
-    __shared__ int sidx[4][kGroupMaxK];
+    // per wave and neighbour k: element offset of its feature row, and its centred coordinates
+    __shared__ unsigned sfb[4][kGroupMaxK];
+    __shared__ float srel[4][kGroupMaxK * 3];
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = threadIdx.x / kWave;
     const int C = 3 + D;
-    const int xo = xyz_first ? 0 : D;   // first channel of the relative coordinates
-    const int fo = xyz_first ? 3 : 0;   // first channel of the features
+    const unsigned xo = xyz_first ? 0 : D;   // first channel of the relative coordinates
+    const unsigned fo = xyz_first ? 3 : 0;   // first channel of the features
     const int total = K * C;
     for (long long q = (long long)blockIdx.x * 4 + wv; q < queries; q += (long long)gridDim.x * 4) {
         const int b = (int)(q / S);
         const float cq0 = new_xyz[q * 3 + 0], cq1 = new_xyz[q * 3 + 1], cq2 = new_xyz[q * 3 + 2];
+        const size_t pbase = (size_t)b * N;
         bool bad = false;
         for (int k = lane; k < K; k += kWave) {
             long long v = (long long)idx[q * K + k];
-            if (v < 0 || v >= N) {  // empty ball -> index N: the reference's advanced indexing raises
-                bad = true;
-                v = -1;
+            if (v < 0 || v >= N) {  // empty ball -> index N: the reference's advanced indexing raises;
+                bad = true;         // here the row is filled from point 0 and the error word is set
+                v = 0;
             }
-            sidx[wv][k] = (int)v;
+            const float *p = xyz + (pbase + v) * 3;
+            sfb[wv][k] = (unsigned)((pbase + v) * D);
+            srel[wv][k * 3 + 0] = p[0] - cq0;
+            srel[wv][k * 3 + 1] = p[1] - cq1;
+            srel[wv][k * 3 + 2] = p[2] - cq2;
         }
         if (__any(bad) && lane == 0) atomicOr(err, 1);
-        // (same wave wrote sidx: LDS ops of one wave complete in order, no barrier needed)
-        const size_t pbase = (size_t)b * N;
+        // (the same wave wrote the tables: LDS operations of one wave complete in order, no barrier needed)
         float *__restrict__ dst = out + (size_t)q * total;
         for (int e0 = lane * VEC; e0 < total; e0 += kWave * VEC) {
-            int k = (int)__umulhi((unsigned)e0, magicC);  // e0 / C (exact for e0 < 2^32 / C)
-            int c = e0 - k * C;
+            unsigned k = __umulhi((unsigned)e0, magicC);  // e0 / C (exact for e0 < 2^32 / C)
+            unsigned c = (unsigned)e0 - k * (unsigned)C;
             float v[VEC];
 #pragma unroll
             for (int u = 0; u < VEC; ++u) {
-                float val = 0.0f;
-                if (e0 + u < total) {
-                    const int pi = sidx[wv][k];
-                    if (pi >= 0) {
-                        const int cx3 = c - xo;
-                        if (cx3 >= 0 && cx3 < 3) {
-                            const float cqv = cx3 == 0 ? cq0 : (cx3 == 1 ? cq1 : cq2);
-                            val = xyz[(pbase + pi) * 3 + cx3] - cqv;
-                        } else {
-                            val = points[(pbase + pi) * D + (c - fo)];
-                        }
-                    }
-                }
-                v[u] = val;
-                if (++c == C) {
+                const unsigned cx = c - xo;                 // 0..2 inside the coordinate triple
+                const bool isx = cx < 3u;
+                const unsigned fb = sfb[wv][k];
+                const float rel = srel[wv][k * 3 + (isx ? cx : 0u)];
+                const float val = points[fb + (isx ? 0u : c - fo)];
+                v[u] = isx ? rel : val;
+                if (++c == (unsigned)C) {
                     c = 0;
                     ++k;
                 }
+                if (VEC > 1 && k >= (unsigned)K) k = K - 1;  // tail lanes of the last vector stay in range
             }
             if constexpr (VEC == 4) {
                 *(float4 *)(dst + e0) = make_float4(v[0], v[1], v[2], v[3]);  // total % 4 == 0 here
@@ -411,7 +410,8 @@ TGN_API int tgn_group_points(int B, int N, int S, int K, int D, const float *xyz
         return TGN_ERR_INVALID_ARGUMENT;
     }
     if (!points) D = 0;
-    if (K > kGroupMaxK || D < 0 || (long long)K * (3 + D) >= (1LL << 31) / (3 + D)) {
+    if (K > kGroupMaxK || D < 0 || (long long)K * (3 + D) >= (1LL << 31) / (3 + D) ||
+        (long long)B * N * (D > 3 ? D : 3) >= (1LL << 32)) {
         set_error("tgn_group_points: nsample %d / channels %d out of the supported range", K, 3 + D);
         return TGN_ERR_UNSUPPORTED;
     }
