@@ -191,7 +191,12 @@ __global__ __launch_bounds__(256) void group_points_kernel(long long queries, in
     const unsigned xo = xyz_first ? 0 : D;   // first channel of the relative coordinates
     const unsigned fo = xyz_first ? 3 : 0;   // first channel of the features
     const int total = K * C;
-    for (long long q = (long long)blockIdx.x * 4 + wv; q < queries; q += (long long)gridDim.x * 4) {
+    // XCD-aware block order: hardware block i runs on XCD i % 8 (observed dispatch; speed only).  Logical
+    // block ids are laid out so that every XCD walks ONE contiguous range of queries, i.e. all queries of a
+    // scan hit the same XCD's L2, where the scan's feature rows (re-read ~S*K/N times) stay resident.
+    const unsigned nb = gridDim.x;  // multiple of 8
+    const unsigned lb = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
+    for (long long q = (long long)lb * 4 + wv; q < queries; q += (long long)nb * 4) {
         const int b = (int)(q / S);
         const float cq0 = new_xyz[q * 3 + 0], cq1 = new_xyz[q * 3 + 1], cq2 = new_xyz[q * 3 + 2];
         const size_t pbase = (size_t)b * N;
@@ -211,6 +216,7 @@ __global__ __launch_bounds__(256) void group_points_kernel(long long queries, in
         if (__any(bad) && lane == 0) atomicOr(err, 1);
         // (the same wave wrote the tables: LDS operations of one wave complete in order, no barrier needed)
         float *__restrict__ dst = out + (size_t)q * total;
+#pragma unroll 2
         for (int e0 = lane * VEC; e0 < total; e0 += kWave * VEC) {
             unsigned k = __umulhi((unsigned)e0, magicC);  // e0 / C (exact for e0 < 2^32 / C)
             unsigned c = (unsigned)e0 - k * (unsigned)C;
@@ -418,8 +424,8 @@ TGN_API int tgn_group_points(int B, int N, int S, int K, int D, const float *xyz
     int *err = index_error_word();
     const int C = 3 + D;
     const unsigned magicC = (unsigned)((0x100000000ULL + C - 1) / C);
-    long long blocks = (queries + 3) / 4;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    long long blocks = ((queries + 3) / 4 + 7) / 8 * 8;  // one query per wave, grid a multiple of the 8 XCDs
+    if (blocks > (1LL << 30)) blocks = 1LL << 30;
     const bool vec4 = ((long long)K * C) % 4 == 0;
     const float *pts = points ? points : xyz;
 #define TGN_GP_LAUNCH(IT, VEC)                                                                                  \
