@@ -40,10 +40,33 @@ def time_fps(B, N, S, cfg, flags=0, reps=3):
     return min(ts), idx
 
 
+def bucket_sweep(batch):
+    """bucket-skipping kernel (fps_bucket.hip) per shape vs the plain kernel."""
+    shapes = [(256, 8), (256, 16), (512, 16), (512, 24), (512, 32), (512, 48), (512, 56)]
+    for (N, S) in [(24000, 4096), (4096, 1024), (6000, 1500), (3072, 768)]:
+        os.environ["TGN_FPS_V1"] = "1"
+        ms1, ref = time_fps(batch, N, S, None)
+        os.environ.pop("TGN_FPS_V1")
+        print(f"N={N:6d} S={S:5d} B={batch:4d} plain            {ms1:9.3f} ms {1e3 * ms1 / (S - 1):7.3f} us/iter", flush=True)
+        for nt, p in shapes:
+            if nt * p < N or nt * p > 4 * N:
+                continue
+            os.environ["TGN_FPS_BUCKET_CONFIG"] = f"{nt},{p}"
+            for B in sorted({1, batch}):
+                ms, idx = time_fps(B, N, S, None)
+                print(f"N={N:6d} S={S:5d} B={B:4d} bucket {nt:4d}x{p:<2d}   {ms:9.3f} ms {1e3 * ms / (S - 1):7.3f} us/iter  "
+                      f"same_idx={bool(torch.equal(idx[0], ref[0]))}", flush=True)
+            os.environ.pop("TGN_FPS_BUCKET_CONFIG")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--bucket", action="store_true")
     args = ap.parse_args()
+    if args.bucket:
+        return bucket_sweep(args.batch)
+    os.environ["TGN_FPS_V1"] = "1"
     for (N, S) in [(24000, 4096), (4096, 1024), (1024, 256), (6000, 1500), (3072, 768)]:
         ref = None
         for cfg in CONFIGS:

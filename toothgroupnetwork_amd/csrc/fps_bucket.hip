@@ -1,0 +1,469 @@
+// fps_bucket.hip -- farthest point sampling with EXACT bucket skipping (gfx950).
+//
+// Same operator, same results as fps_resident_kernel (fps.hip): the cloud and its running minimum
+// distances live in VGPRs of one workgroup for the whole kernel.  What changes is how much of the
+// cloud an iteration touches.  FPS's update `tmp[k] = min(tmp[k], |p_k - q|^2)` is a no-op for every
+// point that is farther from the new sample q than its current minimum distance, and after the first
+// few hundred samples that is almost the whole cloud.  So:
+//
+//   * once per cloud the points are ordered along a Z-order curve (5+5+5-bit cell code | 15-bit index,
+//     one in-LDS bitonic sort by the workgroup) and dealt out so that every (wave, register slot) pair
+//     -- a "bucket" of 64 points, one per lane -- is a compact patch of the scan;
+//   * lane s of a wave keeps bucket s's bounding box, its current largest minimum distance `bmax` and the
+//     tie key of the point that attains it;
+//   * per iteration the P metadata lanes of every wave evaluate, with the SAME operation order as the
+//     point update, the distance L from q to each bucket's box.  Every fp32 operation involved (subtract,
+//     square, add, and fma in FMA mode) is monotone, so L <= d_fp(p, q) holds EXACTLY for every point p in
+//     the box, with no tolerance.  If L >= bmax then d_fp(p,q) >= tmp[p] for all its points: the update
+//     cannot change anything and the bucket is skipped.  Only touched buckets are recomputed (8 VALU per
+//     point) and get their (bmax, key) refreshed by a 64-lane DPP max.
+//   * a wave's candidate is the max over its <= 64 bucket maxima (cached while the wave is untouched);
+//     the block argmax is the packed 64-bit max of fps.hip.
+//
+// Results are bit-identical to the plain kernel and to the oracle by construction (skipped updates are
+// provably no-ops); tests/test_gpu_parity.py runs every launch shape against the oracle, including
+// lattices and duplicated vertices (exact ties) and NaN coordinates.
+// Measured (profiles/): 24 000 -> 4096 drops from 2.3 us to 1.25 us per iteration (8.6 of 375 buckets touched on
+// average; what remains is the latency of ~3 bucket updates on the busiest wave plus the block hand-off).
+#include "fps_common.h"
+
+#include <stdlib.h>
+
+#include <type_traits>
+
+namespace tgn {
+
+// 64-lane max / min of an fp32 value; wave-uniform result.  Written as six v_max_f32_dpp / v_min_f32_dpp
+// (row_shr 1,2,4,8 then row_bcast 15,31): lanes without a DPP source are write-disabled and keep their value.
+// hipcc expands the same reduction from builtins into 5 instructions per step (identity mov, dpp mov, two
+// canonicalising v_max, v_max), a ~350-cycle dependent chain; this is ~60.  The s_nop 1 before each step is
+// the VALU-write -> DPP-read hazard (2 wait states) that the assembler does not insert inside asm blocks.
+#define TGN_DPP_REDUCE(OP)                                                                \
+    asm volatile("s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"   \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"   \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"   \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"   \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+                 "s_nop 1"                                                                    \
+                 : "+v"(v))
+__device__ __forceinline__ float wave_max_f32_dpp(float v) {
+    TGN_DPP_REDUCE("v_max_f32_dpp");
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_min_f32_dpp(float v) {
+    TGN_DPP_REDUCE("v_min_f32_dpp");
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ unsigned wave_min_u32_shfl(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+// deposit a wave-uniform value into one lane of a per-lane register (the metadata lane of a bucket)
+__device__ __forceinline__ float writelane_f32(float old, float val_uniform, int lane) {
+    return lane_id() == lane ? val_uniform : old;
+}
+__device__ __forceinline__ unsigned writelane_u32(unsigned old, unsigned val_uniform, int lane) {
+    return lane_id() == lane ? val_uniform : old;
+}
+// one v_writelane_b32 (the value must be wave-uniform, the lane a compile-time constant)
+template <int LANE>
+__device__ __forceinline__ void vwritelane(float &reg, float val_uniform) {
+    const int sv = __builtin_amdgcn_readfirstlane(__float_as_int(val_uniform));
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(reg) : "s"(sv), "n"(LANE));
+}
+template <int LANE>
+__device__ __forceinline__ void vwritelane(unsigned &reg, unsigned val_uniform) {
+    const int sv = __builtin_amdgcn_readfirstlane((int)val_uniform);
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(reg) : "s"(sv), "n"(LANE));
+}
+
+// Binary tree of wave-uniform branches mapping a runtime slot number to a compile-time constant, so that the
+// per-lane point arrays stay statically indexed (registers).  log2(P) scalar compare+branch pairs per call;
+// a lone wave issues roughly one instruction per 5 cycles whatever its kind, so the 4*P-instruction
+// "test every mask bit" chain this replaces cost more than the bucket updates themselves.
+template <int LO, int HI, typename F>
+__device__ __forceinline__ void static_dispatch(int s, F &&f) {
+    if constexpr (HI - LO == 1) {
+        f(std::integral_constant<int, LO>{});
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (s < MID)
+            static_dispatch<LO, MID>(s, f);
+        else
+            static_dispatch<MID, HI>(s, f);
+    }
+}
+
+__device__ __forceinline__ unsigned spread5(unsigned v) {  // abcde -> a00b00c00d00e
+    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6) | ((v & 16u) << 8);
+}
+
+constexpr int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+template <int NT, int P, int MODE>
+__global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
+    constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0;
+    constexpr int NW = NT / kWave;
+    constexpr int CAP = NT * P;
+    constexpr int M = next_pow2(CAP);  // sort size
+    constexpr int PER = M / NT;
+    static_assert(P <= kWave, "bucket metadata lives in lanes 0..P-1");
+    static_assert(M <= 32768, "15-bit local indices");
+    __shared__ unsigned sortbuf[M];  // keys, then (aliased) the u16 sorted-position -> point-index table
+    __shared__ float red[6][NW];
+    __shared__ float4 rec[2][NW][2];  // per wave: {value, tie key} and {x, y, z} of its candidate
+    __shared__ float bmeta[4][NW][P];  // per bucket: x, y, z, lane of the point holding its largest min-distance
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid / kWave;
+    int start_n, n, start_m, m;
+    fps_segment(a, blockIdx.x, start_n, n, start_m, m);
+    if (m <= 0) return;
+    const float *__restrict__ base = a.xyz + (size_t)start_n * 3;
+    const int log2bs = a.ref_log2_block;
+
+    // ---- 1. bounding box of the cloud (finite values only; NaN is ignored by fmin/fmax) ----------------
+    {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = tid; k < n; k += NT) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = base[(size_t)k * 3 + c];
+                if (fabsf(v) <= 3.0e38f) {
+                    lo[c] = fminf(lo[c], v);
+                    hi[c] = fmaxf(hi[c], v);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float l = wave_min_f32_dpp(lo[c]), h = wave_max_f32_dpp(hi[c]);
+            if (lane == 0) {
+                red[c][wave] = l;
+                red[3 + c][wave] = h;
+            }
+        }
+    }
+    __syncthreads();
+    float glo[3], gscale[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float l = INFINITY, h = -INFINITY;
+        for (int w = 0; w < NW; ++w) {
+            l = fminf(l, red[c][w]);
+            h = fmaxf(h, red[3 + c][w]);
+        }
+        const float ext = h - l;
+        glo[c] = l;
+        gscale[c] = (ext > 0.0f && ext < 3.0e38f) ? 32.0f / ext : 0.0f;
+    }
+
+    // ---- 2. sort keys: (15-bit Z-order cell code << 15) | local index ; padding sorts last --------------
+    for (int i = tid; i < M; i += NT) {
+        unsigned key = 0xFFFFFFFFu;
+        if (i < n) {
+            unsigned cc[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float t = (base[(size_t)i * 3 + c] - glo[c]) * gscale[c];
+                t = fminf(fmaxf(t, 0.0f), 31.0f);  // NaN -> 0
+                cc[c] = (unsigned)(int)t;
+            }
+            const unsigned code = spread5(cc[0]) | (spread5(cc[1]) << 1) | (spread5(cc[2]) << 2);
+            key = (code << 15) | (unsigned)i;
+        }
+        sortbuf[i] = key;
+    }
+    __syncthreads();
+    // ---- 3. bitonic sort in LDS ---------------------------------------------------------------------------
+    for (int k = 2; k <= M; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < M / 2; t += NT) {
+                const int i = 2 * t - (t & (j - 1));
+                const int l = i + j;
+                const unsigned va = sortbuf[i], vb = sortbuf[l];
+                const bool up = (i & k) == 0;
+                if ((va > vb) == up) {
+                    sortbuf[i] = vb;
+                    sortbuf[l] = va;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- 4. compact to the u16 table tab[sorted position] = local point index (0xFFFF = padding) ---------
+    unsigned short *tab = (unsigned short *)sortbuf;
+    {
+        unsigned r[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) r[i] = sortbuf[tid * PER + i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER; ++i) tab[tid * PER + i] = r[i] == 0xFFFFFFFFu ? (unsigned short)0xFFFF : (unsigned short)(r[i] & 0x7FFFu);
+        __syncthreads();
+    }
+
+    // ---- 5. my P points.  Z-order bucket b (sorted positions [64b, 64b+64)) goes to wave b % NW, slot b / NW:
+    //         neighbouring buckets -- the ones a new sample touches together -- sit in DIFFERENT waves, so
+    //         their updates run concurrently instead of queueing on one wave. ---------------------------------
+    float x[P], y[P], z[P], d[P];
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+        const unsigned o = tab[(s * NW + wave) * kWave + lane];
+        const bool valid = o != 0xFFFFu;
+        x[s] = valid ? base[(size_t)o * 3 + 0] : 0.0f;
+        y[s] = valid ? base[(size_t)o * 3 + 1] : 0.0f;
+        z[s] = valid ? base[(size_t)o * 3 + 2] : 0.0f;
+        d[s] = valid ? 1e10f : -1.0f;  // pointops.py:22 ; padding never wins (real distances are >= 0)
+    }
+    // ---- 6. bucket metadata.  Lane s of a wave keeps bucket s's box and largest min-distance in VGPRs (read
+    //         every iteration); the arg-max point of the bucket (its coordinates and lane) sits in LDS, written
+    //         by the winning lane itself with one 16-B store and read only when the wave's candidate changes. ----
+    float blo0 = INFINITY, blo1 = INFINITY, blo2 = INFINITY, bhi0 = -INFINITY, bhi1 = -INFINITY, bhi2 = -INFINITY;
+    float bmax = -1.0f;
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+        const bool valid = d[s] >= 0.0f;
+        // NaN coordinates are left out of the box: such a point can never be updated anyway (min ignores NaN)
+        const float l0 = wave_min_f32_dpp(valid ? x[s] : INFINITY), h0 = wave_max_f32_dpp(valid ? x[s] : -INFINITY);
+        const float l1 = wave_min_f32_dpp(valid ? y[s] : INFINITY), h1 = wave_max_f32_dpp(valid ? y[s] : -INFINITY);
+        const float l2 = wave_min_f32_dpp(valid ? z[s] : INFINITY), h2 = wave_max_f32_dpp(valid ? z[s] : -INFINITY);
+        const float any = wave_max_f32_dpp(d[s]);
+        blo0 = writelane_f32(blo0, l0, s);
+        blo1 = writelane_f32(blo1, l1, s);
+        blo2 = writelane_f32(blo2, l2, s);
+        bhi0 = writelane_f32(bhi0, h0, s);
+        bhi1 = writelane_f32(bhi1, h1, s);
+        bhi2 = writelane_f32(bhi2, h2, s);
+        bmax = writelane_f32(bmax, any, s);  // 1e10 if the bucket holds a real point, else -1 (first pass fixes the rest)
+    }
+
+    float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+    if (n > 0) {
+        qx = base[0];
+        qy = base[1];
+        qz = base[2];
+    }
+    // Results are parked in registers -- thread t keeps row r with r % NT == t -- and written NT rows at a time,
+    // coalesced: the per-iteration store sequence of one lane was ~20 instructions on the critical wave.
+    int hold_k = 0;                                   // row 0: sampling_cuda_kernel.cu:39
+    float hold_x = qx, hold_y = qy, hold_z = qz;
+
+    // cached wave candidate (wave-uniform): value, tie key, coordinates
+    float wm = -1.0f, wx = 0.0f, wy = 0.0f, wz = 0.0f;
+    unsigned wkey = 0;
+    bool dirty = true;
+
+    // optional instrumentation (flag 0x100 + tmp): touched-bucket census and per-phase cycles of one wave
+    const bool dbg = (a.flags & 0x100) && a.tmp;
+    unsigned long long st_touched = 0, st_waves = 0, cyA = 0, cyU = 0, cyB = 0, cyC = 0;
+
+    for (int j = 1; j < m; ++j) {
+        long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if (dbg) t0 = clock64();
+        // ---- A. which of my buckets can the new sample change? (monotone lower bound, exact) -------------
+        const float ex = fmaxf(fmaxf(blo0 - qx, qx - bhi0), 0.0f);
+        const float ey = fmaxf(fmaxf(blo1 - qy, qy - bhi1), 0.0f);
+        const float ez = fmaxf(fmaxf(blo2 - qz, qz - bhi2), 0.0f);
+        const float L = FMA ? dist_direct_fma(ex, ey, ez) : dist_direct_nofma(ex, ey, ez);
+        const bool need = lane < P && !(L >= bmax);
+        const unsigned long long mask = __ballot(need);
+        if (dbg) {
+            t1 = clock64();
+            st_touched += __popcll(mask);
+            st_waves += mask ? 1 : 0;
+        }
+        if (mask) {  // wave-uniform
+            dirty = true;
+            // A lone wave issues roughly one instruction per 5 cycles whatever its kind, so the mask is walked
+            // hierarchically (groups of 8 slots, 32-bit tests: 2 scalar instructions per test) rather than bit by bit.
+            const unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
+#pragma unroll
+            for (int g = 0; g < (P + 7) / 8; ++g) {
+                const unsigned mg = ((g < 4 ? mlo : mhi) >> ((g & 3) * 8)) & 0xFFu;
+                if (mg) {  // wave-uniform
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int s = g * 8 + u;  // compile-time after unrolling
+                        if (s < P && (mg & (1u << u))) {  // wave-uniform
+                            const float dx = x[s] - qx, dy = y[s] - qy, dz = z[s] - qz;
+                            const float dd = FMA ? dist_direct_fma(dx, dy, dz) : dist_direct_nofma(dx, dy, dz);
+                            const float nd = vmin_f32(dd, d[s]);  // min(d, tmp[k]) sampling_cuda_kernel.cu:55
+                            d[s] = nd;
+                            const float mx = wave_max_f32_dpp(nd);
+                            const unsigned long long eq = __ballot(nd == mx);
+                            bool win = nd == mx;
+                            if (__popcll(eq) != 1) {  // exact tie inside the bucket (rare): the smallest tie key wins
+                                const unsigned o = tab[(s * NW + wave) * kWave + lane];
+                                const unsigned kl = win ? (TREE ? compat_key((int)o, log2bs) : o) : 0xFFFFFFFFu;
+                                const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kl));
+                                win = win && kl == kmin;
+                            }
+                            if (win) {  // four 4-B stores into separate planes: one 16-B store would pin (x,y,z,lane)
+                                        // of every slot to an aligned register quadruple and double the footprint
+                                bmeta[0][wave][s] = x[s];
+                                bmeta[1][wave][s] = y[s];
+                                bmeta[2][wave][s] = z[s];
+                                bmeta[3][wave][s] = __int_as_float(lane);
+                            }
+                            bmax = lane == s ? mx : bmax;
+                        }
+                    }
+                }
+            }
+        }
+        if (dbg) t2 = clock64();
+        // ---- B. wave candidate = max over my bucket maxima (recomputed only if a bucket changed) ---------
+        if (dirty) {
+            const float v = lane < P ? bmax : -1.0f;
+            wm = wave_max_f32_dpp(v);
+            const bool cand = lane < P && v == wm && wm >= 0.0f;
+            // tie key of each candidate bucket's arg-max point (two dependent LDS reads; usually a single lane)
+            unsigned kl = 0xFFFFFFFFu;
+            float4 pm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (cand) {
+                pm = make_float4(bmeta[0][wave][lane], bmeta[1][wave][lane], bmeta[2][wave][lane], bmeta[3][wave][lane]);
+                const unsigned o = tab[(lane * NW + wave) * kWave + __float_as_int(pm.w)];
+                kl = TREE ? compat_key((int)o, log2bs) : o;
+            }
+            const unsigned long long cm = __ballot(cand);
+            int sl = cm ? __builtin_ctzll(cm) : 0;
+            if (__popcll(cm) > 1) {
+                const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kl));
+                sl = __builtin_ctzll(__ballot(kl == kmin));
+            }
+            wkey = (unsigned)__builtin_amdgcn_readlane((int)kl, sl);
+            wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pm.x), sl));
+            wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pm.y), sl));
+            wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pm.z), sl));
+            dirty = false;
+        }
+        if (dbg) t3 = clock64();
+        // ---- C. block argmax over the wave candidates: one LDS record per wave, ONE barrier ------------------
+        unsigned kwin;
+        if constexpr (NW == 1) {
+            kwin = wm < 0.0f ? 0xFFFFFFFFu : wkey;
+            qx = wx;
+            qy = wy;
+            qz = wz;
+        } else {
+            if (lane == 0) {
+                rec[j & 1][wave][0] = make_float4(wm < 0.0f ? 0.0f : wm, __uint_as_float(wm < 0.0f ? 0xFFFFFFFFu : wkey), 0.0f, 0.0f);
+                rec[j & 1][wave][1] = make_float4(wx, wy, wz, 0.0f);
+            }
+            __syncthreads();
+            // distances are >= 0: their bit patterns order like unsigned integers
+            const float4 r0 = lane < NW ? rec[j & 1][lane][0] : make_float4(0.0f, __uint_as_float(0xFFFFFFFFu), 0.0f, 0.0f);
+            const unsigned vb = __float_as_uint(r0.x);
+            unsigned mb = vb;
+            asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                         : "+v"(mb));
+            mb = (unsigned)__builtin_amdgcn_readlane((int)mb, 15);
+            const bool wc = lane < NW && vb == mb;
+            const unsigned kk = wc ? __float_as_uint(r0.y) : 0xFFFFFFFFu;
+            const unsigned long long wmask = __ballot(wc);
+            int wl = __builtin_ctzll(wmask);
+            if (__popcll(wmask) > 1) {
+                const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kk));
+                wl = __builtin_ctzll(__ballot(kk == kmin));
+            }
+            kwin = (unsigned)__builtin_amdgcn_readlane((int)kk, wl);
+            const float4 r1 = rec[j & 1][wl][1];
+            qx = r1.x;
+            qy = r1.y;
+            qz = r1.z;
+        }
+        int k = kwin == 0xFFFFFFFFu ? 0 : (TREE ? compat_index(kwin, log2bs) : (int)kwin);
+        k = __builtin_amdgcn_readfirstlane(k);
+        if ((j & (NT - 1)) == tid) {
+            hold_k = k;
+            hold_x = qx;
+            hold_y = qy;
+            hold_z = qz;
+        }
+        if ((j & (NT - 1)) == NT - 1) fps_emit(a, start_m + j - (NT - 1) + tid, start_n, hold_k, hold_x, hold_y, hold_z);
+        if (dbg) {
+            const long long t4 = clock64();
+            cyA += t1 - t0;
+            cyU += t2 - t1;
+            cyB += t3 - t2;
+            cyC += t4 - t3;
+        }
+    }
+    {   // rows of the last, partial chunk
+        const int cb = ((m - 1) / NT) * NT;
+        if (((m - 1) & (NT - 1)) != NT - 1 && cb + tid <= m - 1)
+            fps_emit(a, start_m + cb + tid, start_n, hold_k, hold_x, hold_y, hold_z);
+    }
+    if (dbg && lane == 0) {
+        unsigned long long *st = (unsigned long long *)a.tmp;
+        atomicAdd(&st[0], st_touched);
+        atomicAdd(&st[1], st_waves);
+        if (wave == 0 && blockIdx.x == 0) {
+            st[2] = cyA;
+            st[3] = cyU;
+            st[4] = cyB;
+            st[5] = cyC;
+            st[6] = (unsigned long long)(m - 1);
+        }
+    }
+}
+
+#define TGN_FPS_BUCKET_CONFIGS(X) X(256, 8) X(256, 16) X(512, 16) X(512, 24) X(512, 32) X(512, 48) X(512, 56)
+
+template <int MODE>
+static int bucket_launch_mode(int b, int n_max, const FpsArgs &a, hipStream_t stream) {
+    int nt = 0, p = 0;
+    if (const char *e = getenv("TGN_FPS_BUCKET_CONFIG")) {  // experiments: force a shape
+        if (sscanf(e, "%d,%d", &nt, &p) != 2 || nt * p < n_max) nt = p = 0;
+    }
+    if (!nt) {
+        int best = 1 << 30;
+#define X(NT_, P_)                                             \
+    if (NT_ * P_ >= n_max && NT_ * P_ < best) {                \
+        best = NT_ * P_;                                       \
+        nt = NT_;                                              \
+        p = P_;                                                \
+    }
+        TGN_FPS_BUCKET_CONFIGS(X)
+#undef X
+    }
+#define X(NT_, P_)                                                                                   \
+    if (nt == NT_ && p == P_) {                                                                      \
+        hipLaunchKernelGGL((fps_bucket_kernel<NT_, P_, MODE>), dim3(b), dim3(NT_), 0, stream, a);    \
+        return check_launch("fps_bucket_kernel");                                                    \
+    }
+    TGN_FPS_BUCKET_CONFIGS(X)
+#undef X
+    return -1;
+}
+
+int fps_bucket_launch(int mode, int b, int n_max, const FpsArgs &a, hipStream_t stream) {
+    // Measured (profiles/r01_fps_bucket_sweep.txt): 24 000 points 1.25 vs 2.3 us per iteration, 6000 points a tie,
+    // 4096 points the plain kernel wins (its whole iteration is already fixed cost).  TGN_FPS_BUCKET_MIN overrides.
+    int min_n = 8192;
+    if (const char *e = getenv("TGN_FPS_BUCKET_MIN")) min_n = atoi(e);
+    if (n_max < min_n) return -1;
+    switch (mode & 3) {
+        case 0: return bucket_launch_mode<0>(b, n_max, a, stream);
+        case 1: return bucket_launch_mode<1>(b, n_max, a, stream);
+        case 2: return bucket_launch_mode<2>(b, n_max, a, stream);
+        default: return bucket_launch_mode<3>(b, n_max, a, stream);
+    }
+}
+
+}  // namespace tgn

@@ -13,6 +13,8 @@
 // channel axis (coalesced row reads and writes), and there is no per-element division.
 #include "tgn_common.h"
 
+#include <stdlib.h>
+
 namespace tgn {
 
 struct RowShape {
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(256) void group_points_kernel(long long queries, in
     // per wave and neighbour k: element offset of its feature row, and its centred coordinates
     __shared__ unsigned sfb[4][kGroupMaxK];
     __shared__ float srel[4][kGroupMaxK * 3];
+    __shared__ __attribute__((aligned(16))) float stage[4][kWave * 4];  // per-wave transpose buffer
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = threadIdx.x / kWave;
     const int C = 3 + D;
@@ -216,29 +219,42 @@ __global__ __launch_bounds__(256) void group_points_kernel(long long queries, in
         if (__any(bad) && lane == 0) atomicOr(err, 1);
         // (the same wave wrote the tables: LDS operations of one wave complete in order, no barrier needed)
         float *__restrict__ dst = out + (size_t)q * total;
-#pragma unroll 2
-        for (int e0 = lane * VEC; e0 < total; e0 += kWave * VEC) {
-            unsigned k = __umulhi((unsigned)e0, magicC);  // e0 / C (exact for e0 < 2^32 / C)
-            unsigned c = (unsigned)e0 - k * (unsigned)C;
-            float v[VEC];
+        if constexpr (VEC == 4) {
+            // 256 elements per step: the four gathers of a lane are LANE-CONTIGUOUS (load u covers elements
+            // e0+64u .. e0+64u+63: two cache lines per wave-instruction; a lane-strided gather touches eight and
+            // is address-path bound at ~2 TB/s), the wave transposes them through LDS, and every lane stores the
+            // 16 contiguous bytes it then owns (total % 4 == 0 here).
+            for (int e0 = 0; e0 < total; e0 += kWave * 4) {
 #pragma unroll
-            for (int u = 0; u < VEC; ++u) {
-                const unsigned cx = c - xo;                 // 0..2 inside the coordinate triple
-                const bool isx = cx < 3u;
-                const unsigned fb = sfb[wv][k];
-                const float rel = srel[wv][k * 3 + (isx ? cx : 0u)];
-                const float val = points[fb + (isx ? 0u : c - fo)];
-                v[u] = isx ? rel : val;
-                if (++c == (unsigned)C) {
-                    c = 0;
-                    ++k;
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * kWave + lane;
+                    float val = 0.0f;
+                    if (e < total) {
+                        const unsigned k = __umulhi((unsigned)e, magicC);  // e / C (exact for e < 2^32 / C)
+                        const unsigned c = (unsigned)e - k * (unsigned)C;
+                        const unsigned cx = c - xo;  // 0..2 inside the coordinate triple
+                        const bool isx = cx < 3u;
+                        const float rel = srel[wv][k * 3 + (isx ? cx : 0u)];
+                        const float ld = points[sfb[wv][k] + (isx ? 0u : c - fo)];
+                        val = isx ? rel : ld;
+                    }
+                    stage[wv][u * kWave + lane] = val;
                 }
-                if (VEC > 1 && k >= (unsigned)K) k = K - 1;  // tail lanes of the last vector stay in range
+                const int e = e0 + lane * 4;
+                if (e < total) *(float4 *)(dst + e) = *(const float4 *)&stage[wv][lane * 4];
             }
-            if constexpr (VEC == 4) {
-                *(float4 *)(dst + e0) = make_float4(v[0], v[1], v[2], v[3]);  // total % 4 == 0 here
-            } else {
-                dst[e0] = v[0];
+        } else {
+            // lane-contiguous gathers AND stores (256 contiguous bytes per wave-instruction); independent
+            // iterations, unrolled so that several gathers per lane are in flight
+#pragma unroll 2
+            for (int e = lane; e < total; e += kWave) {
+                const unsigned k = __umulhi((unsigned)e, magicC);
+                const unsigned c = (unsigned)e - k * (unsigned)C;
+                const unsigned cx = c - xo;
+                const bool isx = cx < 3u;
+                const float rel = srel[wv][k * 3 + (isx ? cx : 0u)];
+                const float ld = points[sfb[wv][k] + (isx ? 0u : c - fo)];
+                dst[e] = isx ? rel : ld;
             }
         }
     }
@@ -426,7 +442,8 @@ TGN_API int tgn_group_points(int B, int N, int S, int K, int D, const float *xyz
     const unsigned magicC = (unsigned)((0x100000000ULL + C - 1) / C);
     long long blocks = ((queries + 3) / 4 + 7) / 8 * 8;  // one query per wave, grid a multiple of the 8 XCDs
     if (blocks > (1LL << 30)) blocks = 1LL << 30;
-    const bool vec4 = ((long long)K * C) % 4 == 0;
+    const char *ev = getenv("TGN_GROUP_VEC1");  // experiments: "0" selects the LDS-transposed 16-B store path
+    const bool vec4 = ((long long)K * C) % 4 == 0 && (ev && ev[0] == '0');  // default: 4-B path (measured faster)
     const float *pts = points ? points : xyz;
 #define TGN_GP_LAUNCH(IT, VEC)                                                                                  \
     hipLaunchKernelGGL((group_points_kernel<IT, VEC>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, \
