@@ -152,6 +152,22 @@ def main():
         if kind == "fps":
             S = hotpath.SHAPE_A["npoint"][lvl]
             out["roofline"]["us_per_fps_iteration"] = 1e3 * avg[dom] / max(S - 1, 1)
+        # HBM bytes per launch from the PMC passes committed under profiles/ (tools/gpu_pmc.sh; same workload)
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
+        except Exception:
+            pass
+        if dom in pmc and B == 256:
+            out["roofline"]["traffic"] = pmc[dom]["fetch"] + pmc[dom]["write"]
+        # the HBM-bound kernel of the path, for reference next to the (latency-bound) dominant one
+        gk = max((k for k in avg if k.startswith("group")), key=lambda k: avg[k])
+        gl = int(gk.split("_l")[1]) - 1
+        galgo = per_level[gl]["group"] * B
+        out["roofline_group"] = {"kernel": gk, "bound": "hbm", "achieved": galgo / (avg[gk] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": galgo / (avg[gk] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "traffic": (pmc[gk]["fetch"] + pmc[gk]["write"]) if gk in pmc and B == 256 else None,
+                                 "algorithmic_bytes_per_launch": galgo, "avg_launch_ms": avg[gk]}
     if rank == 0 and world == 1 and args.cpu_meshes != 0:
         from oracle import cpu as O
         budget = args.cpu_meshes if args.cpu_meshes > 0 else max(8, 2 * O.num_threads())
