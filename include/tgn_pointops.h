@@ -98,6 +98,15 @@ int tgn_fps_resident_capacity(void);
 /* kNN (pointops.py:30-45): b segments; idx (m,nsample) int32; dist2 (m,nsample) squared, ascending. */
 int tgn_knnquery(int b, int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
                  const int *new_offset, int *idx, float *dist2, tgn_stream_t stream);
+/*
+ * Same result, ~30x faster: with tgn_knnquery_workspace_bytes(m) bytes of device scratch the wave-parallel
+ * kernel runs first and only queries whose k+1 smallest distances tie bit-for-bit are redone by the exact
+ * heap kernel (whose insertion history decides the order of tied neighbours, knnquery_cuda_kernel.cu:21-48).
+ */
+size_t tgn_knnquery_workspace_bytes(int m);
+int tgn_knnquery_ws(int b, int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
+                    const int *new_offset, int *idx, float *dist2, void *workspace, size_t workspace_bytes,
+                    tgn_stream_t stream);
 
 int tgn_grouping_forward(int m, int nsample, int c, const float *input, const int *idx, float *output,
                          tgn_stream_t stream);

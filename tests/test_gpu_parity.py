@@ -324,6 +324,25 @@ def test_knn_self_query_none_and_tensor_k(dev, oracle, regression):
     assert np.array_equal(dist.cpu().numpy(), r["p_knn_self_dist"])
 
 
+def test_knn_memo_hits_and_invalidates(dev, oracle):
+    from toothgroupnetwork_amd import pointops as P
+    P.knn_cache_clear()
+    xyz_np = synth.uniform_cloud(500, 1)
+    xyz = T(xyz_np, dev)
+    off = torch.tensor([500], dtype=torch.int32, device=dev)
+    a, _ = P.knnquery(8, xyz, xyz, off, off)
+    n0 = len(P._KNN_CACHE)
+    b, _ = P.knnquery(8, xyz, None, off, off)      # same arguments -> memo hit (blocks.py:34-35 pattern)
+    assert len(P._KNN_CACHE) == n0 and torch.equal(a, b)
+    a[0, 0] = -7                                     # callers get private copies
+    c, _ = P.knnquery(8, xyz, xyz, off, off)
+    assert c[0, 0] != -7
+    xyz[3] += 1.0                                    # in-place edit bumps the version -> recomputed
+    d, _ = P.knnquery(8, xyz, xyz, off, off)
+    xyz_np[3] += 1.0
+    assert np.array_equal(d.cpu().numpy(), oracle.knnquery(8, xyz_np, xyz_np, [500], [500])[0])
+
+
 def test_knn_vs_reference_kernel_on_this_gpu(dev, regression):
     from oracle import ref_gpu
     if not ref_gpu.available():

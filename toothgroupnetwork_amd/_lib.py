@@ -41,6 +41,8 @@ SIGNATURES = {
     "tgn_furthestsampling_dense": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "tgn_fps_resident_capacity": (c_int, []),
     "tgn_knnquery": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "tgn_knnquery_workspace_bytes": (c_size_t, [c_int]),
+    "tgn_knnquery_ws": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "tgn_grouping_forward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P]),
     "tgn_grouping_backward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P]),
     "tgn_interpolation_forward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P]),

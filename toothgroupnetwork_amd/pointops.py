@@ -8,6 +8,9 @@ Layout conventions of the reference ("packed batch"): xyz (n,3) fp32, features (
 ``offset`` (b) int32 cumulative end of every cloud.  Everything runs through the C ABI of
 libtgn_pointops.so on the current HIP stream; there is no CPU path.
 """
+import os
+from collections import OrderedDict
+
 import torch
 from torch.autograd import Function
 
@@ -93,9 +96,39 @@ def _knn_raw(nsample, xyz, new_xyz, offset, new_offset):
     m = new_xyz.shape[0]
     idx = torch.empty(m, nsample, dtype=torch.int32, device=xyz.device)
     dist2 = torch.empty(m, nsample, dtype=torch.float32, device=xyz.device)
-    check(lib().tgn_knnquery(offset.shape[0], m, nsample, ptr(xyz), ptr(new_xyz), ptr(offset), ptr(new_offset),
-                             ptr(idx), ptr(dist2), stream()), "tgn_knnquery")
+    nbytes = int(lib().tgn_knnquery_workspace_bytes(m))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device) if nbytes else None
+    check(lib().tgn_knnquery_ws(offset.shape[0], m, nsample, ptr(xyz), ptr(new_xyz), ptr(offset), ptr(new_offset),
+                                ptr(idx), ptr(dist2), ptr(ws), nbytes, stream()), "tgn_knnquery")
     return idx, dist2
+
+
+# kNN memo.  The reference recomputes identical neighbour lists again and again: PointTransformerLayer calls
+# queryandgroup(idx=None) twice with the same arguments (blocks.py:34-35) and every block of a stage repeats it.
+# Results are keyed on the identity AND version counter of the argument tensors, which are kept alive by the
+# cache (so an address can not be recycled under a live key); an in-place write bumps the version and misses.
+_KNN_CACHE = OrderedDict()
+_KNN_CACHE_SIZE = int(os.environ.get("TGN_KNN_CACHE", "16"))
+
+
+def _knn_cached(nsample, xyz, new_xyz, offset, new_offset):
+    if _KNN_CACHE_SIZE <= 0:
+        return _knn_raw(nsample, xyz, new_xyz, offset, new_offset)
+    tensors = (xyz, xyz if new_xyz is None else new_xyz, offset, new_offset)
+    key = (as_int(nsample),) + tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype) for t in tensors)
+    hit = _KNN_CACHE.get(key)
+    if hit is not None:
+        _KNN_CACHE.move_to_end(key)
+        return hit[1], hit[2]
+    idx, dist2 = _knn_raw(nsample, xyz, new_xyz, offset, new_offset)
+    _KNN_CACHE[key] = (tensors, idx, dist2)
+    while len(_KNN_CACHE) > _KNN_CACHE_SIZE:
+        _KNN_CACHE.popitem(last=False)
+    return idx, dist2
+
+
+def knn_cache_clear():
+    _KNN_CACHE.clear()
 
 
 class KNNQuery(Function):
@@ -105,7 +138,8 @@ class KNNQuery(Function):
         input: xyz: (n, 3), new_xyz: (m, 3), offset: (b), new_offset: (b)
         output: idx: (m, nsample), dist: (m, nsample)  (sqrt of the squared distances) [pointops.py:30-43]
         """
-        idx, dist2 = _knn_raw(nsample, xyz, new_xyz, offset, new_offset)
+        idx, dist2 = _knn_cached(nsample, xyz, new_xyz, offset, new_offset)
+        idx = idx.clone()  # callers may write into the result; the memo must stay intact
         dist = torch.sqrt(dist2)
         ctx.mark_non_differentiable(idx, dist)
         return idx, dist
