@@ -94,6 +94,18 @@ int tgn_furthestsampling(int b, int n_max, const float *xyz, const int *offset, 
 int tgn_furthestsampling_dense(int B, int N, int S, const float *xyz, float *tmp, void *idx, float *new_xyz,
                                int flags, tgn_stream_t stream);
 int tgn_fps_resident_capacity(void);
+/*
+ * Clouds larger than tgn_fps_resident_capacity() (raw scans, preprocess_data.py:55-56) run the bucket-skipping
+ * kernel out of a cell-sorted workspace of tgn_fps_workspace_bytes(b, n_max) bytes (20 B per point; 0 when every
+ * cloud fits the register-resident kernels; clouds above 262 144 points fall back to streaming through the same
+ * buffer used as the reference's tmp array, which then must hold 4 B per point of the batch).
+ */
+size_t tgn_fps_workspace_bytes(int b, int n_max);
+int tgn_furthestsampling_ws(int b, int n_max, const float *xyz, const int *offset, const int *new_offset,
+                            void *workspace, size_t workspace_bytes, void *idx, float *new_xyz, int flags,
+                            tgn_stream_t stream);
+int tgn_furthestsampling_dense_ws(int B, int N, int S, const float *xyz, void *workspace, size_t workspace_bytes,
+                                  void *idx, float *new_xyz, int flags, tgn_stream_t stream);
 
 /* kNN (pointops.py:30-45): b segments; idx (m,nsample) int32; dist2 (m,nsample) squared, ascending. */
 int tgn_knnquery(int b, int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,

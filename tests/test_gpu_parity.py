@@ -111,7 +111,39 @@ def test_fps_edge_cases(dev, oracle):
                           oracle.furthestsampling(xyz, o, m))
 
 
-def test_fps_streaming_kernel_for_oversized_cloud(dev, oracle):
+@pytest.mark.parametrize("mode", [0, 3])
+def test_fps_large_cloud_workspace_kernel(dev, oracle, mode):
+    """Clouds beyond the register capacity (raw scans): bucket kernel over the cell-sorted workspace, ragged
+    batch with ties / NaN, both against the oracle; and the legacy tmp-only entry (streaming kernel)."""
+    from toothgroupnetwork_amd import _lib
+    L = _lib.lib()
+    cap = L.tgn_fps_resident_capacity()
+    a = synth.arch_cloud(cap + 1500, 5, False)
+    a[[7, 20000]] = np.nan
+    bcl = np.concatenate([synth.lattice_cloud(30, dup=3000, seed=2), synth.uniform_cloud(5000, 3)])   # 35000 pts, ties
+    c = synth.uniform_cloud(1000, 4)                                                                 # small cloud in the same batch
+    xyz_np = np.concatenate([a, bcl, c])
+    off_np = np.cumsum([a.shape[0], bcl.shape[0], c.shape[0]]).astype(np.int32)
+    noff_np = np.cumsum([700, 900, 300]).astype(np.int32)
+    n_max = int(max(a.shape[0], bcl.shape[0]))
+    flags = (_lib.FPS_FMA if mode & 1 else 0) | (_lib.FPS_TREE_TIES if mode & 2 else 0)
+    xyz, off, noff = T(xyz_np, dev), T(off_np, dev), T(noff_np, dev)
+    ref = oracle.furthestsampling(xyz_np, off_np, noff_np, mode=mode)
+    nbytes = int(L.tgn_fps_workspace_bytes(3, n_max))
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    out = torch.empty(int(noff_np[-1]), dtype=torch.int32, device=dev)
+    _lib.check(L.tgn_furthestsampling_ws(3, n_max, _lib.ptr(xyz), _lib.ptr(off), _lib.ptr(noff), _lib.ptr(ws), nbytes,
+                                         _lib.ptr(out), None, flags, _lib.stream()))
+    assert np.array_equal(out.cpu().numpy(), ref)
+    tmp = torch.empty(xyz_np.shape[0], dtype=torch.float32, device=dev)     # reference-style tmp: streaming kernel
+    out2 = torch.empty_like(out)
+    _lib.check(L.tgn_furthestsampling(3, n_max, _lib.ptr(xyz), _lib.ptr(off), _lib.ptr(noff), _lib.ptr(tmp),
+                                      _lib.ptr(out2), None, flags, _lib.stream()))
+    assert np.array_equal(out2.cpu().numpy(), ref)
+
+
+def test_fps_oversized_cloud_through_python_api(dev, oracle):
     from toothgroupnetwork_amd import _lib, pointops as P
     n = _lib.lib().tgn_fps_resident_capacity() + 1500
     xyz = synth.arch_cloud(n, 5, False)

@@ -40,6 +40,9 @@ SIGNATURES = {
     "tgn_furthestsampling": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "tgn_furthestsampling_dense": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "tgn_fps_resident_capacity": (c_int, []),
+    "tgn_fps_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "tgn_furthestsampling_ws": (c_int, [c_int, c_int, _P, _P, _P, _P, c_size_t, _P, _P, c_int, _P]),
+    "tgn_furthestsampling_dense_ws": (c_int, [c_int, c_int, c_int, _P, _P, c_size_t, _P, _P, c_int, _P]),
     "tgn_knnquery": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "tgn_knnquery_workspace_bytes": (c_size_t, [c_int]),
     "tgn_knnquery_ws": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),

@@ -219,6 +219,10 @@ static int fps_launch(int b, int n_max, const FpsArgs &a, hipStream_t stream) {
         TGN_FPS_CONFIGS(X)
 #undef X
     }
+    {
+        const int rc = fps_bucket_stream_launch(MODE, b, n_max, a, stream);
+        if (rc >= 0) return rc;
+    }
     if (!a.tmp) {
         set_error("tgn_furthestsampling: cloud of %d points exceeds the resident capacity (%d) and tmp is NULL",
                   n_max, fps_capacity());
@@ -272,7 +276,25 @@ TGN_API int tgn_furthestsampling(int b, int n_max, const float *xyz, const int *
         set_error("tgn_furthestsampling: null offsets");
         return TGN_ERR_INVALID_ARGUMENT;
     }
-    FpsArgs a{xyz, offset, new_offset, 0, 0, idx, new_xyz, tmp, flags, 0};
+    FpsArgs a{xyz, offset, new_offset, 0, 0, idx, new_xyz, tmp, nullptr, 0, n_max, flags, 0};
+    return fps_dispatch(b, n_max, a, (hipStream_t)stream);
+}
+
+TGN_API size_t tgn_fps_workspace_bytes(int b, int n_max) {
+    if (n_max <= fps_capacity()) return 0;
+    return fps_stream_workspace_bytes(b, n_max);
+}
+
+TGN_API int tgn_furthestsampling_ws(int b, int n_max, const float *xyz, const int *offset, const int *new_offset,
+                                    void *workspace, size_t workspace_bytes, void *idx, float *new_xyz, int flags,
+                                    tgn_stream_t stream) {
+    if (b > 0 && (!offset || !new_offset)) {
+        set_error("tgn_furthestsampling_ws: null offsets");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    // clouds beyond both the register capacity and the workspace kernel (262 144 points) stream through `workspace`
+    // as the reference's tmp array if it is large enough for that (4 B per point of the whole batch)
+    FpsArgs a{xyz, offset, new_offset, 0, 0, idx, new_xyz, (float *)workspace, workspace, workspace_bytes, n_max, flags, 0};
     return fps_dispatch(b, n_max, a, (hipStream_t)stream);
 }
 
@@ -282,7 +304,17 @@ TGN_API int tgn_furthestsampling_dense(int B, int N, int S, const float *xyz, fl
         set_error("tgn_furthestsampling_dense: negative size");
         return TGN_ERR_INVALID_ARGUMENT;
     }
-    FpsArgs a{xyz, nullptr, nullptr, N, S, idx, new_xyz, tmp, flags, 0};
+    FpsArgs a{xyz, nullptr, nullptr, N, S, idx, new_xyz, tmp, nullptr, 0, N, flags, 0};
+    return fps_dispatch(B, N, a, (hipStream_t)stream);
+}
+
+TGN_API int tgn_furthestsampling_dense_ws(int B, int N, int S, const float *xyz, void *workspace, size_t workspace_bytes,
+                                          void *idx, float *new_xyz, int flags, tgn_stream_t stream) {
+    if (N < 0 || S < 0) {
+        set_error("tgn_furthestsampling_dense_ws: negative size");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    FpsArgs a{xyz, nullptr, nullptr, N, S, idx, new_xyz, (float *)workspace, workspace, workspace_bytes, N, flags, 0};
     return fps_dispatch(B, N, a, (hipStream_t)stream);
 }
 

@@ -55,6 +55,10 @@ __device__ __forceinline__ float wave_min_f32_dpp(float v) {
     TGN_DPP_REDUCE("v_min_f32_dpp");
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+__device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v) {
+    TGN_DPP_REDUCE("v_min_u32_dpp");
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ unsigned wave_min_u32_shfl(unsigned v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -421,6 +425,274 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             st[6] = (unsigned long long)(m - 1);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Large clouds (raw scans of 10^5 points, preprocess_data.py:55-56 resamples N_raw -> 24 000): the same exact
+// bucket skipping with the points in a cell-sorted workspace instead of registers.  The streaming fallback re-reads
+// 20 B per point per iteration (2 MB at 10^5 points; 18-36 us per iteration measured); here an iteration tests
+// ~N/64 bucket boxes held in LDS and touches only the few buckets the new sample can change (1 KiB each, L2-resident).
+//   workspace per cloud: rec[NBpad] float4 (x, y, z, running min distance) + sidx[NBpad] int (original index),
+//   sorted by 15-bit Z-order cell (counting sort: LDS histogram -> scan -> scatter); bucket = 64 consecutive records.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kStreamThreads = 1024;
+constexpr int kStreamMaxBuckets = 4096;           // 262 144 points
+constexpr int kStreamCells = 32768;
+constexpr int kStreamListCap = 1024;
+
+__host__ __device__ inline size_t fps_stream_cloud_bytes(int n_max) {
+    const size_t npad = ((size_t)n_max + 63) / 64 * 64;
+    return npad * (sizeof(float4) + sizeof(int));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kStreamThreads) void fps_bucket_stream_kernel(FpsArgs a) {
+    constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0;
+    constexpr int NT = kStreamThreads, NW = NT / kWave, NBM = kStreamMaxBuckets;
+    // 128 KiB: cell histogram during set-up, then the bucket planes lo[3], hi[3], bmax (float) and bkey (u32)
+    __shared__ unsigned lds[kStreamCells];
+    __shared__ float red[6][NW];
+    __shared__ unsigned long long slots[2][NW];
+    __shared__ int tlist[kStreamListCap];
+    __shared__ int tcount;
+    __shared__ int wave_tot[NW];
+    float *plo0 = (float *)lds, *plo1 = plo0 + NBM, *plo2 = plo1 + NBM, *phi0 = plo2 + NBM, *phi1 = phi0 + NBM,
+          *phi2 = phi1 + NBM, *pmax = phi2 + NBM;
+    unsigned *pkey = lds + 7 * NBM;
+
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    int start_n, n, start_m, m;
+    fps_segment(a, blockIdx.x, start_n, n, start_m, m);
+    if (m <= 0) return;
+    const float *__restrict__ base = a.xyz + (size_t)start_n * 3;
+    const int log2bs = a.ref_log2_block;
+    unsigned char *wsb = (unsigned char *)a.ws + (size_t)blockIdx.x * fps_stream_cloud_bytes(a.n_max);
+    const int NB = (n + 63) / 64;
+    const int npad = NB * 64;
+    float4 *__restrict__ rec = (float4 *)wsb;
+    int *__restrict__ sidx = (int *)(wsb + (((size_t)a.n_max + 63) / 64 * 64) * sizeof(float4));
+
+    // ---- set-up 1: bounding box -------------------------------------------------------------------------------
+    {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = tid; k < n; k += NT) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = base[(size_t)k * 3 + c];
+                if (fabsf(v) <= 3.0e38f) {
+                    lo[c] = fminf(lo[c], v);
+                    hi[c] = fmaxf(hi[c], v);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float l = wave_min_f32_dpp(lo[c]), h = wave_max_f32_dpp(hi[c]);
+            if (lane == 0) {
+                red[c][wave] = l;
+                red[3 + c][wave] = h;
+            }
+        }
+    }
+    for (int i = tid; i < kStreamCells; i += NT) lds[i] = 0;
+    if (tid == 0) tcount = 0;
+    __syncthreads();
+    float glo[3], gscale[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float l = INFINITY, h = -INFINITY;
+        for (int w = 0; w < NW; ++w) {
+            l = fminf(l, red[c][w]);
+            h = fmaxf(h, red[3 + c][w]);
+        }
+        const float ext = h - l;
+        glo[c] = l;
+        gscale[c] = (ext > 0.0f && ext < 3.0e38f) ? 32.0f / ext : 0.0f;
+    }
+    auto cell_of = [&](int i) -> unsigned {
+        unsigned cc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t = (base[(size_t)i * 3 + c] - glo[c]) * gscale[c];
+            t = fminf(fmaxf(t, 0.0f), 31.0f);  // NaN -> 0
+            cc[c] = (unsigned)(int)t;
+        }
+        return spread5(cc[0]) | (spread5(cc[1]) << 1) | (spread5(cc[2]) << 2);
+    };
+    // ---- set-up 2: counting sort by Z-order cell into the workspace ---------------------------------------------
+    for (int i = tid; i < n; i += NT) atomicAdd(&lds[cell_of(i)], 1u);
+    __syncthreads();
+    {
+        constexpr int PER = kStreamCells / NT;  // 32 cells per thread
+        unsigned local[PER];
+        unsigned sum = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            local[i] = sum;
+            sum += lds[tid * PER + i];
+        }
+        unsigned incl = sum;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const unsigned v = (unsigned)__shfl_up((int)incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == kWave - 1) wave_tot[wave] = (int)incl;
+        __syncthreads();
+        unsigned wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += (unsigned)wave_tot[w];
+        const unsigned tbase = wbase + incl - sum;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) lds[tid * PER + i] = tbase + local[i];  // running insert position
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+        const unsigned pos = atomicAdd(&lds[cell_of(i)], 1u);
+        rec[pos] = make_float4(base[(size_t)i * 3 + 0], base[(size_t)i * 3 + 1], base[(size_t)i * 3 + 2], 1e10f);
+        sidx[pos] = i;
+    }
+    for (int i = n + tid; i < npad; i += NT) {
+        rec[i] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);  // padding never wins
+        sidx[i] = 0x7FFFFFFF;
+    }
+    __syncthreads();  // workspace complete and visible to the whole workgroup; histogram no longer needed
+    // ---- set-up 3: bucket planes ---------------------------------------------------------------------------------
+    for (int bk = wave; bk < NBM; bk += NW) {
+        float l0 = INFINITY, l1 = INFINITY, l2 = INFINITY, h0 = -INFINITY, h1 = -INFINITY, h2 = -INFINITY, mx = -1.0f;
+        unsigned key = 0xFFFFFFFFu;
+        if (bk < NB) {
+            const float4 r = rec[bk * kWave + lane];
+            const bool valid = r.w >= 0.0f;
+            l0 = wave_min_f32_dpp(valid ? r.x : INFINITY);
+            h0 = wave_max_f32_dpp(valid ? r.x : -INFINITY);
+            l1 = wave_min_f32_dpp(valid ? r.y : INFINITY);
+            h1 = wave_max_f32_dpp(valid ? r.y : -INFINITY);
+            l2 = wave_min_f32_dpp(valid ? r.z : INFINITY);
+            h2 = wave_max_f32_dpp(valid ? r.z : -INFINITY);
+            mx = wave_max_f32_dpp(r.w);
+            const unsigned o = (unsigned)sidx[bk * kWave + lane];
+            key = wave_min_u32_shfl(valid ? (TREE ? compat_key((int)o, log2bs) : o) : 0xFFFFFFFFu);
+        }
+        if (lane == 0) {
+            plo0[bk] = l0;
+            plo1[bk] = l1;
+            plo2[bk] = l2;
+            phi0[bk] = h0;
+            phi1[bk] = h1;
+            phi2[bk] = h2;
+            pmax[bk] = mx;
+            pkey[bk] = key;
+        }
+    }
+    float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+    if (n > 0) {
+        qx = base[0];
+        qy = base[1];
+        qz = base[2];
+    }
+    int hold_k = 0;
+    float hold_x = qx, hold_y = qy, hold_z = qz;
+    __syncthreads();
+
+    for (int j = 1; j < m; ++j) {
+        // ---- A. every thread tests its buckets; touched ones go to the list ----------------------------------------
+        for (int bk = tid; bk < NBM; bk += NT) {  // NBM is a multiple of NT: uniform trip count, ballots are safe
+            bool need = false;
+            if (bk < NB) {
+                const float ex = fmaxf(fmaxf(plo0[bk] - qx, qx - phi0[bk]), 0.0f);
+                const float ey = fmaxf(fmaxf(plo1[bk] - qy, qy - phi1[bk]), 0.0f);
+                const float ez = fmaxf(fmaxf(plo2[bk] - qz, qz - phi2[bk]), 0.0f);
+                const float L = FMA ? dist_direct_fma(ex, ey, ez) : dist_direct_nofma(ex, ey, ez);
+                need = !(L >= pmax[bk]);
+            }
+            const unsigned long long mk = __ballot(need);
+            if (mk) {
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&tcount, (int)__popcll(mk));
+                wbase = __builtin_amdgcn_readfirstlane(wbase);
+                const int pos = wbase + mbcnt(mk);
+                if (need && pos < kStreamListCap) tlist[pos] = bk;
+            }
+            if (bk - tid + NT >= NB) break;  // uniform: no bucket left in later rounds
+        }
+        __syncthreads();
+        // ---- B. update the touched buckets (waves take them round-robin) ---------------------------------------------
+        {
+            const int cnt = tcount;
+            const bool overflow = cnt > kStreamListCap;  // fall back to re-testing every bucket
+            const int total = overflow ? NB : cnt;
+            for (int e = wave; e < total; e += NW) {
+                int bk = overflow ? e : tlist[e];
+                if (overflow) {
+                    const float ex = fmaxf(fmaxf(plo0[bk] - qx, qx - phi0[bk]), 0.0f);
+                    const float ey = fmaxf(fmaxf(plo1[bk] - qy, qy - phi1[bk]), 0.0f);
+                    const float ez = fmaxf(fmaxf(plo2[bk] - qz, qz - phi2[bk]), 0.0f);
+                    const float L = FMA ? dist_direct_fma(ex, ey, ez) : dist_direct_nofma(ex, ey, ez);
+                    if (L >= pmax[bk]) continue;  // wave-uniform
+                }
+                const int p = bk * kWave + lane;
+                const float4 r = rec[p];
+                const float dx = r.x - qx, dy = r.y - qy, dz = r.z - qz;
+                const float dd = FMA ? dist_direct_fma(dx, dy, dz) : dist_direct_nofma(dx, dy, dz);
+                const float nd = vmin_f32(dd, r.w);
+                rec[p].w = nd;
+                const float mx = wave_max_f32_dpp(nd);
+                const unsigned o = (unsigned)sidx[p];
+                const unsigned kl = (nd == mx) ? (TREE ? compat_key((int)o, log2bs) : o) : 0xFFFFFFFFu;
+                const unsigned key = wave_min_u32_dpp(kl);
+                if (lane == 0) {
+                    pmax[bk] = mx;
+                    pkey[bk] = key;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) tcount = 0;
+        // ---- C. block argmax over all bucket maxima -------------------------------------------------------------------
+        unsigned long long pk = 0ull;
+        for (int bk = tid; bk < NB; bk += NT) {
+            const float v = pmax[bk];
+            const unsigned long long c = v < 0.0f ? 0ull : pack64(__float_as_uint(v), 0xFFFFFFFFu - pkey[bk]);
+            pk = c > pk ? c : pk;
+        }
+        const unsigned long long bmax64 = fps_block_max<NW>(pk, slots, j & 1, wave, lane);
+        const unsigned key = 0xFFFFFFFFu - (unsigned)bmax64;
+        int k = bmax64 == 0ull ? 0 : (TREE ? compat_index(key, log2bs) : (int)key);
+        k = __builtin_amdgcn_readfirstlane(k);
+        if (n > 0) {
+            qx = base[(size_t)k * 3 + 0];
+            qy = base[(size_t)k * 3 + 1];
+            qz = base[(size_t)k * 3 + 2];
+        }
+        if ((j & (NT - 1)) == tid) {
+            hold_k = k;
+            hold_x = qx;
+            hold_y = qy;
+            hold_z = qz;
+        }
+        if ((j & (NT - 1)) == NT - 1) fps_emit(a, start_m + j - (NT - 1) + tid, start_n, hold_k, hold_x, hold_y, hold_z);
+    }
+    {
+        const int cb = ((m - 1) / NT) * NT;
+        if (((m - 1) & (NT - 1)) != NT - 1 && cb + tid <= m - 1)
+            fps_emit(a, start_m + cb + tid, start_n, hold_k, hold_x, hold_y, hold_z);
+    }
+}
+
+size_t fps_stream_workspace_bytes(int b, int n_max) {
+    if (n_max <= 0 || b <= 0 || n_max > kStreamMaxBuckets * kWave) return 0;
+    return (size_t)b * fps_stream_cloud_bytes(n_max);
+}
+
+int fps_bucket_stream_launch(int mode, int b, int n_max, const FpsArgs &a, hipStream_t stream) {
+    if (!a.ws || n_max > kStreamMaxBuckets * kWave || a.ws_bytes < fps_stream_workspace_bytes(b, n_max)) return -1;
+    switch (mode & 3) {
+        case 0: hipLaunchKernelGGL((fps_bucket_stream_kernel<0>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
+        case 1: hipLaunchKernelGGL((fps_bucket_stream_kernel<1>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((fps_bucket_stream_kernel<2>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
+        default: hipLaunchKernelGGL((fps_bucket_stream_kernel<3>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
+    }
+    return check_launch("fps_bucket_stream_kernel");
 }
 
 #define TGN_FPS_BUCKET_CONFIGS(X) X(256, 8) X(256, 16) X(512, 16) X(512, 24) X(512, 32) X(512, 48) X(512, 56)

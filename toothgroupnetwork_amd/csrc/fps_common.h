@@ -13,6 +13,9 @@ struct FpsArgs {
     void *idx;
     float *new_xyz;         // optional (m,3)
     float *tmp;             // only used by the streaming kernel
+    void *ws;               // workspace of the large-cloud bucket kernel (tgn_fps_workspace_bytes)
+    size_t ws_bytes;
+    int n_max;              // largest cloud of the batch (workspace stride)
     int flags;
     int ref_log2_block;     // log2 of the reference's block size (cuda-compat tie order)
 };
@@ -79,5 +82,8 @@ __device__ __forceinline__ unsigned long long fps_block_max(unsigned long long p
 
 // fps_bucket.hip: launches the bucket-skipping kernel when a shape covers n_max; returns -1 if none does.
 int fps_bucket_launch(int mode, int b, int n_max, const FpsArgs &a, hipStream_t stream);
+// large clouds through a cell-sorted workspace; -1 if the workspace is missing / too small / cloud too large
+int fps_bucket_stream_launch(int mode, int b, int n_max, const FpsArgs &a, hipStream_t stream);
+size_t fps_stream_workspace_bytes(int b, int n_max);
 
 }  // namespace tgn

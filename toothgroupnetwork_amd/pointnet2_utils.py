@@ -149,12 +149,11 @@ def _fps_dense(xyz, npoint, want_coords=False, cuda_compat=False):
     B, N, _ = xyz.shape
     idx = torch.empty(B, npoint, dtype=torch.int64, device=xyz.device)
     new_xyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=xyz.device) if want_coords else None
-    tmp = None
-    if N > lib().tgn_fps_resident_capacity():
-        tmp = torch.empty(B * N, dtype=torch.float32, device=xyz.device)
+    from .pointops import fps_workspace
+    ws, nbytes = fps_workspace(B, N, B * N, xyz.device)
     flags = _lib.FPS_LOCAL_INDEX | _lib.FPS_INDEX64 | (_lib.FPS_CUDA_COMPAT if cuda_compat else 0)
-    check(lib().tgn_furthestsampling_dense(B, N, npoint, ptr(xyz), ptr(tmp), ptr(idx), ptr(new_xyz), flags, stream()),
-          "tgn_furthestsampling_dense")
+    check(lib().tgn_furthestsampling_dense_ws(B, N, npoint, ptr(xyz), ptr(ws), nbytes, ptr(idx), ptr(new_xyz), flags,
+                                              stream()), "tgn_furthestsampling_dense")
     return idx, new_xyz
 
 

@@ -39,6 +39,16 @@ def _max_segment(off_h):
     return n_max
 
 
+def fps_workspace(b, n_max, n_total, device):
+    """Scratch for clouds that do not fit the register-resident FPS kernels (raw scans): the cell-sorted
+    workspace of the large-cloud kernel, or -- above its 262 144-point limit -- the reference's tmp array."""
+    if n_max <= lib().tgn_fps_resident_capacity():
+        return None, 0
+    nbytes = int(lib().tgn_fps_workspace_bytes(b, n_max))
+    nbytes = max(nbytes, 4 * int(n_total))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
 def fps_with_coords(xyz, offset, new_offset, cuda_compat=False):
     """furthestsampling that also returns the sampled coordinates xyz[idx] straight from the kernel
     (what blocks.py:69-70 computes with a second gather).  Returns (idx int32 (m,), new_xyz (m,3))."""
@@ -56,12 +66,10 @@ def fps_with_coords(xyz, offset, new_offset, cuda_compat=False):
     m = noff_h[-1]
     idx = torch.empty(m, dtype=torch.int32, device=xyz.device)
     new_xyz = torch.empty(m, 3, dtype=torch.float32, device=xyz.device)
-    tmp = None
-    if n_max > lib().tgn_fps_resident_capacity():
-        tmp = torch.empty(xyz.shape[0], dtype=torch.float32, device=xyz.device)
+    ws, nbytes = fps_workspace(b, n_max, xyz.shape[0], xyz.device)
     flags = _lib.FPS_CUDA_COMPAT if cuda_compat else 0
-    check(lib().tgn_furthestsampling(b, n_max, ptr(xyz), ptr(offset), ptr(new_offset), ptr(tmp), ptr(idx),
-                                     ptr(new_xyz), flags, stream()), "tgn_furthestsampling")
+    check(lib().tgn_furthestsampling_ws(b, n_max, ptr(xyz), ptr(offset), ptr(new_offset), ptr(ws), nbytes, ptr(idx),
+                                        ptr(new_xyz), flags, stream()), "tgn_furthestsampling")
     return idx, new_xyz
 
 
