@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void ball_query_scan_kernel(int B, int N, int 
     const int lane = threadIdx.x & (kWave - 1);
     const int wpb = blockDim.x / kWave;
     const long long total = (long long)B * S;
-    for (long long q = (long long)blockIdx.x * wpb + threadIdx.x / kWave; q < total; q += (long long)gridDim.x * wpb) {
+    for (long long q = (long long)blockIdx.x * wpb + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave); q < total; q += (long long)gridDim.x * wpb) {
         const int b = (int)(q / S);
         ball_scan_row<IdxT>(N, K, r2, xyz + (size_t)b * N * 3, new_xyz[q * 3 + 0], new_xyz[q * 3 + 1],
                             new_xyz[q * 3 + 2], out + q * K, lane);
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kGridThreads) void ball_grid_build_kernel(int N, fl
     __shared__ float red[7][kGridThreads / kWave];
     __shared__ int wave_tot[kGridThreads / kWave];
     __shared__ GridHeader hdr_s;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float *__restrict__ pts = xyz + (size_t)b * N * 3;
     unsigned char *base = ws + (size_t)b * grid_cloud_bytes(N);
     GridHeader *hdr = (GridHeader *)base;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void ball_grid_query_kernel(int B, int N, int 
     __shared__ int hits_s[4][kHitCap];
     __shared__ int keep_s[4][kGridMaxK];
     const int lane = threadIdx.x & (kWave - 1);
-    const int wv = threadIdx.x / kWave;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     int *hits = hits_s[wv];
     int *keep = keep_s[wv];
     const long long total = (long long)B * S;

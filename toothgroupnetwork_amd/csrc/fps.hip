@@ -39,7 +39,7 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(FpsArgs a) {
     __shared__ unsigned long long slots[2][NW];
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
-    const int wave = tid / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);  // wave-uniform (SGPR)
     int start_n, n, start_m, m;
     fps_segment(a, blockIdx.x, start_n, n, start_m, m);
     if (m <= 0) return;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(1024) void fps_streaming_kernel(FpsArgs a) {
     __shared__ unsigned long long slots[2][NW];
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
-    const int wave = tid / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);  // wave-uniform (SGPR)
     int start_n, n, start_m, m;
     fps_segment(a, blockIdx.x, start_n, n, start_m, m);
     if (m <= 0) return;

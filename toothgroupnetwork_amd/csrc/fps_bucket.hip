@@ -126,11 +126,12 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
     __shared__ unsigned sortbuf[M];  // keys, then (aliased) the u16 sorted-position -> point-index table
     __shared__ float red[6][NW];
     __shared__ float4 rec[2][NW][2];  // per wave: {value, tie key} and {x, y, z} of its candidate
+    __shared__ float4 outbuf[NT];      // results of the current chunk of NT iterations
     __shared__ float bmeta[4][NW][P];  // per bucket: x, y, z, lane of the point holding its largest min-distance
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
-    const int wave = tid / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);  // wave-uniform (SGPR)
     int start_n, n, start_m, m;
     fps_segment(a, blockIdx.x, start_n, n, start_m, m);
     if (m <= 0) return;
@@ -259,10 +260,9 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
         qy = base[1];
         qz = base[2];
     }
-    // Results are parked in registers -- thread t keeps row r with r % NT == t -- and written NT rows at a time,
-    // coalesced: the per-iteration store sequence of one lane was ~20 instructions on the critical wave.
-    int hold_k = 0;                                   // row 0: sampling_cuda_kernel.cu:39
-    float hold_x = qx, hold_y = qy, hold_z = qz;
+    // Results are parked in LDS (one 16-B record per row, written by one lane) and flushed NT rows at a time,
+    // coalesced: the per-iteration global store sequence of one lane was ~20 instructions on the critical wave.
+    if (tid == 0) outbuf[0] = make_float4(__int_as_float(0), qx, qy, qz);  // row 0: sampling_cuda_kernel.cu:39
 
     // cached wave candidate (wave-uniform): value, tie key, coordinates
     float wm = -1.0f, wx = 0.0f, wy = 0.0f, wz = 0.0f;
@@ -393,13 +393,13 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
         }
         int k = kwin == 0xFFFFFFFFu ? 0 : (TREE ? compat_index(kwin, log2bs) : (int)kwin);
         k = __builtin_amdgcn_readfirstlane(k);
-        if ((j & (NT - 1)) == tid) {
-            hold_k = k;
-            hold_x = qx;
-            hold_y = qy;
-            hold_z = qz;
+        if (tid == 0) outbuf[j & (NT - 1)] = make_float4(__int_as_float(k), qx, qy, qz);
+        if ((j & (NT - 1)) == NT - 1) {  // wave-uniform
+            __syncthreads();
+            const float4 o = outbuf[tid];
+            fps_emit(a, start_m + j - (NT - 1) + tid, start_n, __float_as_int(o.x), o.y, o.z, o.w);
+            __syncthreads();
         }
-        if ((j & (NT - 1)) == NT - 1) fps_emit(a, start_m + j - (NT - 1) + tid, start_n, hold_k, hold_x, hold_y, hold_z);
         if (dbg) {
             const long long t4 = clock64();
             cyA += t1 - t0;
@@ -408,10 +408,13 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             cyC += t4 - t3;
         }
     }
-    {   // rows of the last, partial chunk
+    if (((m - 1) & (NT - 1)) != NT - 1) {  // rows of the last, partial chunk
+        __syncthreads();
         const int cb = ((m - 1) / NT) * NT;
-        if (((m - 1) & (NT - 1)) != NT - 1 && cb + tid <= m - 1)
-            fps_emit(a, start_m + cb + tid, start_n, hold_k, hold_x, hold_y, hold_z);
+        if (cb + tid <= m - 1) {
+            const float4 o = outbuf[tid];
+            fps_emit(a, start_m + cb + tid, start_n, __float_as_int(o.x), o.y, o.z, o.w);
+        }
     }
     if (dbg && lane == 0) {
         unsigned long long *st = (unsigned long long *)a.tmp;
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(kStreamThreads) void fps_bucket_stream_kernel(FpsAr
           *phi2 = phi1 + NBM, *pmax = phi2 + NBM;
     unsigned *pkey = lds + 7 * NBM;
 
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     int start_n, n, start_m, m;
     fps_segment(a, blockIdx.x, start_n, n, start_m, m);
     if (m <= 0) return;
@@ -695,7 +698,7 @@ int fps_bucket_stream_launch(int mode, int b, int n_max, const FpsArgs &a, hipSt
     return check_launch("fps_bucket_stream_kernel");
 }
 
-#define TGN_FPS_BUCKET_CONFIGS(X) X(256, 8) X(256, 16) X(512, 16) X(512, 24) X(512, 32) X(512, 48) X(512, 56)
+#define TGN_FPS_BUCKET_CONFIGS(X) X(256, 8) X(256, 16) X(512, 16) X(512, 24) X(512, 32) X(512, 47) X(512, 48) X(512, 56)
 
 template <int MODE>
 static int bucket_launch_mode(int b, int n_max, const FpsArgs &a, hipStream_t stream) {

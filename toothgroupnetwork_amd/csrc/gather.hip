@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void group_points_kernel(long long queries, in
     __shared__ float srel[4][kGroupMaxK * 3];
     __shared__ __attribute__((aligned(16))) float stage[4][kWave * 4];  // per-wave transpose buffer
     const int lane = threadIdx.x & (kWave - 1);
-    const int wv = threadIdx.x / kWave;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: q and its pointers live in SGPRs
     const int C = 3 + D;
     const unsigned xo = xyz_first ? 0 : D;   // first channel of the relative coordinates
     const unsigned fo = xyz_first ? 3 : 0;   // first channel of the features
@@ -204,17 +204,19 @@ __global__ __launch_bounds__(256) void group_points_kernel(long long queries, in
         const float cq0 = new_xyz[q * 3 + 0], cq1 = new_xyz[q * 3 + 1], cq2 = new_xyz[q * 3 + 2];
         const size_t pbase = (size_t)b * N;
         bool bad = false;
+        const IdxT *__restrict__ qidx = idx + q * K;  // wave-uniform
         for (int k = lane; k < K; k += kWave) {
-            long long v = (long long)idx[q * K + k];
-            if (v < 0 || v >= N) {  // empty ball -> index N: the reference's advanced indexing raises;
-                bad = true;         // here the row is filled from point 0 and the error word is set
+            const long long v64 = (long long)qidx[k];
+            unsigned v = (unsigned)v64;
+            if (v64 < 0 || v64 >= N) {  // empty ball -> index N: the reference's advanced indexing raises;
+                bad = true;             // here the row is filled from point 0 and the error word is set
                 v = 0;
             }
-            const float *p = xyz + (pbase + v) * 3;
-            sfb[wv][k] = (unsigned)((pbase + v) * D);
-            srel[wv][k * 3 + 0] = p[0] - cq0;
-            srel[wv][k * 3 + 1] = p[1] - cq1;
-            srel[wv][k * 3 + 2] = p[2] - cq2;
+            const unsigned pv = (unsigned)pbase + v;  // B*N*max(D,3) < 2^32 is checked by the launcher
+            sfb[wv][k] = pv * (unsigned)D;
+            srel[wv][k * 3 + 0] = xyz[pv * 3u + 0u] - cq0;
+            srel[wv][k * 3 + 1] = xyz[pv * 3u + 1u] - cq1;
+            srel[wv][k * 3 + 2] = xyz[pv * 3u + 2u] - cq2;
         }
         if (__any(bad) && lane == 0) atomicOr(err, 1);
         // (the same wave wrote the tables: LDS operations of one wave complete in order, no barrier needed)

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(int b, int m, int k, cons
                                                         const int *__restrict__ new_offset, int *__restrict__ idx,
                                                         float *__restrict__ dist2, int *__restrict__ redo) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int q0 = (blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) * kKnnQ;
+    const int q0 = (blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave)) * kKnnQ;
     if (q0 >= m) return;
     float qx[kKnnQ], qy[kKnnQ], qz[kKnnQ], ld[kKnnQ], tau[kKnnQ];
     int li[kKnnQ], st[kKnnQ], en[kKnnQ];
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void knn_heap_wave_kernel(int b, int m, int ns
     __shared__ float hd_s[4][kKnnHeapMax];
     __shared__ int hi_s[4][kKnnHeapMax];
     const int lane = threadIdx.x & (kWave - 1);
-    const int wv = threadIdx.x / kWave;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     float *hd = hd_s[wv];
     int *hi = hi_s[wv];
     const int total = only ? only[0] : m;
