@@ -159,6 +159,17 @@ int tgn_ball_query(int B, int N, int S, int nsample, float r2, const float *xyz,
  */
 int tgn_group_points(int B, int N, int S, int K, int D, const float *xyz, const float *new_xyz, const float *points,
                      const void *idx, int idx_is_int64, int xyz_first, float *out, tgn_stream_t stream);
+/*
+ * Fused first layer of a set-abstraction shared MLP, eval mode (pointnet2_utils.py:229-236, 281-294): the 1x1
+ * convolution commutes with the gather, so the caller transforms the POINTS once (A = scale*(W_p*points + W_x*xyz),
+ * (B,N,C)) and folds bias / BatchNorm / the centre term into Cst (B,S,C); this writes
+ *   out[b,s,k,:] = act(A[b, idx[b,s,k], :] + Cst[b,s,:])   (B,S,K,C)      -- the grouped (B,S,K,3+D) tensor never exists
+ * and the _max form reduces over k as well (single-layer MLPs): out (B,S,C).  relu != 0 applies max(.,0).
+ */
+int tgn_sa_first_layer(int B, int N, int S, int K, int C, const float *A, const float *Cst, const void *idx,
+                       int idx_is_int64, int relu, float *out, tgn_stream_t stream);
+int tgn_sa_first_layer_max(int B, int N, int S, int K, int C, const float *A, const float *Cst, const void *idx,
+                           int idx_is_int64, int relu, float *out, tgn_stream_t stream);
 /* index_points (pointnet2_utils.py:44-61): out[b,j,:] = points[b, idx[b,j], :], idx flattened to (B,M). */
 int tgn_gather_points(int B, int N, int M, int C, const float *points, const void *idx, int idx_is_int64, float *out,
                       tgn_stream_t stream);

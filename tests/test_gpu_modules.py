@@ -47,6 +47,30 @@ def test_set_abstraction_ssg_and_feature_propagation_match_reference_modules(dev
     np.testing.assert_allclose(out.cpu().numpy(), golden["mod_fp_out"], rtol=1e-4, atol=1e-4)
 
 
+def test_fused_first_layer_equals_unfused_path(dev, golden, weights, monkeypatch):
+    """eval-mode fused first layer (grouped tensor never built) vs the materialised path, same weights."""
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    xyz, pts = T(golden["mod_xyz_cf"], dev), T(golden["mod_pts_cf"], dev)
+    sa = U.PointNetSetAbstractionMsg(128, [0.1, 0.2], [8, 16], 6, [[16, 24], [16, 32]]).to(dev).eval()
+    sa.load_state_dict(weights["sa"])
+    ssg = U.PointNetSetAbstraction(64, 0.2, 16, 9, [16, 32], False).to(dev).eval()
+    ssg.load_state_dict(weights["ssg"])
+    one = U.PointNetSetAbstraction(64, 0.2, 16, 9, [20], False).to(dev).eval()      # single layer: max fused too
+    onem = U.PointNetSetAbstractionMsg(64, [0.2], [16], 6, [[20]]).to(dev).eval()
+    with torch.no_grad():
+        for m_ in (one, onem):
+            for bn in [x for x in m_.modules() if isinstance(x, torch.nn.BatchNorm2d)]:
+                bn.running_mean.normal_(0, 0.2)
+                bn.running_var.uniform_(0.5, 2.0)
+        fused = [m(xyz, pts) for m in (sa, ssg, one, onem)]
+        monkeypatch.setattr(U, "FUSED_SA", False)
+        plain = [m(xyz, pts) for m in (sa, ssg, one, onem)]
+    for (fx, ff), (px, pf) in zip(fused, plain):
+        assert torch.equal(fx, px)
+        torch.testing.assert_close(ff, pf, rtol=1e-4, atol=1e-4)
+    assert fused[2][1].shape == (2, 20, 64)
+
+
 def test_modules_train_step_runs_and_gradients_flow(dev):
     from toothgroupnetwork_amd import pointnet2_utils as U
     torch.manual_seed(0)

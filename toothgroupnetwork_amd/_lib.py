@@ -58,6 +58,8 @@ SIGNATURES = {
     "tgn_ball_query_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "tgn_ball_query": (c_int, [c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "tgn_group_points": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "tgn_sa_first_layer": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P]),
+    "tgn_sa_first_layer_max": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P]),
     "tgn_gather_points": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P]),
     "tgn_scatter_add_points": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P]),
     "tgn_three_nn": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),

@@ -262,6 +262,63 @@ __global__ __launch_bounds__(256) void group_points_kernel(long long queries, in
     }
 }
 
+// Set-abstraction first layer, fused.  A 1x1 convolution commutes with the gather:
+//   W * [points[idx], xyz[idx] - c] + b  ==  (W_p*points + W_x*xyz)[idx] - W_x*c + b
+// so the first shared-MLP layer is evaluated once per POINT (N rows, a plain GEMM done by the host side)
+// instead of once per (query, neighbour) pair (S*K rows), and the grouped (B,S,K,3+D) tensor of
+// pointnet2_utils.py:162-169 / 281-285 is never materialised.  With eval-mode BatchNorm folded in,
+//   out[b,s,k,:] = relu(A[b, idx[b,s,k], :] + Cst[b,s,:])       (this kernel; same lane-contiguous walk as group_points)
+// and for a single-layer MLP the max over k (pointnet2_utils.py:236/294) is taken in registers:
+//   outmax[b,s,:] = relu(max_k A[b, idx[b,s,k], :] + Cst[b,s,:]).
+template <typename IdxT, bool MAXK>
+__global__ __launch_bounds__(256) void sa_first_layer_kernel(long long queries, int N, int S, int K, int C,
+                                                              unsigned magicC, const float *__restrict__ A,
+                                                              const float *__restrict__ Cst,
+                                                              const IdxT *__restrict__ idx, int relu,
+                                                              float *__restrict__ out, int *__restrict__ err) {
+    __shared__ unsigned sfb[4][kGroupMaxK];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const unsigned nb = gridDim.x;  // multiple of 8: XCD-aware order as in group_points_kernel
+    const unsigned lb = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
+    for (long long q = (long long)lb * 4 + wv; q < queries; q += (long long)nb * 4) {
+        const int b = (int)(q / S);
+        const size_t pbase = (size_t)b * N;
+        const IdxT *__restrict__ qidx = idx + q * K;
+        bool bad = false;
+        for (int k = lane; k < K; k += kWave) {
+            const long long v64 = (long long)qidx[k];
+            unsigned v = (unsigned)v64;
+            if (v64 < 0 || v64 >= N) {
+                bad = true;
+                v = 0;
+            }
+            sfb[wv][k] = ((unsigned)pbase + v) * (unsigned)C;
+        }
+        if (__any(bad) && lane == 0) atomicOr(err, 1);
+        const float *__restrict__ cst = Cst + (size_t)q * C;
+        if constexpr (MAXK) {
+            float *__restrict__ dst = out + (size_t)q * C;
+            for (int c = lane; c < C; c += kWave) {
+                float m = -INFINITY;
+                for (int k = 0; k < K; ++k) m = fmaxf(m, A[sfb[wv][k] + (unsigned)c]);
+                const float v = m + cst[c];
+                dst[c] = relu ? fmaxf(v, 0.0f) : v;
+            }
+        } else {
+            const int total = K * C;
+            float *__restrict__ dst = out + (size_t)q * total;
+#pragma unroll 2
+            for (int e = lane; e < total; e += kWave) {
+                const unsigned k = __umulhi((unsigned)e, magicC);
+                const unsigned c = (unsigned)e - k * (unsigned)C;
+                const float v = A[sfb[wv][k] + c] + cst[c];
+                dst[e] = relu ? fmaxf(v, 0.0f) : v;
+            }
+        }
+    }
+}
+
 template <typename IdxT>
 __global__ __launch_bounds__(256) void gather_points_kernel(long long rows, int N, int M, int C, int cx_log2,
                                                              const float *__restrict__ points,
@@ -457,6 +514,43 @@ TGN_API int tgn_group_points(int B, int N, int S, int K, int D, const float *xyz
     }
 #undef TGN_GP_LAUNCH
     return check_launch("group_points_kernel");
+}
+
+static int sa_first_layer_launch(int B, int N, int S, int K, int C, const float *A, const float *Cst, const void *idx,
+                                 int idx_is_int64, int relu, float *out, bool maxk, hipStream_t st) {
+    const long long queries = (long long)B * S;
+    if (queries <= 0 || K <= 0 || C <= 0) return TGN_OK;
+    if (!A || !Cst || !idx || !out) {
+        set_error("tgn_sa_first_layer: null pointer");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    if (K > kGroupMaxK || (long long)K * C >= (1LL << 31) / C || (long long)B * N * C >= (1LL << 32)) {
+        set_error("tgn_sa_first_layer: nsample %d / channels %d out of the supported range", K, C);
+        return TGN_ERR_UNSUPPORTED;
+    }
+    int *err = index_error_word();
+    const unsigned magicC = (unsigned)((0x100000000ULL + C - 1) / C);
+    const long long blocks = ((queries + 3) / 4 + 7) / 8 * 8;
+#define TGN_SA_LAUNCH(IT, MK)                                                                                     \
+    hipLaunchKernelGGL((sa_first_layer_kernel<IT, MK>), dim3((unsigned)blocks), dim3(256), 0, st, queries, N, S, K, C, \
+                       magicC, A, Cst, (const IT *)idx, relu, out, err)
+    if (idx_is_int64) {
+        if (maxk) TGN_SA_LAUNCH(long long, true); else TGN_SA_LAUNCH(long long, false);
+    } else {
+        if (maxk) TGN_SA_LAUNCH(int, true); else TGN_SA_LAUNCH(int, false);
+    }
+#undef TGN_SA_LAUNCH
+    return check_launch("sa_first_layer_kernel");
+}
+
+TGN_API int tgn_sa_first_layer(int B, int N, int S, int K, int C, const float *A, const float *Cst, const void *idx,
+                               int idx_is_int64, int relu, float *out, tgn_stream_t stream) {
+    return sa_first_layer_launch(B, N, S, K, C, A, Cst, idx, idx_is_int64, relu, out, false, (hipStream_t)stream);
+}
+
+TGN_API int tgn_sa_first_layer_max(int B, int N, int S, int K, int C, const float *A, const float *Cst, const void *idx,
+                                   int idx_is_int64, int relu, float *out, tgn_stream_t stream) {
+    return sa_first_layer_launch(B, N, S, K, C, A, Cst, idx, idx_is_int64, relu, out, true, (hipStream_t)stream);
 }
 
 TGN_API int tgn_gather_points(int B, int N, int M, int C, const float *points, const void *idx, int idx_is_int64,

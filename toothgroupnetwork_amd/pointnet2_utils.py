@@ -10,6 +10,7 @@ and three_interpolate are single HIP kernels (include/tgn_pointops.h section 3) 
 torch kernels that materialise (B,S,N) matrices and sort them.  The shared MLPs stay nn.Conv/BatchNorm
 layers with the reference's parameter names, so state_dicts are interchangeable.
 """
+import os
 from time import time
 
 import numpy as np
@@ -370,6 +371,64 @@ def three_interpolate(points2, dist, idx):
 
 
 # ---------------------------------------------------------------------------------------------
+# fused first layer of a set-abstraction MLP (eval mode)
+# ---------------------------------------------------------------------------------------------
+FUSED_SA = os.environ.get("TGN_FUSED_SA", "1") != "0"
+
+
+def _can_fuse(module, *tensors):
+    """Eval-mode, no autograd through the inputs: BatchNorm is a fixed affine map and can be folded."""
+    if not FUSED_SA or module.training:
+        return False
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        return False
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        return False
+    return True
+
+
+def sa_first_layer(xyz, new_xyz, points, idx, conv, bn, xyz_first, reduce_max=False):
+    """relu(bn(conv(grouped))) of the FIRST shared-MLP layer without ever building `grouped`
+    (pointnet2_utils.py:162-169 + 229-233, or 281-292 for Msg).  The 1x1 convolution commutes with the gather:
+        W*[points[idx], xyz[idx]-c] + b = (W_p*points + W_x*xyz)[idx] + (b - W_x*c)
+    so the dense part runs over the N points (one GEMM) instead of the S*K grouped rows, and the HIP kernel only
+    gathers, adds the per-query constant and applies ReLU (optionally also the max over the K neighbours).
+    Returns (B,S,K,C1), or (B,S,C1) with reduce_max.  Eval-mode BatchNorm statistics are folded in."""
+    B, N, _ = xyz.shape
+    _, S, K = idx.shape
+    C1 = conv.out_channels
+    W = conv.weight.detach().reshape(C1, -1).float()
+    bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(C1, device=W.device)
+    scale = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).float()
+    shift = (bn.bias.detach() - bn.running_mean * scale).float()
+    D = 0 if points is None else points.shape[2]
+    Wx, Wp = (W[:, :3], W[:, 3:]) if xyz_first else (W[:, D:], W[:, :D])
+    G = torch.matmul(xyz, Wx.t())
+    if points is not None:
+        G = G + torch.matmul(points, Wp.t())
+    A = (G * scale).contiguous()                                                   # (B,N,C1)
+    Cst = (shift + scale * (bias - torch.matmul(new_xyz, Wx.t()))).contiguous()    # (B,S,C1)
+    idx = idx.contiguous()
+    if reduce_max:
+        out = torch.empty(B, S, C1, dtype=torch.float32, device=xyz.device)
+        check(lib().tgn_sa_first_layer_max(B, N, S, K, C1, ptr(A), ptr(Cst), ptr(idx), int(idx.dtype == torch.int64), 1,
+                                           ptr(out), stream()), "sa_first_layer_max")
+    else:
+        out = torch.empty(B, S, K, C1, dtype=torch.float32, device=xyz.device)
+        check(lib().tgn_sa_first_layer(B, N, S, K, C1, ptr(A), ptr(Cst), ptr(idx), int(idx.dtype == torch.int64), 1,
+                                       ptr(out), stream()), "sa_first_layer")
+    return out
+
+
+def _mlp_tail_and_max(x_bskc, convs, bns, first):
+    """Layers `first`.. of the shared MLP on a (B,S,K,C) tensor, then max over K -> (B,C',S)."""
+    x = x_bskc.permute(0, 3, 2, 1)  # [B, C, K, S] view, exactly what the reference feeds its Conv2d stack
+    for j in range(first, len(convs)):
+        x = F.relu(bns[j](convs[j](x)))
+    return torch.max(x, 2)[0]
+
+
+# ---------------------------------------------------------------------------------------------
 # modules (constructor signatures and parameter names of pointnet2_utils.py:198-352)
 # ---------------------------------------------------------------------------------------------
 class PointNetSetAbstraction(nn.Module):
@@ -399,6 +458,17 @@ class PointNetSetAbstraction(nn.Module):
         xyz = xyz.permute(0, 2, 1)
         if points is not None:
             points = points.permute(0, 2, 1)
+        if not self.group_all and _can_fuse(self, xyz, points) and len(self.mlp_convs) > 0:
+            # eval fast path: FPS (+coordinates) -> ball query -> fused first layer; `grouped` is never built
+            xyz_c = _f32c(xyz)
+            points_c = None if points is None else _f32c(points)
+            _, new_xyz = _fps_dense(xyz_c, self.npoint, want_coords=True)
+            idx = query_ball_point(self.radius, self.nsample, xyz_c, new_xyz)
+            single = len(self.mlp_convs) == 1
+            y = sa_first_layer(xyz_c, new_xyz, points_c, idx, self.mlp_convs[0], self.mlp_bns[0], xyz_first=True,
+                               reduce_max=single)
+            new_points = y.permute(0, 2, 1) if single else _mlp_tail_and_max(y, self.mlp_convs, self.mlp_bns, 1)
+            return new_xyz.permute(0, 2, 1), new_points
         if self.group_all:
             new_xyz, new_points = sample_and_group_all(xyz, points)
         else:
@@ -451,10 +521,18 @@ class PointNetSetAbstractionMsg(nn.Module):
             _, new_xyz = _fps_dense(xyz, S, want_coords=True)
         xyz_c = _f32c(xyz)
         points_c = None if points is None else _f32c(points)
+        fuse = _can_fuse(self, xyz, points)
         new_points_list = []
         for i, radius in enumerate(self.radius_list):
             K = self.nsample_list[i]
             group_idx = query_ball_point(radius, K, xyz_c, new_xyz)
+            if fuse:
+                convs, bns = self.conv_blocks[i], self.bn_blocks[i]
+                single = len(convs) == 1
+                y = sa_first_layer(xyz_c, new_xyz, points_c, group_idx, convs[0], bns[0], xyz_first=False,
+                                   reduce_max=single)
+                new_points_list.append(y.permute(0, 2, 1) if single else _mlp_tail_and_max(y, convs, bns, 1))
+                continue
             grouped_points = group_points(xyz_c, new_xyz, points_c, group_idx, xyz_first=False)  # [feat, rel_xyz] (:285)
             grouped_points = grouped_points.permute(0, 3, 2, 1)  # [B, D, K, S]
             for j in range(len(self.conv_blocks[i])):
