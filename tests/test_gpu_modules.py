@@ -182,6 +182,31 @@ def test_full_size_shape_a_properties(dev, oracle):
             cur_pts = torch.randn(3, S, D_next, device=dev)
 
 
+def test_hotpath_pipelined_equals_single_stream(dev):
+    """The two-stream, double-buffered schedule of bench.py produces exactly the single-stream results."""
+    from toothgroupnetwork_amd import hotpath
+    shape = dict(n=6000, npoint=[1024, 256], radius=[0.1, 0.2], nsample=[32, 32], d=[6, 64])
+    B = 6
+    scans = synth.scan_batch(B, 6000, "arch", 77)
+    pts = T(scans, dev)
+    xyz = pts[:, :, :3].contiguous()
+    feats = [pts, torch.randn(B, 1024, 64, device=dev)]
+    ref = hotpath.HotPath(B, dev, shape=shape)
+    ref.run(xyz, feats)
+    torch.cuda.synchronize()
+    pipe = hotpath.HotPath(B, dev, shape=shape, pipeline=True)
+    for step in range(5):
+        levels = pipe.run(xyz, feats)
+        torch.cuda.synchronize()
+        for a, b in zip(levels, ref.levels):
+            for key in ("fps_idx", "new_xyz", "group_idx", "grouped"):
+                assert torch.equal(a[key], b[key]), (step, key)
+    levels = [pipe.run(xyz, feats) for _ in range(4)][-1]     # back-to-back, no host sync in between
+    torch.cuda.synchronize()
+    for a, b in zip(levels, ref.levels):
+        assert torch.equal(a["grouped"], b["grouped"])
+
+
 def test_full_size_knn_and_three_nn_properties(dev):
     from toothgroupnetwork_amd import pointnet2_utils as U, pointops as P
     xyz_np = synth.arch_cloud(24000, 31, False)

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
 
     // optional instrumentation (flag 0x100 + tmp): touched-bucket census and per-phase cycles of one wave
     const bool dbg = (a.flags & 0x100) && a.tmp;
-    unsigned long long st_touched = 0, st_waves = 0, cyA = 0, cyU = 0, cyB = 0, cyC = 0;
+    unsigned long long st_touched = 0, st_waves = 0, cyA = 0, cyU = 0, cyB = 0, cyC = 0, cyC1 = 0, cyC2 = 0;
 
     for (int j = 1; j < m; ++j) {
         long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
@@ -366,7 +366,14 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
                 rec[j & 1][wave][0] = make_float4(wm < 0.0f ? 0.0f : wm, __uint_as_float(wm < 0.0f ? 0xFFFFFFFFu : wkey), 0.0f, 0.0f);
                 rec[j & 1][wave][1] = make_float4(wx, wy, wz, 0.0f);
             }
+            long long tc1 = 0, tc2 = 0;
+            if (dbg) tc1 = clock64();
             __syncthreads();
+            if (dbg) {
+                tc2 = clock64();
+                cyC1 += tc1 - t3;
+                cyC2 += tc2 - tc1;
+            }
             // distances are >= 0: their bit patterns order like unsigned integers
             const float4 r0 = lane < NW ? rec[j & 1][lane][0] : make_float4(0.0f, __uint_as_float(0xFFFFFFFFu), 0.0f, 0.0f);
             const unsigned vb = __float_as_uint(r0.x);
@@ -426,6 +433,8 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             st[4] = cyB;
             st[5] = cyC;
             st[6] = (unsigned long long)(m - 1);
+            st[7] = cyC1;
+            st[8] = cyC2;
         }
     }
 }

@@ -246,9 +246,10 @@ __global__ __launch_bounds__(256) void group_points_kernel(long long queries, in
                 if (e < total) *(float4 *)(dst + e) = *(const float4 *)&stage[wv][lane * 4];
             }
         } else {
-            // lane-contiguous gathers AND stores (256 contiguous bytes per wave-instruction); independent
-            // iterations, unrolled so that several gathers per lane are in flight
-#pragma unroll 2
+            // lane-contiguous gathers AND stores (256 contiguous bytes per wave-instruction).  Not unrolled on
+            // purpose: at 26 VGPRs a wave of this kernel fits beside the FPS workgroup that owns 94 % of a CU's
+            // registers (bench.py --pipeline), and unrolling by 2 measured no faster on an empty chip.
+#pragma unroll 1
             for (int e = lane; e < total; e += kWave) {
                 const unsigned k = __umulhi((unsigned)e, magicC);
                 const unsigned c = (unsigned)e - k * (unsigned)C;

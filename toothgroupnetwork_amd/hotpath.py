@@ -33,13 +33,33 @@ def algorithmic_bytes(n, npoint, nsample, d, fused=False):
 
 
 class HotPath:
-    """Pre-planned FPS -> ball query -> group over `levels` for a fixed batch of B scans."""
+    """Pre-planned FPS -> ball query -> group over `levels` for a fixed batch of B scans.
 
-    def __init__(self, B, device, shape=SHAPE_A, xyz_first=True, index_dtype=torch.int32):
+    pipeline=True software-pipelines consecutive steps over two HIP streams: the FPS chain of step k+1 (latency
+    bound: one workgroup per CU, nearly all registers, almost no issue slots or bandwidth) runs on a high-priority
+    stream while the ball queries and groupings of step k (HBM / VALU bound, 26-56 VGPRs) run on a second stream and
+    fill the CUs around it.  Buffers are double-buffered by step parity; HIP events order FPS level l before the
+    ball query / grouping of level l of the same step, and step k-2's consumers before step k's producers."""
+
+    def __init__(self, B, device, shape=SHAPE_A, xyz_first=True, index_dtype=torch.int32, pipeline=False):
         self.B, self.device, self.shape = B, device, shape
         self.xyz_first = xyz_first
         self.L = lib()
-        self.levels = []
+        self.pipeline = pipeline
+        self.sets = [self._alloc(B, device, shape, index_dtype) for _ in range(2 if pipeline else 1)]
+        self.levels = self.sets[0]
+        self.idx64 = int(index_dtype == torch.int64)
+        self.events = None
+        self.step_no = 0
+        if pipeline:
+            self.s_fps = torch.cuda.Stream(device=device, priority=-1)
+            self.s_rest = torch.cuda.Stream(device=device, priority=0)
+            self.ev_fps = [[torch.cuda.Event() for _ in shape["npoint"]] for _ in range(2)]
+            self.ev_done = [torch.cuda.Event() for _ in range(2)]
+            self.ev_start = torch.cuda.Event()
+
+    def _alloc(self, B, device, shape, index_dtype):
+        levels = []
         N = shape["n"]
         f32 = dict(dtype=torch.float32, device=device)
         for S, r, K, D in zip(shape["npoint"], shape["radius"], shape["nsample"], shape["d"]):
@@ -52,10 +72,9 @@ class HotPath:
             nbytes = int(self.L.tgn_ball_query_workspace_bytes(B, N, S))
             lv["ws_bytes"] = nbytes
             lv["ws"] = torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None
-            self.levels.append(lv)
+            levels.append(lv)
             N = S
-        self.idx64 = int(index_dtype == torch.int64)
-        self.events = None
+        return levels
 
     def enable_kernel_timing(self, steps):
         """HIP events on the launch stream around each kernel class (start/stop per step)."""
@@ -67,17 +86,22 @@ class HotPath:
     def kernel_times_ms(self):
         return {n: [a.elapsed_time(b) for a, b in evs[:self._step]] for n, evs in self.events.items()}
 
-    def _timed(self, name, fn):
+    def _timed(self, name, fn, stream=None):
         if self.events is None or self._step >= len(self.events[name]):
             return fn()
         a, b = self.events[name][self._step]
-        a.record()
+        a.record(stream)
         fn()
-        b.record()
+        b.record(stream)
 
-    def run(self, xyz, feats):
+    def run(self, xyz, feats, inputs_on_current_stream=True):
         """xyz: (B, N, 3) fp32 contiguous; feats: list of per-level feature tensors (B, N_l, D_l).
-        Results land in self.levels[l]['grouped'] etc.  Asynchronous on the current stream."""
+        Results land in self.levels[l]['grouped'] etc. (pipelined: self.sets[step parity]).  Asynchronous.
+        Pipelined mode: inputs_on_current_stream=False tells the planner that the inputs were complete before
+        an earlier step was enqueued (e.g. a resident dataset), so this step need not wait for the caller's stream
+        -- which itself waits for the previous step's results -- and consecutive steps can overlap."""
+        if self.pipeline:
+            return self._run_pipelined(xyz, feats, inputs_on_current_stream)
         L, st = self.L, _lib.stream()
         cur_xyz = xyz
         for i, lv in enumerate(self.levels):
@@ -95,3 +119,45 @@ class HotPath:
         if self.events is not None:
             self._step += 1
         return self.levels
+
+    def _run_pipelined(self, xyz, feats, inputs_on_current_stream=True):
+        L = self.L
+        p = self.step_no & 1
+        levels = self.sets[p]
+        sf, sg = self.s_fps, self.s_rest
+        pf, pg = _lib.c_void_p(sf.cuda_stream), _lib.c_void_p(sg.cuda_stream)
+        cur = torch.cuda.current_stream()
+        if inputs_on_current_stream or self.step_no == 0:
+            self.ev_start.record(cur)      # inputs produced on the caller's stream
+            sf.wait_event(self.ev_start)
+            sg.wait_event(self.ev_start)
+        if self.step_no >= 2:
+            sf.wait_event(self.ev_done[p])  # buffer set p is free again once step k-2's consumers are through
+        B = self.B
+        cur_xyz = xyz
+        # stream F: the latency-bound chain FPS_l -> ball query_l (needs 56 VGPRs: it cannot squeeze in beside an FPS
+        # workgroup, so it stays in line with them); stream G: the groupings (26 VGPRs), which slot in beside the
+        # next step's FPS level 1
+        for i, lv in enumerate(levels):
+            N, S, K = lv["N"], lv["S"], lv["K"]
+            self._timed(f"fps_l{i + 1}", lambda: check(L.tgn_furthestsampling_dense(
+                B, N, S, ptr(cur_xyz), None, ptr(lv["fps_idx"]), ptr(lv["new_xyz"]), _lib.FPS_LOCAL_INDEX, pf), "fps"), sf)
+            self._timed(f"ball_l{i + 1}", lambda: check(L.tgn_ball_query(
+                B, N, S, K, lv["r2"], ptr(cur_xyz), ptr(lv["new_xyz"]), ptr(lv["group_idx"]), self.idx64,
+                ptr(lv["ws"]), lv["ws_bytes"], pf), "ball_query"), sf)
+            self.ev_fps[p][i].record(sf)
+            cur_xyz = lv["new_xyz"]
+        cur_xyz = xyz
+        for i, lv in enumerate(levels):
+            N, S, K, D = lv["N"], lv["S"], lv["K"], lv["D"]
+            sg.wait_event(self.ev_fps[p][i])
+            self._timed(f"group_l{i + 1}", lambda: check(L.tgn_group_points(
+                B, N, S, K, D, ptr(cur_xyz), ptr(lv["new_xyz"]), ptr(feats[i]), ptr(lv["group_idx"]), self.idx64,
+                int(self.xyz_first), ptr(lv["grouped"]), pg), "group_points"), sg)
+            cur_xyz = lv["new_xyz"]
+        self.ev_done[p].record(sg)
+        cur.wait_event(self.ev_done[p])     # the caller's stream sees this step's results
+        self.step_no += 1
+        if self.events is not None:
+            self._step += 1
+        return levels
