@@ -15,5 +15,5 @@ for (N, S, B) in [(24000, 4096, 1), (24000, 4096, 256), (4096, 1024, 256)]:
     torch.cuda.synchronize()
     v = st[:32].view(torch.int64).cpu().numpy()
     it = max(int(v[6]), 1)
-    print(f"N={N} S={S} B={B}: touched buckets/iter/cloud={v[0] / it / B:.2f}  waves touched/iter/cloud={v[1] / it / B:.2f}  "
+    print(f"N={N} S={S} B={B}: refresh-skipped/iter/cloud={v[9] / it / B:.2f} touched buckets/iter/cloud={v[0] / it / B:.2f}  waves touched/iter/cloud={v[1] / it / B:.2f}  "
           f"cycles/iter wave0: A={v[2] / it:.0f} update={v[3] / it:.0f} cand={v[4] / it:.0f} C={v[5] / it:.0f} (rec write {v[7] / it:.0f}, barrier wait {v[8] / it:.0f})")

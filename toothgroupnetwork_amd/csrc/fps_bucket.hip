@@ -31,6 +31,10 @@
 
 #include <type_traits>
 
+#ifndef TGN_REFRESH_SKIP
+#define TGN_REFRESH_SKIP 1
+#endif
+
 namespace tgn {
 
 // 64-lane max / min of an fp32 value; wave-uniform result.  Written as six v_max_f32_dpp / v_min_f32_dpp
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
     //         by the winning lane itself with one 16-B store and read only when the wave's candidate changes. ----
     float blo0 = INFINITY, blo1 = INFINITY, blo2 = INFINITY, bhi0 = -INFINITY, bhi1 = -INFINITY, bhi2 = -INFINITY;
     float bmax = -1.0f;
+    int blane = 0;  // lane of the bucket's arg-max point (refreshed together with bmax)
 #pragma unroll
     for (int s = 0; s < P; ++s) {
         const bool valid = d[s] >= 0.0f;
@@ -251,7 +256,20 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
         bhi0 = writelane_f32(bhi0, h0, s);
         bhi1 = writelane_f32(bhi1, h1, s);
         bhi2 = writelane_f32(bhi2, h2, s);
-        bmax = writelane_f32(bmax, any, s);  // 1e10 if the bucket holds a real point, else -1 (first pass fixes the rest)
+        bmax = writelane_f32(bmax, any, s);  // 1e10 if the bucket holds a real point, else -1
+        // initial arg-max of the bucket: all real points sit at 1e10, the smallest tie key wins
+        const unsigned o = tab[(s * NW + wave) * kWave + lane];
+        const unsigned kl = valid ? (TREE ? compat_key((int)o, log2bs) : o) : 0xFFFFFFFFu;
+        const unsigned kmin = wave_min_u32_dpp(kl);
+        const bool win = valid && kl == kmin;
+        if (win) {
+            bmeta[0][wave][s] = x[s];
+            bmeta[1][wave][s] = y[s];
+            bmeta[2][wave][s] = z[s];
+            bmeta[3][wave][s] = __int_as_float(lane);
+        }
+        const unsigned long long wm0 = __ballot(win);
+        blane = lane == s ? (wm0 ? (int)__builtin_ctzll(wm0) : 0) : blane;
     }
 
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
@@ -271,7 +289,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
 
     // optional instrumentation (flag 0x100 + tmp): touched-bucket census and per-phase cycles of one wave
     const bool dbg = (a.flags & 0x100) && a.tmp;
-    unsigned long long st_touched = 0, st_waves = 0, cyA = 0, cyU = 0, cyB = 0, cyC = 0, cyC1 = 0, cyC2 = 0;
+    unsigned long long st_skip = 0, st_touched = 0, st_waves = 0, cyA = 0, cyU = 0, cyB = 0, cyC = 0, cyC1 = 0, cyC2 = 0;
 
     for (int j = 1; j < m; ++j) {
         long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
@@ -305,6 +323,14 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
                             const float dd = FMA ? dist_direct_fma(dx, dy, dz) : dist_direct_nofma(dx, dy, dz);
                             const float nd = vmin_f32(dd, d[s]);  // min(d, tmp[k]) sampling_cuda_kernel.cu:55
                             d[s] = nd;
+                            // Distances only shrink: if the bucket's arg-max point kept its value, the bucket's
+                            // maximum and arg-max are unchanged and the 64-lane refresh is skipped.
+                            const float bold = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bmax), s));
+                            const int alane = __builtin_amdgcn_readlane(blane, s);
+                            const float na = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nd), alane));
+                            const bool unchanged = TGN_REFRESH_SKIP && na == bold;  // wave-uniform
+                            if (dbg && unchanged) ++st_skip;
+                            if (!unchanged) {
                             const float mx = wave_max_f32_dpp(nd);
                             const unsigned long long eq = __ballot(nd == mx);
                             bool win = nd == mx;
@@ -321,7 +347,10 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
                                 bmeta[2][wave][s] = z[s];
                                 bmeta[3][wave][s] = __int_as_float(lane);
                             }
+                            const int wlane = (int)__builtin_ctzll(__ballot(win));  // (ballot OUTSIDE the per-lane select)
                             bmax = lane == s ? mx : bmax;
+                            blane = lane == s ? wlane : blane;
+                            }
                         }
                     }
                 }
@@ -376,6 +405,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             }
             // distances are >= 0: their bit patterns order like unsigned integers
             const float4 r0 = lane < NW ? rec[j & 1][lane][0] : make_float4(0.0f, __uint_as_float(0xFFFFFFFFu), 0.0f, 0.0f);
+            const float4 r1 = lane < NW ? rec[j & 1][lane][1] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // same LDS round trip
             const unsigned vb = __float_as_uint(r0.x);
             unsigned mb = vb;
             asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
@@ -393,10 +423,9 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
                 wl = __builtin_ctzll(__ballot(kk == kmin));
             }
             kwin = (unsigned)__builtin_amdgcn_readlane((int)kk, wl);
-            const float4 r1 = rec[j & 1][wl][1];
-            qx = r1.x;
-            qy = r1.y;
-            qz = r1.z;
+            qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.x), wl));
+            qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.y), wl));
+            qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.z), wl));
         }
         int k = kwin == 0xFFFFFFFFu ? 0 : (TREE ? compat_index(kwin, log2bs) : (int)kwin);
         k = __builtin_amdgcn_readfirstlane(k);
@@ -435,6 +464,9 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             st[6] = (unsigned long long)(m - 1);
             st[7] = cyC1;
             st[8] = cyC2;
+        }
+        atomicAdd(&st[9], st_skip);
+        if (false) {
         }
     }
 }
