@@ -76,14 +76,8 @@ class _SquareDistance3(Function):
 
 
 def square_distance(src, dst):
-    """
-    Calculate squared Euclidean distance between each two points.
-    Input:
-        src: source points, [B, N, C]
-        dst: target points, [B, M, C]
-    Output:
-        dist: per-point square distance, [B, N, M]
-    """
+    """All-pairs squared distances, src (B,N,C) x dst (B,M,C) -> (B,N,M), in the expanded form
+    -2*src.dst + |src|^2 + |dst|^2 of the reference (so values can be slightly negative, as there)."""
     require_cuda(src, dst)
     if src.shape[-1] == 3 and dst.shape[-1] == 3:
         return _SquareDistance3.apply(src, dst)
@@ -125,13 +119,8 @@ class _IndexPoints(Function):
 
 
 def index_points(points, idx):
-    """
-    Input:
-        points: input points data, [B, N, C]
-        idx: sample index data, [B, S] (or [B, S, K])
-    Return:
-        new_points:, indexed points data, [B, S, C] (or [B, S, K, C])
-    """
+    """points (B,N,C) gathered with idx (B,S) or (B,S,K) (int64/int32, per-cloud indices) -> (B,S[,K],C);
+    differentiable w.r.t. points (scatter-add backward)."""
     require_cuda(points, idx)
     if idx.dtype not in (torch.int64, torch.int32):
         idx = idx.long()
@@ -159,14 +148,8 @@ def _fps_dense(xyz, npoint, want_coords=False, cuda_compat=False):
 
 
 def farthest_point_sample(xyz, npoint):
-    """
-    Input:
-        xyz: pointcloud data, [B, N, 3]
-        npoint: number of samples
-    Return:
-        centroids: sampled pointcloud index, [B, npoint]  (int64, local to each cloud; first sample = point 0
-        as in the CUDA kernel the reference calls, pointnet2_utils.py:87-98 / sampling_cuda_kernel.cu:39)
-    """
+    """(B,N,3) -> (B,npoint) int64 indices local to each cloud; the first sample is point 0, as in the kernel the
+    reference calls (pointnet2_utils.py:87-98 / sampling_cuda_kernel.cu:39)."""
     return _fps_dense(xyz, npoint)[0]
 
 
@@ -205,16 +188,9 @@ def _workspace(nbytes, device):
 
 
 def query_ball_point(radius, nsample, xyz, new_xyz):
-    """
-    Input:
-        radius: local region radius
-        nsample: max sample number in local region
-        xyz: all points, [B, N, 3]
-        new_xyz: query points, [B, S, 3]
-    Return:
-        group_idx: grouped points index, [B, S, nsample]  (int64; first nsample hits in index order,
-        padded with the first hit -- pointnet2_utils.py:120-144)
-    """
+    """xyz (B,N,3) cloud, new_xyz (B,S,3) centres -> (B,S,nsample) int64: per centre the first `nsample` point
+    indices, in ascending index order, whose expanded-form squared distance is <= radius**2; short rows repeat
+    their first hit (reference pointnet2_utils.py:120-144, without its (B,S,N) matrix and sort)."""
     require_cuda(xyz, new_xyz)
     nsample = as_int(nsample)
     xyz, new_xyz = _f32c(xyz.detach()), _f32c(new_xyz.detach())
@@ -281,15 +257,9 @@ def group_points(xyz, new_xyz, points, idx, xyz_first=True):
 
 
 def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False):
-    """
-    Input:
-        npoint, radius, nsample
-        xyz: input points position data, [B, N, 3]
-        points: input points data, [B, N, D]
-    Return:
-        new_xyz: sampled points position data, [B, npoint, 3]
-        new_points: sampled points data, [B, npoint, nsample, 3+D]   ([rel_xyz, feat] order, :168)
-    """
+    """FPS -> ball query -> fused grouping.  xyz (B,N,3), points (B,N,D) or None ->
+    new_xyz (B,npoint,3), new_points (B,npoint,nsample,3+D) in [centred xyz, features] order (reference :168);
+    with returnfps also the gathered absolute coordinates and the FPS indices."""
     fps_idx = farthest_point_sample(xyz, npoint)  # [B, npoint]
     new_xyz = index_points(xyz, fps_idx)
     idx = query_ball_point(radius, nsample, xyz, new_xyz)
@@ -301,14 +271,7 @@ def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False):
 
 
 def sample_and_group_all(xyz, points):
-    """
-    Input:
-        xyz: input points position data, [B, N, 3]
-        points: input points data, [B, N, D]
-    Return:
-        new_xyz: sampled points position data, [B, 1, 3]
-        new_points: sampled points data, [B, 1, N, 3+D]
-    """
+    """One group holding the whole cloud: new_xyz (B,1,3) zeros, new_points (B,1,N,3+D) = [xyz, points]."""
     device = xyz.device
     B, N, C = xyz.shape
     new_xyz = torch.zeros(B, 1, C).to(device)
@@ -447,14 +410,8 @@ class PointNetSetAbstraction(nn.Module):
         self.group_all = group_all
 
     def forward(self, xyz, points):
-        """
-        Input:
-            xyz: input points position data, [B, C, N]
-            points: input points data, [B, D, N]
-        Return:
-            new_xyz: sampled points position data, [B, C, S]
-            new_points_concat: sample points feature data, [B, D', S]
-        """
+        """channel-first in, channel-first out: xyz (B,3,N), points (B,D,N) or None ->
+        new_xyz (B,3,S) sampled centres, features (B,D',S)."""
         xyz = xyz.permute(0, 2, 1)
         if points is not None:
             points = points.permute(0, 2, 1)
@@ -502,14 +459,8 @@ class PointNetSetAbstractionMsg(nn.Module):
             self.bn_blocks.append(bns)
 
     def forward(self, xyz, points):
-        """
-        Input:
-            xyz: input points position data, [B, C, N]
-            points: input points data, [B, D, N]
-        Return:
-            new_xyz: sampled points position data, [B, C, S]
-            new_points_concat: sample points feature data, [B, D', S]
-        """
+        """channel-first in, channel-first out: xyz (B,3,N), points (B,D,N) or None ->
+        new_xyz (B,3,S) sampled centres, features (B,D',S)."""
         xyz = xyz.permute(0, 2, 1)
         if points is not None:
             points = points.permute(0, 2, 1)
@@ -558,15 +509,9 @@ class PointNetFeaturePropagation(nn.Module):
             last_channel = out_channel
 
     def forward(self, xyz1, xyz2, points1, points2):
-        """
-        Input:
-            xyz1: input points position data, [B, C, N]
-            xyz2: sampled input points position data, [B, C, S]
-            points1: input points data, [B, D, N]
-            points2: input points data, [B, D, S]
-        Return:
-            new_points: upsampled points data, [B, D', N]
-        """
+        """xyz1 (B,3,N) dense level, xyz2 (B,3,S) coarse level, points1 (B,D1,N) skip features or None,
+        points2 (B,D2,S) coarse features -> (B,D',N): inverse-distance interpolation of points2 onto xyz1,
+        concatenated after points1, then the Conv1d/BN/ReLU stack."""
         xyz1 = xyz1.permute(0, 2, 1)
         xyz2 = xyz2.permute(0, 2, 1)
         points2 = points2.permute(0, 2, 1)
