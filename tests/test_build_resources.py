@@ -1,0 +1,40 @@
+"""CPU: register / scratch budgets the design relies on, read from hipcc's resource-usage remarks (no GPU needed).
+
+bench.py's two-stream schedule only pays off if a wave of the grouping kernel fits beside the FPS level-1 workgroup
+on every SIMD: FPS allocates 2 waves x 240 VGPRs (granule 8) of the 512 per SIMD lane, which leaves 32."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import REPO
+
+CSRC = os.path.join(REPO, "toothgroupnetwork_amd", "csrc")
+
+
+def _usage(src):
+    out = subprocess.run(["python", os.path.join(CSRC, "resource_usage.py"), os.path.join(CSRC, src)],
+                         capture_output=True, text=True, check=True).stdout
+    table = {}
+    for line in out.splitlines():
+        m = re.match(r"(?:void )?(\S.*?)\s+vgpr=\s*(\d+).*scratch=\s*(\d+).*lds=(\d+)", line)
+        if m:
+            table[m.group(1).strip()] = tuple(int(v) for v in m.groups()[1:])
+    return table
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_fps_and_group_kernels_can_share_a_cu():
+    fps = _usage("fps_bucket.hip")
+    vgpr, scratch, lds = fps["tgn::fps_bucket_kernel<512, 48, 0>"]
+    assert scratch == 0, "the 24 000-point FPS kernel must not spill"
+    assert vgpr <= 240, f"FPS level-1 kernel uses {vgpr} VGPRs: no room left for a grouping wave (needs <= 240)"
+    g = _usage("gather.hip")
+    gv, gs, glds = g["tgn::group_points_kernel<int, 1>"]
+    assert gs == 0 and gv <= 32, f"grouping kernel uses {gv} VGPRs (> 32: cannot sit beside the FPS workgroup)"
+    assert lds + glds <= 160 * 1024
+    for name, (v, s, _) in fps.items():
+        if name.endswith(", 0>") and "stream" not in name and "56" not in name:
+            assert s == 0, f"{name} spills"

@@ -52,6 +52,7 @@ def bucket_sweep(batch):
             if nt * p < N or nt * p > 4 * N:
                 continue
             os.environ["TGN_FPS_BUCKET_CONFIG"] = f"{nt},{p}"
+            os.environ["TGN_FPS_BUCKET_MIN"] = "0"
             for B in sorted({1, batch}):
                 ms, idx = time_fps(B, N, S, None)
                 print(f"N={N:6d} S={S:5d} B={B:4d} bucket {nt:4d}x{p:<2d}   {ms:9.3f} ms {1e3 * ms / (S - 1):7.3f} us/iter  "

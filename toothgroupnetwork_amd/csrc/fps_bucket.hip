@@ -739,7 +739,7 @@ int fps_bucket_stream_launch(int mode, int b, int n_max, const FpsArgs &a, hipSt
     return check_launch("fps_bucket_stream_kernel");
 }
 
-#define TGN_FPS_BUCKET_CONFIGS(X) X(256, 8) X(256, 16) X(512, 16) X(512, 24) X(512, 32) X(512, 47) X(512, 48) X(512, 56)
+#define TGN_FPS_BUCKET_CONFIGS(X) X(256, 8) X(256, 16) X(512, 16) X(512, 24) X(512, 32) X(512, 48) X(512, 56)
 
 template <int MODE>
 static int bucket_launch_mode(int b, int n_max, const FpsArgs &a, hipStream_t stream) {
