@@ -13,8 +13,8 @@ import torch  # noqa: E402
 
 from toothgroupnetwork_amd import _lib, synth  # noqa: E402
 
-CONFIGS = [(64, 1), (64, 2), (64, 4), (64, 8), (64, 16), (256, 8), (256, 16), (512, 16), (512, 24), (512, 32),
-           (1024, 24), (512, 48), (512, 56)]
+CONFIGS = [(64, 1), (64, 2), (64, 4), (64, 8), (64, 16), (256, 8), (512, 8), (256, 16),
+           (512, 16), (512, 24), (512, 32), (1024, 24), (512, 48), (512, 56)]
 
 
 def time_fps(B, N, S, cfg, flags=0, reps=3):
@@ -68,10 +68,10 @@ def main():
     if args.bucket:
         return bucket_sweep(args.batch)
     os.environ["TGN_FPS_V1"] = "1"
-    for (N, S) in [(24000, 4096), (4096, 1024), (1024, 256), (6000, 1500), (3072, 768)]:
+    for (N, S) in [(4096, 1024), (1024, 256), (6000, 1500), (3072, 768), (1500, 375)]:
         ref = None
         for cfg in CONFIGS:
-            if cfg[0] * cfg[1] < N or cfg[0] * cfg[1] > 8 * max(N, 64):
+            if cfg[0] * cfg[1] < N or cfg[0] * cfg[1] > 2 * max(N, 64):
                 continue
             for B in sorted({1, args.batch}):
                 ms, idx = time_fps(B, N, S, cfg)

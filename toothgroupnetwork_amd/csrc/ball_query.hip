@@ -323,33 +323,47 @@ __global__ __launch_bounds__(256) void ball_grid_query_kernel(int B, int N, int 
         }
         const float s1 = sumsq3(cx, cy, cz);
         int H = 0;       // entries in the buffer
-        int total_hits = 0;
-        for (int r = 0; r < 9; ++r) {
-            const int s = __builtin_amdgcn_readlane(rs, r), e = __builtin_amdgcn_readlane(re, r);
-            for (int j0 = s; j0 < e; j0 += kWave) {
-                const int j = j0 + lane;
-                bool hit = false;
-                int pidx = 0;
-                if (j < e) {
-                    const float4 p = rec[j];
-                    const float d = sqdist_expanded(cx, cy, cz, s1, p.x, p.y, p.z, sumsq3(p.x, p.y, p.z));
-                    hit = !(d > r2);
-                    pidx = __float_as_int(p.w);
-                }
-                const unsigned long long mask = __ballot(hit);
-                if (mask == 0) continue;
-                const int nh = __popcll(mask);
-                if (H + nh > kHitCap) {
-                    // compact: only the K smallest indices can matter
-                    rank_select<int>(hits, H, K, keep, lane);
-                    const int nk = H < K ? H : K;
-                    for (int i = lane; i < nk; i += kWave) hits[i] = keep[i];
-                    H = nk;
-                }
-                if (hit) hits[H + mbcnt(mask)] = pidx;
-                H += nh;
-                total_hits += nh;
+        // The <= 9 runs are walked as ONE flattened candidate list, 64 candidates per step (a run holds ~15
+        // records on a scan surface: one step per run would leave three quarters of the lanes idle and pay nine
+        // dependent-load latencies instead of ~three).  Lane r < 9 holds run r's [rs, re); pre[r] = records before it.
+        const int len = re - rs;
+        int pre = len;  // inclusive scan over lanes 0..15 (one DPP row), then made exclusive
+        pre += (int)dpp_or_zero<0x111, 0xF>((unsigned)pre);
+        pre += (int)dpp_or_zero<0x112, 0xF>((unsigned)pre);
+        pre += (int)dpp_or_zero<0x114, 0xF>((unsigned)pre);
+        pre += (int)dpp_or_zero<0x118, 0xF>((unsigned)pre);
+        const int T = __builtin_amdgcn_readlane(pre, 8);  // lanes 9.. have len 0
+        pre -= len;
+        const int delta = rs - pre;  // record index = flattened index + delta of its run
+        int ends[9];                 // wave-uniform run ends in the flattened list
+#pragma unroll
+        for (int r = 0; r < 9; ++r) ends[r] = __builtin_amdgcn_readlane(pre + len, r);
+        for (int g0 = 0; g0 < T; g0 += kWave) {
+            const int g = g0 + lane;
+            int r = 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) r += (g >= ends[t]) ? 1 : 0;
+            const int j = g + __shfl(delta, r);
+            bool hit = false;
+            int pidx = 0;
+            if (g < T) {
+                const float4 p = rec[j];
+                const float d = sqdist_expanded(cx, cy, cz, s1, p.x, p.y, p.z, sumsq3(p.x, p.y, p.z));
+                hit = !(d > r2);
+                pidx = __float_as_int(p.w);
             }
+            const unsigned long long mask = __ballot(hit);
+            if (mask == 0) continue;
+            const int nh = __popcll(mask);
+            if (H + nh > kHitCap) {
+                // compact: only the K smallest indices can matter
+                rank_select<int>(hits, H, K, keep, lane);
+                const int nk = H < K ? H : K;
+                for (int i = lane; i < nk; i += kWave) hits[i] = keep[i];
+                H = nk;
+            }
+            if (hit) hits[H + mbcnt(mask)] = pidx;
+            H += nh;
         }
         if (H == 0) {
             for (int j = lane; j < K; j += kWave) row[j] = (IdxT)N;  // no hit at all -> N (:136-141)
@@ -364,7 +378,6 @@ __global__ __launch_bounds__(256) void ball_grid_query_kernel(int B, int N, int 
             for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
             for (int j = H + lane; j < K; j += kWave) row[j] = (IdxT)mn;
         }
-        (void)total_hits;
     }
 }
 

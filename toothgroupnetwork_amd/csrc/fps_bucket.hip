@@ -37,41 +37,6 @@
 
 namespace tgn {
 
-// 64-lane max / min of an fp32 value; wave-uniform result.  Written as six v_max_f32_dpp / v_min_f32_dpp
-// (row_shr 1,2,4,8 then row_bcast 15,31): lanes without a DPP source are write-disabled and keep their value.
-// hipcc expands the same reduction from builtins into 5 instructions per step (identity mov, dpp mov, two
-// canonicalising v_max, v_max), a ~350-cycle dependent chain; this is ~60.  The s_nop 1 before each step is
-// the VALU-write -> DPP-read hazard (2 wait states) that the assembler does not insert inside asm blocks.
-#define TGN_DPP_REDUCE(OP)                                                                \
-    asm volatile("s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"   \
-                 "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"   \
-                 "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"   \
-                 "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"   \
-                 "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
-                 "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
-                 "s_nop 1"                                                                    \
-                 : "+v"(v))
-__device__ __forceinline__ float wave_max_f32_dpp(float v) {
-    TGN_DPP_REDUCE("v_max_f32_dpp");
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-__device__ __forceinline__ float wave_min_f32_dpp(float v) {
-    TGN_DPP_REDUCE("v_min_f32_dpp");
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-__device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v) {
-    TGN_DPP_REDUCE("v_min_u32_dpp");
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-__device__ __forceinline__ unsigned wave_min_u32_shfl(unsigned v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned t = (unsigned)__shfl_xor((int)v, o);
-        v = t < v ? t : v;
-    }
-    return v;
-}
-
 // deposit a wave-uniform value into one lane of a per-lane register (the metadata lane of a bucket)
 __device__ __forceinline__ float writelane_f32(float old, float val_uniform, int lane) {
     return lane_id() == lane ? val_uniform : old;

@@ -80,6 +80,83 @@ __device__ __forceinline__ unsigned long long fps_block_max(unsigned long long p
     }
 }
 
+// ---- wave reductions written as v_*_dpp instructions (shared by all FPS kernels) ------------------------------
+// 64-lane max / min of an fp32 value; wave-uniform result.  Written as six v_max_f32_dpp / v_min_f32_dpp
+// (row_shr 1,2,4,8 then row_bcast 15,31): lanes without a DPP source are write-disabled and keep their value.
+// hipcc expands the same reduction from builtins into 5 instructions per step (identity mov, dpp mov, two
+// canonicalising v_max, v_max), a ~350-cycle dependent chain; this is ~60.  The s_nop 1 before each step is
+// the VALU-write -> DPP-read hazard (2 wait states) that the assembler does not insert inside asm blocks.
+#define TGN_DPP_REDUCE(OP)                                                                \
+    asm volatile("s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"   \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"   \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"   \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"   \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+                 "s_nop 1"                                                                    \
+                 : "+v"(v))
+__device__ __forceinline__ float wave_max_f32_dpp(float v) {
+    TGN_DPP_REDUCE("v_max_f32_dpp");
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_min_f32_dpp(float v) {
+    TGN_DPP_REDUCE("v_min_f32_dpp");
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v) {
+    TGN_DPP_REDUCE("v_min_u32_dpp");
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_min_u32_shfl(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+
+// Block-wide argmax of (value, tie key): value = max (values >= 0, or -1 for "none"), smallest tie key among equal
+// values.  One LDS slot per wave, one barrier.  Returns the winning tie key (0xFFFFFFFF if no lane had a value).
+// The common case (a single lane / a single wave holds the maximum) costs one 6-instruction DPP max, a ballot and a
+// readlane per level; exact ties fall back to a key minimum.
+template <int NW>
+__device__ __forceinline__ unsigned fps_block_argmax(float best, unsigned key, unsigned long long (*slots)[NW],
+                                                     int parity, int wave, int lane) {
+    const float wm = wave_max_f32_dpp(best);
+    const bool mine = best == wm && wm >= 0.0f;
+    const unsigned long long eq = __ballot(mine);
+    unsigned wkey = 0xFFFFFFFFu;
+    if (eq) {
+        if (__popcll(eq) == 1)
+            wkey = (unsigned)__builtin_amdgcn_readlane((int)key, __builtin_ctzll(eq));
+        else
+            wkey = wave_min_u32_dpp(mine ? key : 0xFFFFFFFFu);
+    }
+    if constexpr (NW == 1) {
+        return wkey;
+    } else {
+        // distances are >= 0: their bit patterns order like unsigned integers
+        if (lane == 0) slots[parity][wave] = pack64(wm < 0.0f ? 0u : __float_as_uint(wm), wkey);
+        __syncthreads();
+        const unsigned long long v = lane < NW ? slots[parity][lane] : pack64(0u, 0xFFFFFFFFu);
+        const unsigned vb = (unsigned)(v >> 32), vk = (unsigned)v;
+        unsigned mb = vb;
+        asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                     : "+v"(mb));
+        mb = (unsigned)__builtin_amdgcn_readlane((int)mb, 15);
+        const bool wc = lane < NW && vb == mb;
+        const unsigned kk = wc ? vk : 0xFFFFFFFFu;
+        const unsigned long long wmask = __ballot(wc);
+        if (__popcll(wmask) == 1) return (unsigned)__builtin_amdgcn_readlane((int)kk, __builtin_ctzll(wmask));
+        return wave_min_u32_dpp(kk);
+    }
+}
+
 // fps_bucket.hip: launches the bucket-skipping kernel when a shape covers n_max; returns -1 if none does.
 int fps_bucket_launch(int mode, int b, int n_max, const FpsArgs &a, hipStream_t stream);
 // large clouds through a cell-sorted workspace; -1 if the workspace is missing / too small / cloud too large
