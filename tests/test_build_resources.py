@@ -28,7 +28,7 @@ def _usage(src):
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
 def test_fps_and_group_kernels_can_share_a_cu():
     fps = _usage("fps_bucket.hip")
-    vgpr, scratch, lds = fps["tgn::fps_bucket_kernel<512, 48, 0>"]
+    vgpr, scratch, lds = fps["tgn::fps_bucket_kernel<512, 48, 0, false>"]
     assert scratch == 0, "the 24 000-point FPS kernel must not spill"
     assert vgpr <= 240, f"FPS level-1 kernel uses {vgpr} VGPRs: no room left for a grouping wave (needs <= 240)"
     g = _usage("gather.hip")
@@ -36,5 +36,5 @@ def test_fps_and_group_kernels_can_share_a_cu():
     assert gs == 0 and gv <= 32, f"grouping kernel uses {gv} VGPRs (> 32: cannot sit beside the FPS workgroup)"
     assert lds + glds <= 160 * 1024
     for name, (v, s, _) in fps.items():
-        if name.endswith(", 0>") and "stream" not in name and "56" not in name:
+        if name.endswith(", 0, false>") and "56" not in name:
             assert s == 0, f"{name} spills"

@@ -83,7 +83,7 @@ constexpr int next_pow2(int v) {
     return p;
 }
 
-template <int NT, int P, int MODE>
+template <int NT, int P, int MODE, bool DBG = false>
 __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
     constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0;
     constexpr int NW = NT / kWave;
@@ -250,10 +250,12 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
     // cached wave candidate (wave-uniform): value, tie key, coordinates
     float wm = -1.0f, wx = 0.0f, wy = 0.0f, wz = 0.0f;
     unsigned wkey = 0;
-    bool dirty = true;
+    int wslot = -1;     // slot of the bucket that currently is this wave's candidate
+    bool dirty = true;  // bucket maxima only shrink: the candidate changes only when ITS bucket's arg-max changes
 
     // optional instrumentation (flag 0x100 + tmp): touched-bucket census and per-phase cycles of one wave
-    const bool dbg = (a.flags & 0x100) && a.tmp;
+    // compile-time switch: even never-taken `if (dbg)` branches cost a lone wave ~10 cycles each per iteration
+    constexpr bool dbg = DBG;
     unsigned long long st_skip = 0, st_touched = 0, st_waves = 0, cyA = 0, cyU = 0, cyB = 0, cyC = 0, cyC1 = 0, cyC2 = 0;
 
     for (int j = 1; j < m; ++j) {
@@ -272,7 +274,6 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             st_waves += mask ? 1 : 0;
         }
         if (mask) {  // wave-uniform
-            dirty = true;
             // A lone wave issues roughly one instruction per 5 cycles whatever its kind, so the mask is walked
             // hierarchically (groups of 8 slots, 32-bit tests: 2 scalar instructions per test) rather than bit by bit.
             const unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
                             const bool unchanged = TGN_REFRESH_SKIP && na == bold;  // wave-uniform
                             if (dbg && unchanged) ++st_skip;
                             if (!unchanged) {
+                            if (s == wslot) dirty = true;
                             const float mx = wave_max_f32_dpp(nd);
                             const unsigned long long eq = __ballot(nd == mx);
                             bool win = nd == mx;
@@ -342,6 +344,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
                 sl = __builtin_ctzll(__ballot(kl == kmin));
             }
             wkey = (unsigned)__builtin_amdgcn_readlane((int)kl, sl);
+            wslot = sl;
             wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pm.x), sl));
             wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pm.y), sl));
             wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pm.z), sl));
@@ -722,6 +725,12 @@ static int bucket_launch_mode(int b, int n_max, const FpsArgs &a, hipStream_t st
     }
         TGN_FPS_BUCKET_CONFIGS(X)
 #undef X
+    }
+    if constexpr (MODE == 0) {
+        if ((a.flags & 0x100) && a.tmp && nt == 512 && p == 48) {  // instrumented build (tools/fps_stats.py)
+            hipLaunchKernelGGL((fps_bucket_kernel<512, 48, 0, true>), dim3(b), dim3(512), 0, stream, a);
+            return check_launch("fps_bucket_kernel<dbg>");
+        }
     }
 #define X(NT_, P_)                                                                                   \
     if (nt == NT_ && p == P_) {                                                                      \
