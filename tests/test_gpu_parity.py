@@ -264,6 +264,31 @@ def test_group_points_orders_and_index_points(dev, oracle):
     assert np.array_equal(got.cpu().numpy(), oracle.index_points(pts, idx))
 
 
+@pytest.mark.parametrize("D,K", [(64, 32), (128, 32), (131, 7), (200, 33), (256, 64), (512, 32), (320, 128), (66, 1)])
+def test_group_points_wide_rows(dev, oracle, D, K):
+    """D >= 64 takes the row kernel (buffer loads/stores of 1, 2 or 4 floats per lane): every width, K not a multiple
+    of the rows in flight, K > 64 (second index register), both channel orders, both index types, a bad index."""
+    from toothgroupnetwork_amd import _lib, pointnet2_utils as U
+    rng = np.random.default_rng(D * 1000 + K)
+    B, N, S = 2, 300, 37
+    xyz = rng.normal(size=(B, N, 3)).astype(np.float32)
+    pts = rng.normal(size=(B, N, D)).astype(np.float32)
+    new_xyz = xyz[:, :S].copy()
+    idx = rng.integers(0, N, size=(B, S, K))
+    for xyz_first in (True, False):
+        want = oracle.group_points(xyz, new_xyz, pts, idx, xyz_first)
+        for dt in (np.int64, np.int32):
+            got = U.group_points(T(xyz, dev), T(new_xyz, dev), T(pts, dev), T(idx.astype(dt), dev), xyz_first=xyz_first)
+            assert np.array_equal(got.cpu().numpy(), want)
+    assert _lib.lib().tgn_take_index_error(_lib.stream()) == 0
+    bad = idx.copy()
+    bad[1, 5, K // 2] = N                              # the empty-ball marker: row filled from point 0, error word set
+    got = U.group_points(T(xyz, dev), T(new_xyz, dev), T(pts, dev), T(bad, dev))
+    assert _lib.lib().tgn_take_index_error(_lib.stream()) == 1
+    bad[1, 5, K // 2] = 0
+    assert np.array_equal(got.cpu().numpy(), oracle.group_points(xyz, new_xyz, pts, bad, True))
+
+
 def test_group_points_empty_ball_is_reported(dev):
     from toothgroupnetwork_amd import _lib, pointnet2_utils as U
     xyz = T(synth.uniform_cloud(64, 1)[None], dev)

@@ -246,9 +246,13 @@ __global__ __launch_bounds__(256) void group_points_kernel(long long queries, in
                 if (e < total) *(float4 *)(dst + e) = *(const float4 *)&stage[wv][lane * 4];
             }
         } else {
-            // lane-contiguous gathers AND stores (256 contiguous bytes per wave-instruction).  Not unrolled on
-            // purpose: at 26 VGPRs a wave of this kernel fits beside the FPS workgroup that owns 94 % of a CU's
-            // registers (bench.py --pipeline), and unrolling by 2 measured no faster on an empty chip.
+            // lane-contiguous gathers AND stores (256 contiguous, 128-B aligned bytes per wave-instruction).
+            // What bounds it (tools/store_bench.hip, tools/gpu_pmc_group.sh; profiles/r01_store_bench.txt): not the
+            // (k, c) arithmetic and not loads in flight (unrolling x2..x8, or a wave-uniform row loop with scalar row
+            // bases and 16-B buffer loads/stores, measured the same or slower) but L2 read misses under the streaming
+            // store: 36 % of the gather requests miss a 4 MB L2 that 17 MB of output per scan flow through, while a
+            // source that stays L2/MALL resident lets the identical loop run at 5 TB/s.  At 26 VGPRs a wave of this
+            // kernel fits beside the FPS workgroup that owns 94 % of a CU's registers (bench.py --pipeline).
 #pragma unroll 1
             for (int e = lane; e < total; e += kWave) {
                 const unsigned k = __umulhi((unsigned)e, magicC);
