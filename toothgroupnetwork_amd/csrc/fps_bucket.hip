@@ -202,11 +202,10 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
         d[s] = valid ? 1e10f : -1.0f;  // pointops.py:22 ; padding never wins (real distances are >= 0)
     }
     // ---- 6. bucket metadata.  Lane s of a wave keeps bucket s's box and largest min-distance in VGPRs (read
-    //         every iteration); the arg-max point of the bucket (its coordinates and lane) sits in LDS, written
+    //         every iteration); the arg-max point of the bucket (its coordinates and tie key) sits in LDS, written
     //         by the winning lane itself with one 16-B store and read only when the wave's candidate changes. ----
     float blo0 = INFINITY, blo1 = INFINITY, blo2 = INFINITY, bhi0 = -INFINITY, bhi1 = -INFINITY, bhi2 = -INFINITY;
     float bmax = -1.0f;
-    int blane = 0;  // lane of the bucket's arg-max point (refreshed together with bmax)
 #pragma unroll
     for (int s = 0; s < P; ++s) {
         const bool valid = d[s] >= 0.0f;
@@ -231,10 +230,8 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             bmeta[0][wave][s] = x[s];
             bmeta[1][wave][s] = y[s];
             bmeta[2][wave][s] = z[s];
-            bmeta[3][wave][s] = __int_as_float(lane);
+            bmeta[3][wave][s] = __uint_as_float(kl);
         }
-        const unsigned long long wm0 = __ballot(win);
-        blane = lane == s ? (wm0 ? (int)__builtin_ctzll(wm0) : 0) : blane;
     }
 
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
@@ -287,36 +284,38 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
                         if (s < P && (mg & (1u << u))) {  // wave-uniform
                             const float dx = x[s] - qx, dy = y[s] - qy, dz = z[s] - qz;
                             const float dd = FMA ? dist_direct_fma(dx, dy, dz) : dist_direct_nofma(dx, dy, dz);
+                            // Distances only shrink: unless a point that HELD the bucket's maximum gets closer, the
+                            // bucket's maximum and arg-max are unchanged and the 64-lane refresh is skipped.
+                            const float bold = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bmax), s));
+                            const bool unchanged = TGN_REFRESH_SKIP && __ballot(d[s] == bold && dd < d[s]) == 0;  // wave-uniform
                             const float nd = vmin_f32(dd, d[s]);  // min(d, tmp[k]) sampling_cuda_kernel.cu:55
                             d[s] = nd;
-                            // Distances only shrink: if the bucket's arg-max point kept its value, the bucket's
-                            // maximum and arg-max are unchanged and the 64-lane refresh is skipped.
-                            const float bold = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bmax), s));
-                            const int alane = __builtin_amdgcn_readlane(blane, s);
-                            const float na = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nd), alane));
-                            const bool unchanged = TGN_REFRESH_SKIP && na == bold;  // wave-uniform
                             if (dbg && unchanged) ++st_skip;
                             if (!unchanged) {
+                            // the lane's tie key (original index), wanted by the winner only: issued first so that the
+                            // LDS round trip hides behind the reduction
+                            const unsigned o = tab[(s * NW + wave) * kWave + lane];
                             if (s == wslot) dirty = true;
                             const float mx = wave_max_f32_dpp(nd);
                             const unsigned long long eq = __ballot(nd == mx);
                             bool win = nd == mx;
+                            const unsigned ko = TREE ? compat_key((int)o, log2bs) : o;
                             if (__popcll(eq) != 1) {  // exact tie inside the bucket (rare): the smallest tie key wins
-                                const unsigned o = tab[(s * NW + wave) * kWave + lane];
-                                const unsigned kl = win ? (TREE ? compat_key((int)o, log2bs) : o) : 0xFFFFFFFFu;
+                                const unsigned kl = win ? ko : 0xFFFFFFFFu;
                                 const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kl));
                                 win = win && kl == kmin;
                             }
-                            if (win) {  // four 4-B stores into separate planes: one 16-B store would pin (x,y,z,lane)
+                            if (win) {  // four 4-B stores into separate planes: one 16-B store would pin (x,y,z,key)
                                         // of every slot to an aligned register quadruple and double the footprint
                                 bmeta[0][wave][s] = x[s];
                                 bmeta[1][wave][s] = y[s];
                                 bmeta[2][wave][s] = z[s];
-                                bmeta[3][wave][s] = __int_as_float(lane);
+                                bmeta[3][wave][s] = __uint_as_float(ko);
                             }
-                            const int wlane = (int)__builtin_ctzll(__ballot(win));  // (ballot OUTSIDE the per-lane select)
-                            bmax = lane == s ? mx : bmax;
-                            blane = lane == s ? wlane : blane;
+                            {  // bmax[lane s] = mx: one v_writelane (a select would keep 48 hoisted lane masks alive in SGPRs)
+                                const int mxs = __builtin_amdgcn_readfirstlane(__float_as_int(mx));
+                                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(bmax) : "s"(mxs), "i"(s));
+                            }
                             }
                         }
                     }
@@ -329,13 +328,12 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             const float v = lane < P ? bmax : -1.0f;
             wm = wave_max_f32_dpp(v);
             const bool cand = lane < P && v == wm && wm >= 0.0f;
-            // tie key of each candidate bucket's arg-max point (two dependent LDS reads; usually a single lane)
+            // coordinates and tie key of each candidate bucket's arg-max point (one LDS round trip; usually a single lane)
             unsigned kl = 0xFFFFFFFFu;
             float4 pm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (cand) {
                 pm = make_float4(bmeta[0][wave][lane], bmeta[1][wave][lane], bmeta[2][wave][lane], bmeta[3][wave][lane]);
-                const unsigned o = tab[(lane * NW + wave) * kWave + __float_as_int(pm.w)];
-                kl = TREE ? compat_key((int)o, log2bs) : o;
+                kl = __float_as_uint(pm.w);
             }
             const unsigned long long cm = __ballot(cand);
             int sl = cm ? __builtin_ctzll(cm) : 0;
@@ -372,16 +370,19 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
                 cyC2 += tc2 - tc1;
             }
             // distances are >= 0: their bit patterns order like unsigned integers
-            const float4 r0 = lane < NW ? rec[j & 1][lane][0] : make_float4(0.0f, __uint_as_float(0xFFFFFFFFu), 0.0f, 0.0f);
-            const float4 r1 = lane < NW ? rec[j & 1][lane][1] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // same LDS round trip
+            // every lane reads record lane % NW (no exec juggling); lanes 0..NW-1 are the ones that count
+            const float4 r0 = rec[j & 1][lane & (NW - 1)][0];
+            const float4 r1 = rec[j & 1][lane & (NW - 1)][1];  // same LDS round trip
             const unsigned vb = __float_as_uint(r0.x);
             unsigned mb = vb;
+            // max over lanes 0..NW-1 lands in lane NW-1 after log2(NW) row_shr steps
             asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
                          : "+v"(mb));
-            mb = (unsigned)__builtin_amdgcn_readlane((int)mb, 15);
+            if constexpr (NW > 4) asm volatile("v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(mb));
+            if constexpr (NW > 8) asm volatile("v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(mb));
+            static_assert(NW == 4 || NW == 8 || NW == 16, "wave count");
+            mb = (unsigned)__builtin_amdgcn_readlane((int)mb, NW - 1);
             const bool wc = lane < NW && vb == mb;
             const unsigned kk = wc ? __float_as_uint(r0.y) : 0xFFFFFFFFu;
             const unsigned long long wmask = __ballot(wc);
