@@ -29,7 +29,6 @@
 
 #include <stdlib.h>
 
-#include <type_traits>
 
 #ifndef TGN_REFRESH_SKIP
 #define TGN_REFRESH_SKIP 1
@@ -41,38 +40,6 @@ namespace tgn {
 __device__ __forceinline__ float writelane_f32(float old, float val_uniform, int lane) {
     return lane_id() == lane ? val_uniform : old;
 }
-__device__ __forceinline__ unsigned writelane_u32(unsigned old, unsigned val_uniform, int lane) {
-    return lane_id() == lane ? val_uniform : old;
-}
-// one v_writelane_b32 (the value must be wave-uniform, the lane a compile-time constant)
-template <int LANE>
-__device__ __forceinline__ void vwritelane(float &reg, float val_uniform) {
-    const int sv = __builtin_amdgcn_readfirstlane(__float_as_int(val_uniform));
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(reg) : "s"(sv), "n"(LANE));
-}
-template <int LANE>
-__device__ __forceinline__ void vwritelane(unsigned &reg, unsigned val_uniform) {
-    const int sv = __builtin_amdgcn_readfirstlane((int)val_uniform);
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(reg) : "s"(sv), "n"(LANE));
-}
-
-// Binary tree of wave-uniform branches mapping a runtime slot number to a compile-time constant, so that the
-// per-lane point arrays stay statically indexed (registers).  log2(P) scalar compare+branch pairs per call;
-// a lone wave issues roughly one instruction per 5 cycles whatever its kind, so the 4*P-instruction
-// "test every mask bit" chain this replaces cost more than the bucket updates themselves.
-template <int LO, int HI, typename F>
-__device__ __forceinline__ void static_dispatch(int s, F &&f) {
-    if constexpr (HI - LO == 1) {
-        f(std::integral_constant<int, LO>{});
-    } else {
-        constexpr int MID = (LO + HI) / 2;
-        if (s < MID)
-            static_dispatch<LO, MID>(s, f);
-        else
-            static_dispatch<MID, HI>(s, f);
-    }
-}
-
 __device__ __forceinline__ unsigned spread5(unsigned v) {  // abcde -> a00b00c00d00e
     return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6) | ((v & 16u) << 8);
 }
