@@ -1,0 +1,93 @@
+"""Seeded random sweeps of the sampling / neighbour-search kernels against the oracle: ragged packed batches with empty,
+one-point and over-sampled segments, coordinates quantised so that exact distance ties are common, every launch shape
+the dispatcher can pick for the drawn sizes.  Sizes stay small enough for the C oracle to finish in seconds."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _cloud(rng, n, style):
+    if style == 0:      # uniform
+        return rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    if style == 1:      # quantised: many exact ties and duplicates
+        return (rng.integers(-6, 7, size=(n, 3)) / 8.0).astype(np.float32)
+    if style == 2:      # thin sheet with clusters (ball queries see crowded and empty neighbourhoods)
+        c = rng.uniform(-1, 1, size=(max(n // 40, 1), 3))
+        p = c[rng.integers(0, len(c), n)] + rng.normal(scale=0.03, size=(n, 3))
+        p[:, 2] *= 0.05
+        return p.astype(np.float32)
+    return np.full((n, 3), 0.25, np.float32)  # all points identical
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fps_random_ragged_batches(dev, oracle, seed):
+    from toothgroupnetwork_amd import pointops as P
+    rng = np.random.default_rng(1000 + seed)
+    b = int(rng.integers(1, 7))
+    sizes = [int(rng.choice([0, 1, 2, 63, 64, 65, 500, 1500, 5000, 9000, 12000])) for _ in range(b)]
+    if seed % 4 == 0:
+        sizes[0] = int(rng.integers(8192, 20000))     # bucket-skipping kernel territory
+    ms = [int(min(max(rng.integers(0, 3) * n // 4 + rng.integers(0, 3), 0), 3000)) if n else 0 for n in sizes]
+    ms = [m if n else 0 for m, n in zip(ms, sizes)]
+    xyz = np.concatenate([_cloud(rng, n, int(rng.integers(0, 4))) for n in sizes] + [np.zeros((0, 3), np.float32)])
+    off = np.cumsum(sizes).astype(np.int32)
+    noff = np.cumsum(ms).astype(np.int32)
+    got = P.furthestsampling(T(xyz, dev), T(off, dev), T(noff, dev)).cpu().numpy()
+    assert got.dtype == np.int32 and got.shape == (int(noff[-1]),)
+    assert np.array_equal(got, oracle.furthestsampling(xyz, off, noff)), (sizes, ms)
+    got_cc, _ = P.fps_with_coords(T(xyz, dev), T(off, dev), T(noff, dev), cuda_compat=True)
+    assert np.array_equal(got_cc.cpu().numpy(), oracle.furthestsampling(xyz, off, noff, mode=3)), (sizes, ms)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_ball_query_random(dev, oracle, seed):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    rng = np.random.default_rng(2000 + seed)
+    B = int(rng.integers(1, 4))
+    N = int(rng.choice([1, 7, 64, 300, 2047, 2048, 4096, 6000]))
+    S = int(rng.choice([1, 5, 64, 257, 700]))
+    K = int(rng.choice([1, 3, 16, 32, 64, 100]))
+    style = int(rng.integers(0, 4))
+    xyz = np.stack([_cloud(rng, N, style) for _ in range(B)])
+    q = np.stack([np.concatenate([xyz[b][rng.integers(0, N, S // 2 + 1)], _cloud(rng, S, 0)])[:S] for b in range(B)])
+    for radius in (float(rng.choice([0.0, 0.05, 0.125, 0.25, 0.5])), float(rng.uniform(0.01, 1.5)), 10.0):
+        got = U.query_ball_point(radius, K, T(xyz, dev), T(q, dev)).cpu().numpy()
+        assert np.array_equal(got, oracle.query_ball_point(radius, K, xyz, q)), (B, N, S, K, style, radius)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_knn_random_ragged(dev, oracle, seed):
+    from toothgroupnetwork_amd import pointops as P
+    P.knn_cache_clear()
+    rng = np.random.default_rng(3000 + seed)
+    b = int(rng.integers(1, 5))
+    sizes = [int(rng.choice([1, 2, 17, 64, 200, 1000, 3000])) for _ in range(b)]
+    qs = [int(rng.choice([1, 3, 64, 300])) for _ in range(b)]
+    k = int(rng.choice([1, 3, 8, 16, 36, 64]))
+    style = int(rng.integers(0, 3))
+    xyz = np.concatenate([_cloud(rng, n, style) for n in sizes])
+    q = np.concatenate([_cloud(rng, m, style) for m in qs])
+    off, noff = np.cumsum(sizes).astype(np.int32), np.cumsum(qs).astype(np.int32)
+    idx, dist = P.knnquery(k, T(xyz, dev), T(q, dev), T(off, dev), T(noff, dev))
+    oi, od = oracle.knnquery(k, xyz, q, off, noff)
+    assert np.array_equal(idx.cpu().numpy(), oi), (sizes, qs, k, style)   # exact ties: the heap's order
+    assert np.array_equal(dist.cpu().numpy(), od)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_three_nn_random(dev, oracle, seed):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    rng = np.random.default_rng(4000 + seed)
+    B, N, S = int(rng.integers(1, 3)), int(rng.choice([5, 100, 1500])), int(rng.choice([3, 4, 64, 500]))
+    xyz1 = np.stack([_cloud(rng, N, int(rng.integers(0, 3))) for _ in range(B)])
+    xyz2 = np.stack([_cloud(rng, S, int(rng.integers(0, 3))) for _ in range(B)])
+    d, i = U.three_nn(T(xyz1, dev), T(xyz2, dev))
+    od, oi = oracle.three_nn(xyz1, xyz2)
+    assert np.array_equal(d.cpu().numpy(), od)
+    assert np.array_equal(i.cpu().numpy(), oi)

@@ -139,6 +139,8 @@ def _fps_dense(xyz, npoint, want_coords=False, cuda_compat=False):
     B, N, _ = xyz.shape
     idx = torch.empty(B, npoint, dtype=torch.int64, device=xyz.device)
     new_xyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=xyz.device) if want_coords else None
+    if B == 0 or npoint == 0:
+        return idx, new_xyz
     from .pointops import fps_workspace
     ws, nbytes = fps_workspace(B, N, B * N, xyz.device)
     flags = _lib.FPS_LOCAL_INDEX | _lib.FPS_INDEX64 | (_lib.FPS_CUDA_COMPAT if cuda_compat else 0)

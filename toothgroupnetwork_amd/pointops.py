@@ -59,7 +59,7 @@ def fps_with_coords(xyz, offset, new_offset, cuda_compat=False):
     both = _offsets_host(torch.cat([offset.reshape(-1), new_offset.reshape(-1)]))  # one device->host copy
     off_h, noff_h = both[:offset.numel()], both[offset.numel():]
     b = offset.shape[0]
-    if b == 0:
+    if b == 0 or noff_h[-1] == 0:      # nothing to sample (no segments, or only empty ones): an empty result, no launch
         return (torch.zeros(0, dtype=torch.int32, device=xyz.device),
                 torch.zeros(0, 3, dtype=torch.float32, device=xyz.device))
     n_max = _max_segment(off_h)
