@@ -91,3 +91,45 @@ def test_three_nn_random(dev, oracle, seed):
     od, oi = oracle.three_nn(xyz1, xyz2)
     assert np.array_equal(d.cpu().numpy(), od)
     assert np.array_equal(i.cpu().numpy(), oi)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_gather_family_random_shapes(dev, oracle, seed):
+    """grouping / subtraction / aggregation / interpolation2 forward and backward at odd channel counts, one-neighbour
+    and wide-neighbour cases (the kernels tile rows x channel lanes: partial tiles everywhere)."""
+    from toothgroupnetwork_amd import pointops as P
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([1, 2, 33, 250, 1031]))
+    m = int(rng.choice([1, 7, 64, 300]))
+    ns = int(rng.choice([1, 2, 3, 8, 17, 36]))
+    wc = int(rng.choice([1, 2, 4, 8]))
+    c = wc * int(rng.choice([1, 3, 5, 16, 33]))
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(dev)
+    npy = lambda t: t.detach().cpu().numpy()
+    # grouping: (n, c) rows gathered by (m, ns)
+    feat = f(n, c).requires_grad_()
+    idx = torch.from_numpy(rng.integers(0, n, (m, ns)).astype(np.int32)).to(dev)
+    out = P.grouping(feat, idx)
+    assert np.array_equal(npy(out), oracle.grouping_forward(npy(feat), npy(idx)))
+    go = f(m, ns, c)
+    out.backward(go)
+    np.testing.assert_allclose(npy(feat.grad), oracle.grouping_backward(npy(go), npy(idx), n), atol=2e-5, rtol=1e-5)
+    # subtraction / aggregation: idx is (n, ns) over the same n rows
+    idx2 = torch.from_numpy(rng.integers(0, n, (n, ns)).astype(np.int32)).to(dev)
+    a, b = f(n, c).requires_grad_(), f(n, c).requires_grad_()
+    out = P.subtraction(a, b, idx2)
+    assert np.array_equal(npy(out), oracle.subtraction_forward(npy(a), npy(b), npy(idx2)))
+    go = f(n, ns, c)
+    out.backward(go)
+    g1, g2 = oracle.subtraction_backward(npy(idx2), npy(go))
+    np.testing.assert_allclose(npy(a.grad), g1, atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(npy(b.grad), g2, atol=2e-5, rtol=1e-5)
+    x, pos, w = f(n, c).requires_grad_(), f(n, ns, c).requires_grad_(), f(n, ns, wc).requires_grad_()
+    out = P.aggregation(x, pos, w, idx2)
+    np.testing.assert_allclose(npy(out), oracle.aggregation_forward(npy(x), npy(pos), npy(w), npy(idx2)), atol=2e-5, rtol=1e-5)
+    go = f(n, c)
+    out.backward(go)
+    gi, gp, gw = oracle.aggregation_backward(npy(x), npy(pos), npy(w), npy(idx2), npy(go))
+    np.testing.assert_allclose(npy(x.grad), gi, atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(npy(pos.grad), gp, atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(npy(w.grad), gw, atol=1e-4, rtol=1e-4)
