@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--pipeline", type=int, default=1, help="1: overlap the FPS chain of step k+1 with ball query / "
                     "grouping of step k on two HIP streams (double-buffered); 0: one stream")
+    ap.add_argument("--fps-prefix", type=int, default=0, help="1: levels 2 and 3 use the FPS-of-an-FPS-result identity "
+                    "(exact, certificate checked on the device) instead of iterating; reported separately, never the headline")
     args = ap.parse_args()
 
     rank, local_rank, world, device = sharding.init_from_env()
@@ -95,7 +97,7 @@ def main():
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     B = args.batch
     xyz, feats, scans = make_inputs(B, device, seed=100 + rank)
-    hp = hotpath.HotPath(B, device, pipeline=bool(args.pipeline))
+    hp = hotpath.HotPath(B, device, pipeline=bool(args.pipeline), fps_prefix=bool(args.fps_prefix))
     for _ in range(max(args.warmup, 0)):
         hp.run(xyz, feats, inputs_on_current_stream=False)   # the synthetic scans are resident before any step
     torch.cuda.synchronize()
@@ -133,6 +135,8 @@ def main():
                                "D=[6,128,512]; FPS+ball_query+group forward, grouped tensors materialised",
                    "meshes_per_step_per_gpu": B, "sharding": f"independent meshes x {world} ranks, no data-path collective",
                    "index_dtype": "int32",
+                   "fps_levels_2_3": "identity shortcut (FPS of an FPS result; certificate checked on device)"
+                   if args.fps_prefix else "iterated like level 1",
                    "schedule": "2 HIP streams, steps software-pipelined (FPS of step k+1 over ball query + group of step k)"
                    if args.pipeline else "1 stream"},
         "path_hbm": {"algorithmic_bytes_per_mesh": bytes_per_mesh,

@@ -106,6 +106,25 @@ int tgn_furthestsampling_ws(int b, int n_max, const float *xyz, const int *offse
                             tgn_stream_t stream);
 int tgn_furthestsampling_dense_ws(int B, int N, int S, const float *xyz, void *workspace, size_t workspace_bytes,
                                   void *idx, float *new_xyz, int flags, tgn_stream_t stream);
+/*
+ * FPS of an FPS result is the identity: if a cloud IS the sequence p_0, p_1, ... produced by farthest point sampling
+ * (canonical first-index tie order, same arithmetic flags), sampling it again returns positions 0, 1, 2, ... -- which
+ * is what the reference's set-abstraction / transition-down chains compute at every level after the first
+ * (pointnet2_utils.py:160 on the previous level's new_xyz; blocks.py:69-70).  It holds as long as every winning
+ * distance of the producing run was > 0 and < 1e10 (no exhausted cloud, no NaN/Inf point); each kernel records the
+ * first iteration that breaks it.
+ *   prefix_out[b] (int32 per cloud, optional): this result's samples 0 .. prefix_out[b]-1 carry the property.
+ *   prefix_in[b]  (int32 per cloud, optional): cloud b of xyz is such a sequence up to prefix_in[b] samples; when that
+ *                 covers the requested sample count (and TGN_FPS_TREE_TIES is not set) the kernel writes the identity
+ *                 (indices, new_xyz, prefix_out) and returns -- decided on the device, per cloud, no host sync.
+ * The caller vouches for provenance: prefix_in must come from the prefix_out of the launch that produced xyz.
+ */
+int tgn_furthestsampling_prefix(int b, int n_max, const float *xyz, const int *offset, const int *new_offset,
+                                void *workspace, size_t workspace_bytes, void *idx, float *new_xyz, const int *prefix_in,
+                                int *prefix_out, int flags, tgn_stream_t stream);
+int tgn_furthestsampling_dense_prefix(int B, int N, int S, const float *xyz, void *workspace, size_t workspace_bytes,
+                                      void *idx, float *new_xyz, const int *prefix_in, int *prefix_out, int flags,
+                                      tgn_stream_t stream);
 
 /* kNN (pointops.py:30-45): b segments; idx (m,nsample) int32; dist2 (m,nsample) squared, ascending. */
 int tgn_knnquery(int b, int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,

@@ -192,3 +192,26 @@ def test_ball_query_semantics(oracle):
     assert (oracle.query_ball_point(0.1, 4, xyz, far) == 2000).all()
     with pytest.raises(IndexError):
         oracle.group_points(xyz, far, None, oracle.query_ball_point(0.1, 4, xyz, far))
+
+
+def test_fps_of_an_fps_result_is_the_identity(oracle):
+    """The property behind tgn_furthestsampling_dense_prefix (include/tgn_pointops.h): farthest point sampling of a
+    cloud that is itself an FPS sequence returns 0, 1, 2, ... -- with exact ties too (first-index order), as long as
+    the producing run never picked a point at distance 0 (exhausted cloud); the tree tie order does not have it."""
+    from toothgroupnetwork_amd import synth
+    rng = np.random.default_rng(5)
+    clouds = {"arch": synth.arch_cloud(5000, 1, False), "uniform": synth.uniform_cloud(4000, 2),
+              "lattice": synth.lattice_cloud(8, dup=3, seed=0),
+              "quantised": (rng.integers(-6, 7, size=(3000, 3)) / 8).astype(np.float32)}
+    for name, c in clouds.items():
+        x = c[None].astype(np.float32)
+        s1 = min(800, x.shape[1])
+        seq = oracle.index_points(x, oracle.farthest_point_sample(x, s1))
+        distinct = len(np.unique(c, axis=0))
+        s2 = min(256, distinct)
+        assert np.array_equal(oracle.farthest_point_sample(seq, s2)[0], np.arange(s2)), name
+    # exhausted: once every distinct point is taken the reference keeps returning point 0 -- NOT the identity
+    c = np.repeat(synth.uniform_cloud(5, 3), 3, axis=0)[None]
+    seq = oracle.index_points(c, oracle.farthest_point_sample(c, 12))
+    again = oracle.farthest_point_sample(seq, 12)[0]
+    assert np.array_equal(again[:5], np.arange(5)) and not np.array_equal(again, np.arange(12))

@@ -47,7 +47,9 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(FpsArgs a) {
     int start_n, n, start_m, m;
     fps_segment(a, blockIdx.x, start_n, n, start_m, m);
     if (m <= 0) return;
+    if (fps_prefix_shortcut<NT>(a, blockIdx.x, start_n, n, start_m, m)) return;
     const float *__restrict__ base = a.xyz + (size_t)start_n * 3;
+    int cert = m;
 
     float x[P], y[P], z[P], d[P];
 #pragma unroll
@@ -96,7 +98,9 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(FpsArgs a) {
             }
         }
         if constexpr (!TREE) bkey = bkey * NT + tid;
-        const unsigned key = fps_block_argmax<NW>(best, bkey, slots, j & 1, wave, lane);
+        unsigned vbits;
+        const unsigned key = fps_block_argmax<NW>(best, bkey, slots, j & 1, wave, lane, vbits);
+        cert = fps_prefix_update(cert, j, vbits);
         int k = key == 0xFFFFFFFFu ? 0 : (TREE ? compat_index(key, a.ref_log2_block) : (int)key);
         k = __builtin_amdgcn_readfirstlane(k);
         if (n > 0) {
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(FpsArgs a) {
         }
         if (tid == 0) fps_emit(a, start_m + j, start_n, k, qx, qy, qz);
     }
+    if (a.prefix_out && tid == 0) a.prefix_out[blockIdx.x] = cert;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -130,7 +135,9 @@ __global__ __launch_bounds__(1024) void fps_streaming_kernel(FpsArgs a) {
     int start_n, n, start_m, m;
     fps_segment(a, blockIdx.x, start_n, n, start_m, m);
     if (m <= 0) return;
+    if (fps_prefix_shortcut<NT>(a, blockIdx.x, start_n, n, start_m, m)) return;
     const float *__restrict__ base = a.xyz + (size_t)start_n * 3;
+    int cert = m;
     float *__restrict__ tmp = a.tmp + start_n;
     for (int k = tid; k < n; k += NT) tmp[k] = 1e10f;
 
@@ -156,7 +163,9 @@ __global__ __launch_bounds__(1024) void fps_streaming_kernel(FpsArgs a) {
             best = take ? nd : best;
             bkey = take ? key : bkey;
         }
-        const unsigned key = fps_block_argmax<NW>(best, bkey, slots, j & 1, wave, lane);
+        unsigned vbits;
+        const unsigned key = fps_block_argmax<NW>(best, bkey, slots, j & 1, wave, lane, vbits);
+        cert = fps_prefix_update(cert, j, vbits);
         int k = key == 0xFFFFFFFFu ? 0 : (TREE ? compat_index(key, a.ref_log2_block) : (int)key);
         k = __builtin_amdgcn_readfirstlane(k);
         if (n > 0) {
@@ -166,6 +175,7 @@ __global__ __launch_bounds__(1024) void fps_streaming_kernel(FpsArgs a) {
         }
         if (tid == 0) fps_emit(a, start_m + j, start_n, k, qx, qy, qz);
     }
+    if (a.prefix_out && tid == 0) a.prefix_out[blockIdx.x] = cert;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -329,6 +339,32 @@ TGN_API int tgn_furthestsampling_dense_ws(int B, int N, int S, const float *xyz,
         return TGN_ERR_INVALID_ARGUMENT;
     }
     FpsArgs a{xyz, nullptr, nullptr, N, S, idx, new_xyz, (float *)workspace, workspace, workspace_bytes, N, flags, 0};
+    return fps_dispatch(B, N, a, (hipStream_t)stream);
+}
+
+// FPS with the prefix certificate (fps_common.h): prefix_in says which clouds ARE FPS sequences already, prefix_out
+// receives the same statement about this call's result.  Either may be null.
+TGN_API int tgn_furthestsampling_prefix(int b, int n_max, const float *xyz, const int *offset, const int *new_offset,
+                                        void *workspace, size_t workspace_bytes, void *idx, float *new_xyz,
+                                        const int *prefix_in, int *prefix_out, int flags, tgn_stream_t stream) {
+    if (b > 0 && (!offset || !new_offset)) {
+        set_error("tgn_furthestsampling_prefix: null offsets");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    FpsArgs a{xyz, offset, new_offset, 0, 0, idx, new_xyz, (float *)workspace, workspace, workspace_bytes, n_max, flags, 0,
+              prefix_in, prefix_out};
+    return fps_dispatch(b, n_max, a, (hipStream_t)stream);
+}
+
+TGN_API int tgn_furthestsampling_dense_prefix(int B, int N, int S, const float *xyz, void *workspace,
+                                              size_t workspace_bytes, void *idx, float *new_xyz, const int *prefix_in,
+                                              int *prefix_out, int flags, tgn_stream_t stream) {
+    if (N < 0 || S < 0) {
+        set_error("tgn_furthestsampling_dense_prefix: negative size");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    FpsArgs a{xyz, nullptr, nullptr, N, S, idx, new_xyz, (float *)workspace, workspace, workspace_bytes, N, flags, 0,
+              prefix_in, prefix_out};
     return fps_dispatch(B, N, a, (hipStream_t)stream);
 }
 

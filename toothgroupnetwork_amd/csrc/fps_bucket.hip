@@ -71,6 +71,8 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
     int start_n, n, start_m, m;
     fps_segment(a, blockIdx.x, start_n, n, start_m, m);
     if (m <= 0) return;
+    if (fps_prefix_shortcut<NT>(a, blockIdx.x, start_n, n, start_m, m)) return;
+    int cert = m;  // first iteration whose winning distance breaks the FPS-prefix property (fps_common.h)
     const float *__restrict__ base = a.xyz + (size_t)start_n * 3;
     const int log2bs = a.ref_log2_block;
 
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
         unsigned kwin;
         if constexpr (NW == 1) {
             kwin = wm < 0.0f ? 0xFFFFFFFFu : wkey;
+            cert = fps_prefix_update(cert, j, wm < 0.0f ? 0u : __float_as_uint(wm));
             qx = wx;
             qy = wy;
             qz = wz;
@@ -350,6 +353,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             if constexpr (NW > 8) asm volatile("v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(mb));
             static_assert(NW == 4 || NW == 8 || NW == 16, "wave count");
             mb = (unsigned)__builtin_amdgcn_readlane((int)mb, NW - 1);
+            cert = fps_prefix_update(cert, j, mb);
             const bool wc = lane < NW && vb == mb;
             const unsigned kk = wc ? __float_as_uint(r0.y) : 0xFFFFFFFFu;
             const unsigned long long wmask = __ballot(wc);
@@ -388,6 +392,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             fps_emit(a, start_m + cb + tid, start_n, __float_as_int(o.x), o.y, o.z, o.w);
         }
     }
+    if (a.prefix_out && tid == 0) a.prefix_out[blockIdx.x] = cert;
     if (dbg && lane == 0) {
         unsigned long long *st = (unsigned long long *)a.tmp;
         atomicAdd(&st[0], st_touched);
@@ -444,6 +449,8 @@ __global__ __launch_bounds__(kStreamThreads) void fps_bucket_stream_kernel(FpsAr
     int start_n, n, start_m, m;
     fps_segment(a, blockIdx.x, start_n, n, start_m, m);
     if (m <= 0) return;
+    if (fps_prefix_shortcut<kStreamThreads>(a, blockIdx.x, start_n, n, start_m, m)) return;
+    int cert = m;
     const float *__restrict__ base = a.xyz + (size_t)start_n * 3;
     const int log2bs = a.ref_log2_block;
     unsigned char *wsb = (unsigned char *)a.ws + (size_t)blockIdx.x * fps_stream_cloud_bytes(a.n_max);
@@ -636,6 +643,7 @@ __global__ __launch_bounds__(kStreamThreads) void fps_bucket_stream_kernel(FpsAr
             pk = c > pk ? c : pk;
         }
         const unsigned long long bmax64 = fps_block_max<NW>(pk, slots, j & 1, wave, lane);
+        cert = fps_prefix_update(cert, j, (unsigned)(bmax64 >> 32));
         const unsigned key = 0xFFFFFFFFu - (unsigned)bmax64;
         int k = bmax64 == 0ull ? 0 : (TREE ? compat_index(key, log2bs) : (int)key);
         k = __builtin_amdgcn_readfirstlane(k);
@@ -657,6 +665,7 @@ __global__ __launch_bounds__(kStreamThreads) void fps_bucket_stream_kernel(FpsAr
         if (((m - 1) & (NT - 1)) != NT - 1 && cb + tid <= m - 1)
             fps_emit(a, start_m + cb + tid, start_n, hold_k, hold_x, hold_y, hold_z);
     }
+    if (a.prefix_out && tid == 0) a.prefix_out[blockIdx.x] = cert;
 }
 
 size_t fps_stream_workspace_bytes(int b, int n_max) {

@@ -18,6 +18,9 @@ struct FpsArgs {
     int n_max;              // largest cloud of the batch (workspace stride)
     int flags;
     int ref_log2_block;     // log2 of the reference's block size (cuda-compat tie order)
+    // FPS of an FPS prefix is the identity (fps_prefix_* below): per-cloud certificates, both optional
+    const int *prefix_in;   // prefix_in[cloud] >= m: the cloud is known to BE an FPS sequence -> samples are 0..m-1
+    int *prefix_out;        // number of leading samples of THIS result that carry the property on
 };
 
 __device__ __forceinline__ void fps_segment(const FpsArgs &a, int bid, int &start_n, int &n, int &start_m, int &m) {
@@ -46,6 +49,29 @@ __device__ __forceinline__ void fps_emit(const FpsArgs &a, int row, int start_n,
         a.new_xyz[(size_t)row * 3 + 1] = y;
         a.new_xyz[(size_t)row * 3 + 2] = z;
     }
+}
+
+// Farthest point sampling of a cloud that is itself an FPS sequence p_0, p_1, ... (same arithmetic, first-index ties)
+// returns positions 0, 1, 2, ...: p_j attains the maximum of the running minimum distance over the whole original
+// cloud, hence over the subset, and every earlier position is an already-picked sample at distance exactly 0.  That
+// needs the winning distance d_j of iteration j to be > 0 (not exhausted: no duplicates picked) and < 1e10 (a point
+// with NaN/Inf coordinates never leaves its initial 1e10 and is picked again and again).  The kernels record, per
+// cloud, the first iteration that violates it; a later launch that is handed this certificate (and does not use
+// the tree tie order) emits the identity without running.  vbits = bit pattern of d_j (>= 0: ordered like unsigned).
+__device__ __forceinline__ int fps_prefix_update(int cert, int j, unsigned vbits) {
+    const bool good = vbits != 0u && vbits < 0x501502F9u;  // 0 < d_j < 1e10f
+    return (!good && j < cert) ? j : cert;
+}
+template <int NT>
+__device__ __forceinline__ bool fps_prefix_shortcut(const FpsArgs &a, int cloud, int start_n, int n, int start_m, int m) {
+    if (!a.prefix_in || (a.flags & TGN_FPS_TREE_TIES)) return false;
+    const int c = a.prefix_in[cloud];  // block-uniform
+    if (c < m || m > n) return false;
+    const float *__restrict__ base = a.xyz + (size_t)start_n * 3;
+    for (int j = threadIdx.x; j < m; j += NT)
+        fps_emit(a, start_m + j, start_n, j, base[(size_t)j * 3 + 0], base[(size_t)j * 3 + 1], base[(size_t)j * 3 + 2]);
+    if (a.prefix_out && threadIdx.x == 0) a.prefix_out[cloud] = m;
+    return true;
 }
 
 // cuda-compat tie order: (bit-reversed reference thread id, position within that thread).
@@ -123,7 +149,7 @@ __device__ __forceinline__ unsigned wave_min_u32_shfl(unsigned v) {
 // readlane per level; exact ties fall back to a key minimum.
 template <int NW>
 __device__ __forceinline__ unsigned fps_block_argmax(float best, unsigned key, unsigned long long (*slots)[NW],
-                                                     int parity, int wave, int lane) {
+                                                     int parity, int wave, int lane, unsigned &vbits) {
     const float wm = wave_max_f32_dpp(best);
     const bool mine = best == wm && wm >= 0.0f;
     const unsigned long long eq = __ballot(mine);
@@ -135,6 +161,7 @@ __device__ __forceinline__ unsigned fps_block_argmax(float best, unsigned key, u
             wkey = wave_min_u32_dpp(mine ? key : 0xFFFFFFFFu);
     }
     if constexpr (NW == 1) {
+        vbits = wm < 0.0f ? 0u : __float_as_uint(wm);
         return wkey;
     } else {
         // distances are >= 0: their bit patterns order like unsigned integers
@@ -149,6 +176,7 @@ __device__ __forceinline__ unsigned fps_block_argmax(float best, unsigned key, u
                      "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
                      : "+v"(mb));
         mb = (unsigned)__builtin_amdgcn_readlane((int)mb, 15);
+        vbits = mb;
         const bool wc = lane < NW && vb == mb;
         const unsigned kk = wc ? vk : 0xFFFFFFFFu;
         const unsigned long long wmask = __ballot(wc);

@@ -41,8 +41,13 @@ class HotPath:
     fill the CUs around it.  Buffers are double-buffered by step parity; HIP events order FPS level l before the
     ball query / grouping of level l of the same step, and step k-2's consumers before step k's producers."""
 
-    def __init__(self, B, device, shape=SHAPE_A, xyz_first=True, index_dtype=torch.int32, pipeline=False):
+    def __init__(self, B, device, shape=SHAPE_A, xyz_first=True, index_dtype=torch.int32, pipeline=False,
+                 fps_prefix=False):
         self.B, self.device, self.shape = B, device, shape
+        # fps_prefix: hand every FPS level the certificate of the level that produced its input (FPS of an FPS result
+        # is the identity, include/tgn_pointops.h): levels > 0 then return 0..S-1 without iterating, decided per cloud
+        # on the device.  Off by default: the headline benchmark runs every level's sampling for real.
+        self.fps_prefix = bool(fps_prefix)
         self.xyz_first = xyz_first
         self.L = lib()
         self.pipeline = pipeline
@@ -68,7 +73,8 @@ class HotPath:
                       fps_idx=torch.empty(B, S, dtype=torch.int32, device=device),
                       new_xyz=torch.empty(B, S, 3, **f32),
                       group_idx=torch.empty(B, S, K, dtype=index_dtype, device=device),
-                      grouped=torch.empty(B, S, K, 3 + D, **f32))
+                      grouped=torch.empty(B, S, K, 3 + D, **f32),
+                      cert=torch.empty(B, dtype=torch.int32, device=device))
             nbytes = int(self.L.tgn_ball_query_workspace_bytes(B, N, S))
             lv["ws_bytes"] = nbytes
             lv["ws"] = torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None
@@ -107,8 +113,7 @@ class HotPath:
         for i, lv in enumerate(self.levels):
             B, N, S, K, D = self.B, lv["N"], lv["S"], lv["K"], lv["D"]
             pts = feats[i]
-            self._timed(f"fps_l{i + 1}", lambda: check(L.tgn_furthestsampling_dense(
-                B, N, S, ptr(cur_xyz), None, ptr(lv["fps_idx"]), ptr(lv["new_xyz"]), _lib.FPS_LOCAL_INDEX, st), "fps"))
+            self._timed(f"fps_l{i + 1}", lambda: self._fps(i, lv, cur_xyz, self.levels, st))
             self._timed(f"ball_l{i + 1}", lambda: check(L.tgn_ball_query(
                 B, N, S, K, lv["r2"], ptr(cur_xyz), ptr(lv["new_xyz"]), ptr(lv["group_idx"]), self.idx64,
                 ptr(lv["ws"]), lv["ws_bytes"], st), "ball_query"))
@@ -119,6 +124,16 @@ class HotPath:
         if self.events is not None:
             self._step += 1
         return self.levels
+
+    def _fps(self, i, lv, cur_xyz, levels, st):
+        L = self.L
+        if not self.fps_prefix:
+            return check(L.tgn_furthestsampling_dense(self.B, lv["N"], lv["S"], ptr(cur_xyz), None, ptr(lv["fps_idx"]),
+                                                      ptr(lv["new_xyz"]), _lib.FPS_LOCAL_INDEX, st), "fps")
+        cert_in = levels[i - 1]["cert"] if i > 0 else None   # level i samples level i-1's new_xyz
+        return check(L.tgn_furthestsampling_dense_prefix(self.B, lv["N"], lv["S"], ptr(cur_xyz), None, 0, ptr(lv["fps_idx"]),
+                                                         ptr(lv["new_xyz"]), ptr(cert_in), ptr(lv["cert"]),
+                                                         _lib.FPS_LOCAL_INDEX, st), "fps")
 
     def _run_pipelined(self, xyz, feats, inputs_on_current_stream=True):
         L = self.L
@@ -140,8 +155,7 @@ class HotPath:
         # next step's FPS level 1
         for i, lv in enumerate(levels):
             N, S, K = lv["N"], lv["S"], lv["K"]
-            self._timed(f"fps_l{i + 1}", lambda: check(L.tgn_furthestsampling_dense(
-                B, N, S, ptr(cur_xyz), None, ptr(lv["fps_idx"]), ptr(lv["new_xyz"]), _lib.FPS_LOCAL_INDEX, pf), "fps"), sf)
+            self._timed(f"fps_l{i + 1}", lambda: self._fps(i, lv, cur_xyz, levels, pf), sf)
             self._timed(f"ball_l{i + 1}", lambda: check(L.tgn_ball_query(
                 B, N, S, K, lv["r2"], ptr(cur_xyz), ptr(lv["new_xyz"]), ptr(lv["group_idx"]), self.idx64,
                 ptr(lv["ws"]), lv["ws_bytes"], pf), "ball_query"), sf)

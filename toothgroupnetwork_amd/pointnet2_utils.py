@@ -126,7 +126,49 @@ def index_points(points, idx):
         idx = idx.long()
     points = _f32c(points)
     out = _IndexPoints.apply(points, idx.contiguous())
+    _fps_prefix_follow(points, idx, out)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# FPS of an FPS result is the identity (include/tgn_pointops.h, tgn_furthestsampling_dense_prefix).  Every
+# set-abstraction level after the first samples the previous level's new_xyz (pointnet2_utils.py:160 /:276), so
+# the kernel that produced new_xyz also leaves a per-cloud certificate, and the next FPS over that very tensor is handed
+# it; the decision (identity or real run) is taken on the device, per cloud.  Provenance is tracked by tensor identity:
+# (storage pointer, version counter, shape), with the tensors kept alive so that a pointer cannot be recycled.
+# TGN_FPS_PREFIX=0 turns the whole mechanism off.
+# ---------------------------------------------------------------------------------------------
+FPS_PREFIX = os.environ.get("TGN_FPS_PREFIX", "1") != "0"
+_FPS_MEMO_CAP = 8
+_fps_seq_memo = {}   # key(new_xyz tensor)  -> (tensor, certificate (B,) int32)
+_fps_idx_memo = {}   # key(fps index tensor) -> (tensor, key(xyz it indexes), certificate)
+fps_prefix_stats = {"offered": 0}
+
+
+def _tkey(t):
+    return (t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device.index)
+
+
+def _memo_put(memo, key, value):
+    memo.pop(key, None)
+    memo[key] = value
+    while len(memo) > _FPS_MEMO_CAP:
+        memo.pop(next(iter(memo)))
+
+
+def fps_prefix_clear():
+    _fps_seq_memo.clear()
+    _fps_idx_memo.clear()
+
+
+def _fps_prefix_follow(points, idx, out):
+    """index_points(xyz, fps_idx) of an index tensor that farthest_point_sample returned for this xyz yields the FPS
+    sequence itself (the reference's own way of getting new_xyz, pointnet2_utils.py:161): pass the certificate on."""
+    if not FPS_PREFIX or not _fps_idx_memo or idx.dim() != 2 or out.shape[-1] != 3:
+        return
+    hit = _fps_idx_memo.get(_tkey(idx))
+    if hit is not None and hit[1] == _tkey(points):
+        _memo_put(_fps_seq_memo, _tkey(out), (out, hit[2]))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -144,8 +186,21 @@ def _fps_dense(xyz, npoint, want_coords=False, cuda_compat=False):
     from .pointops import fps_workspace
     ws, nbytes = fps_workspace(B, N, B * N, xyz.device)
     flags = _lib.FPS_LOCAL_INDEX | _lib.FPS_INDEX64 | (_lib.FPS_CUDA_COMPAT if cuda_compat else 0)
-    check(lib().tgn_furthestsampling_dense_ws(B, N, npoint, ptr(xyz), ptr(ws), nbytes, ptr(idx), ptr(new_xyz), flags,
-                                              stream()), "tgn_furthestsampling_dense")
+    use_prefix = FPS_PREFIX and not cuda_compat      # the tree tie order of cuda-compat breaks the identity
+    cert_in = cert_out = None
+    if use_prefix:
+        hit = _fps_seq_memo.get(_tkey(xyz))
+        if hit is not None:
+            cert_in = hit[1]
+            fps_prefix_stats["offered"] += 1
+        cert_out = torch.empty(B, dtype=torch.int32, device=xyz.device)
+    check(lib().tgn_furthestsampling_dense_prefix(B, N, npoint, ptr(xyz), ptr(ws), nbytes, ptr(idx), ptr(new_xyz),
+                                                  ptr(cert_in), ptr(cert_out), flags, stream()),
+          "tgn_furthestsampling_dense")
+    if use_prefix:
+        if new_xyz is not None:
+            _memo_put(_fps_seq_memo, _tkey(new_xyz), (new_xyz, cert_out))
+        _memo_put(_fps_idx_memo, _tkey(idx), (idx, _tkey(xyz), cert_out))
     return idx, new_xyz
 
 
