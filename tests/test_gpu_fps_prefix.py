@@ -166,3 +166,40 @@ def test_hotpath_with_prefix_certificates_equals_plain(dev):
             for key in ("fps_idx", "new_xyz", "group_idx", "grouped"):
                 assert torch.equal(a[key], b[key]), (pipeline, key)
         assert all(int(lv["cert"].min()) == lv["S"] for lv in levels)
+
+
+def test_packed_transition_down_chain_with_content_checked_certificates(dev, oracle):
+    """the Point-Transformer idiom (blocks.py:62-74): idx = furthestsampling(p, o, n_o); n_p = p[idx]; next level
+    samples n_p.  Provenance is checked by content on the device; ragged batch with one degenerate cloud (falls back
+    inside the same launch) and a perturbed copy (must not be believed)."""
+    from toothgroupnetwork_amd import pointops as P
+    P.fps_prefix_clear()
+    P.fps_prefix_stats["offered"] = 0
+    dup = np.repeat(synth.uniform_cloud(150, 4), 8, axis=0)                  # 150 distinct points in 1200 rows
+    clouds = [synth.arch_cloud(9000, 1, False), dup, synth.uniform_cloud(3000, 2)]
+    xyz = np.concatenate(clouds).astype(np.float32)
+    off = np.cumsum([c.shape[0] for c in clouds]).astype(np.int32)
+    p, o = T(xyz, dev), T(off, dev)
+    p_np, o_np = xyz, off
+    for level in range(4):
+        sizes = np.diff(np.concatenate([[0], o_np]))
+        n_o_np = np.cumsum(sizes // 4).astype(np.int32)
+        n_o = T(n_o_np, dev)
+        idx = P.furthestsampling(p, o, n_o)
+        want = oracle.furthestsampling(p_np, o_np, n_o_np)
+        assert np.array_equal(idx.cpu().numpy(), want), level
+        n_p = p[idx.long(), :]                                               # the model's own gather: a new tensor
+        p, o, p_np, o_np = n_p, n_o, p_np[want.astype(np.int64)], n_o_np
+    assert P.fps_prefix_stats["offered"] == 3
+    # same layout, different coordinates: the kernel must notice and sample for real
+    q = (p * 1.5).contiguous()
+    n_o2 = T(np.cumsum(np.diff(np.concatenate([[0], o_np])) // 2).astype(np.int32), dev)
+    got = P.furthestsampling(q, o, n_o2)
+    assert np.array_equal(got.cpu().numpy(), oracle.furthestsampling(q.cpu().numpy(), o_np, n_o2.cpu().numpy()))
+    # TGN_FPS_PREFIX off: identical indices
+    P.FPS_PREFIX, keep = False, P.FPS_PREFIX
+    try:
+        off_idx = P.furthestsampling(T(xyz, dev), T(off, dev), T(np.cumsum([c.shape[0] // 4 for c in clouds]).astype(np.int32), dev))
+    finally:
+        P.FPS_PREFIX = keep
+    assert np.array_equal(off_idx.cpu().numpy(), oracle.furthestsampling(xyz, off, np.cumsum([c.shape[0] // 4 for c in clouds]).astype(np.int32)))

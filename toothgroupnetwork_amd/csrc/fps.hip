@@ -346,13 +346,14 @@ TGN_API int tgn_furthestsampling_dense_ws(int B, int N, int S, const float *xyz,
 // receives the same statement about this call's result.  Either may be null.
 TGN_API int tgn_furthestsampling_prefix(int b, int n_max, const float *xyz, const int *offset, const int *new_offset,
                                         void *workspace, size_t workspace_bytes, void *idx, float *new_xyz,
-                                        const int *prefix_in, int *prefix_out, int flags, tgn_stream_t stream) {
+                                        const int *prefix_in, const float *prefix_ref, int *prefix_out, int flags,
+                                        tgn_stream_t stream) {
     if (b > 0 && (!offset || !new_offset)) {
         set_error("tgn_furthestsampling_prefix: null offsets");
         return TGN_ERR_INVALID_ARGUMENT;
     }
     FpsArgs a{xyz, offset, new_offset, 0, 0, idx, new_xyz, (float *)workspace, workspace, workspace_bytes, n_max, flags, 0,
-              prefix_in, prefix_out};
+              prefix_in, prefix_out, prefix_ref};
     return fps_dispatch(b, n_max, a, (hipStream_t)stream);
 }
 
@@ -364,7 +365,7 @@ TGN_API int tgn_furthestsampling_dense_prefix(int B, int N, int S, const float *
         return TGN_ERR_INVALID_ARGUMENT;
     }
     FpsArgs a{xyz, nullptr, nullptr, N, S, idx, new_xyz, (float *)workspace, workspace, workspace_bytes, N, flags, 0,
-              prefix_in, prefix_out};
+              prefix_in, prefix_out, nullptr};
     return fps_dispatch(B, N, a, (hipStream_t)stream);
 }
 

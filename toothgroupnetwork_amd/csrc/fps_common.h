@@ -21,6 +21,8 @@ struct FpsArgs {
     // FPS of an FPS prefix is the identity (fps_prefix_* below): per-cloud certificates, both optional
     const int *prefix_in;   // prefix_in[cloud] >= m: the cloud is known to BE an FPS sequence -> samples are 0..m-1
     int *prefix_out;        // number of leading samples of THIS result that carry the property on
+    const float *prefix_ref;  // optional: the coordinates the certificate was issued for (same layout as xyz); the
+                              // shortcut is taken only if the cloud equals them bit for bit
 };
 
 __device__ __forceinline__ void fps_segment(const FpsArgs &a, int bid, int &start_n, int &n, int &start_m, int &m) {
@@ -57,7 +59,8 @@ __device__ __forceinline__ void fps_emit(const FpsArgs &a, int row, int start_n,
 // needs the winning distance d_j of iteration j to be > 0 (not exhausted: no duplicates picked) and < 1e10 (a point
 // with NaN/Inf coordinates never leaves its initial 1e10 and is picked again and again).  The kernels record, per
 // cloud, the first iteration that violates it; a later launch that is handed this certificate (and does not use
-// the tree tie order) emits the identity without running.  vbits = bit pattern of d_j (>= 0: ordered like unsigned).
+// the tree tie order) emits the identity without running; with prefix_ref the kernel first checks that the cloud
+// really is the sequence the certificate was issued for.  vbits = bit pattern of d_j (>= 0: ordered like unsigned).
 __device__ __forceinline__ int fps_prefix_update(int cert, int j, unsigned vbits) {
     const bool good = vbits != 0u && vbits < 0x501502F9u;  // 0 < d_j < 1e10f
     return (!good && j < cert) ? j : cert;
@@ -68,6 +71,14 @@ __device__ __forceinline__ bool fps_prefix_shortcut(const FpsArgs &a, int cloud,
     const int c = a.prefix_in[cloud];  // block-uniform
     if (c < m || m > n) return false;
     const float *__restrict__ base = a.xyz + (size_t)start_n * 3;
+    if (a.prefix_ref) {
+        // provenance by content: the caller only believes that xyz is the sequence the certificate belongs to
+        const unsigned *__restrict__ u = (const unsigned *)base;
+        const unsigned *__restrict__ r = (const unsigned *)(a.prefix_ref + (size_t)start_n * 3);
+        int same = 1;
+        for (int i = threadIdx.x; i < 3 * n; i += NT) same &= (u[i] == r[i]) ? 1 : 0;
+        if (!__syncthreads_and(same)) return false;
+    }
     for (int j = threadIdx.x; j < m; j += NT)
         fps_emit(a, start_m + j, start_n, j, base[(size_t)j * 3 + 0], base[(size_t)j * 3 + 1], base[(size_t)j * 3 + 2]);
     if (a.prefix_out && threadIdx.x == 0) a.prefix_out[cloud] = m;
