@@ -34,7 +34,7 @@ namespace tgn {
 // ---------------------------------------------------------------------------------------------
 template <int NT, int P, int MODE>
 __global__ __launch_bounds__(NT) void fps_resident_kernel(FpsArgs a) {
-    constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0;
+    constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0, CERT = (MODE & kFpsModeCert) != 0;
     constexpr int NW = NT / kWave;
     // small clouds also keep a copy of the coordinates in LDS: the winner's coordinates are then one LDS read away
     // instead of a dependent global load (~300+ cycles of an iteration that is all latency)
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(FpsArgs a) {
     if (m <= 0) return;
     if (fps_prefix_shortcut<NT>(a, blockIdx.x, start_n, n, start_m, m)) return;
     const float *__restrict__ base = a.xyz + (size_t)start_n * 3;
-    int cert = m;
+    FpsPrefixCert cert;
 
     float x[P], y[P], z[P], d[P];
 #pragma unroll
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(FpsArgs a) {
         if constexpr (!TREE) bkey = bkey * NT + tid;
         unsigned vbits;
         const unsigned key = fps_block_argmax<NW>(best, bkey, slots, j & 1, wave, lane, vbits);
-        cert = fps_prefix_update(cert, j, vbits);
+        if constexpr (CERT) cert.update(vbits);
         int k = key == 0xFFFFFFFFu ? 0 : (TREE ? compat_index(key, a.ref_log2_block) : (int)key);
         k = __builtin_amdgcn_readfirstlane(k);
         if (n > 0) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(FpsArgs a) {
         }
         if (tid == 0) fps_emit(a, start_m + j, start_n, k, qx, qy, qz);
     }
-    if (a.prefix_out && tid == 0) a.prefix_out[blockIdx.x] = cert;
+    if (a.prefix_out && tid == 0) a.prefix_out[blockIdx.x] = CERT ? cert.value(m) : 1;  // not tracked: no claim
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(FpsArgs a) {
 // ---------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(1024) void fps_streaming_kernel(FpsArgs a) {
-    constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0;
+    constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0, CERT = (MODE & kFpsModeCert) != 0;
     constexpr int NT = 1024, NW = NT / kWave;
     __shared__ unsigned long long slots[2][NW];
     const int tid = threadIdx.x;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(1024) void fps_streaming_kernel(FpsArgs a) {
     if (m <= 0) return;
     if (fps_prefix_shortcut<NT>(a, blockIdx.x, start_n, n, start_m, m)) return;
     const float *__restrict__ base = a.xyz + (size_t)start_n * 3;
-    int cert = m;
+    FpsPrefixCert cert;
     float *__restrict__ tmp = a.tmp + start_n;
     for (int k = tid; k < n; k += NT) tmp[k] = 1e10f;
 
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(1024) void fps_streaming_kernel(FpsArgs a) {
         }
         unsigned vbits;
         const unsigned key = fps_block_argmax<NW>(best, bkey, slots, j & 1, wave, lane, vbits);
-        cert = fps_prefix_update(cert, j, vbits);
+        if constexpr (CERT) cert.update(vbits);
         int k = key == 0xFFFFFFFFu ? 0 : (TREE ? compat_index(key, a.ref_log2_block) : (int)key);
         k = __builtin_amdgcn_readfirstlane(k);
         if (n > 0) {
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(1024) void fps_streaming_kernel(FpsArgs a) {
         }
         if (tid == 0) fps_emit(a, start_m + j, start_n, k, qx, qy, qz);
     }
-    if (a.prefix_out && tid == 0) a.prefix_out[blockIdx.x] = cert;
+    if (a.prefix_out && tid == 0) a.prefix_out[blockIdx.x] = CERT ? cert.value(m) : 1;  // not tracked: no claim
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -280,12 +280,11 @@ static int fps_dispatch(int b, int n_max, FpsArgs a, hipStream_t stream) {
         return TGN_ERR_INVALID_ARGUMENT;
     }
     a.ref_log2_block = ref_log2_block(n_max);
-    switch (a.flags & (TGN_FPS_FMA | TGN_FPS_TREE_TIES)) {
-        case 0: return fps_launch<0>(b, n_max, a, stream);
-        case TGN_FPS_FMA: return fps_launch<1>(b, n_max, a, stream);
-        case TGN_FPS_TREE_TIES: return fps_launch<2>(b, n_max, a, stream);
-        default: return fps_launch<3>(b, n_max, a, stream);
-    }
+    const bool tree = (a.flags & TGN_FPS_TREE_TIES) != 0, fma = (a.flags & TGN_FPS_FMA) != 0;
+    if (tree) return fma ? fps_launch<3>(b, n_max, a, stream) : fps_launch<2>(b, n_max, a, stream);
+    if (a.prefix_out)  // certificate wanted: the tracking variants (the tree tie order never carries the property)
+        return fma ? fps_launch<1 | kFpsModeCert>(b, n_max, a, stream) : fps_launch<kFpsModeCert>(b, n_max, a, stream);
+    return fma ? fps_launch<1>(b, n_max, a, stream) : fps_launch<0>(b, n_max, a, stream);
 }
 
 }  // namespace tgn

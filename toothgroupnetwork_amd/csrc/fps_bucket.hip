@@ -52,7 +52,7 @@ constexpr int next_pow2(int v) {
 
 template <int NT, int P, int MODE, bool DBG = false>
 __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
-    constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0;
+    constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0, CERT = (MODE & kFpsModeCert) != 0;
     constexpr int NW = NT / kWave;
     constexpr int CAP = NT * P;
     constexpr int M = next_pow2(CAP);  // sort size
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
     fps_segment(a, blockIdx.x, start_n, n, start_m, m);
     if (m <= 0) return;
     if (fps_prefix_shortcut<NT>(a, blockIdx.x, start_n, n, start_m, m)) return;
-    int cert = m;  // first iteration whose winning distance breaks the FPS-prefix property (fps_common.h)
+    FpsPrefixCert cert;  // first iteration whose winning distance breaks the FPS-prefix property (fps_common.h)
     const float *__restrict__ base = a.xyz + (size_t)start_n * 3;
     const int log2bs = a.ref_log2_block;
 
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
         unsigned kwin;
         if constexpr (NW == 1) {
             kwin = wm < 0.0f ? 0xFFFFFFFFu : wkey;
-            cert = fps_prefix_update(cert, j, wm < 0.0f ? 0u : __float_as_uint(wm));
+            if constexpr (CERT) cert.update(wm < 0.0f ? 0u : __float_as_uint(wm));
             qx = wx;
             qy = wy;
             qz = wz;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             if constexpr (NW > 8) asm volatile("v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(mb));
             static_assert(NW == 4 || NW == 8 || NW == 16, "wave count");
             mb = (unsigned)__builtin_amdgcn_readlane((int)mb, NW - 1);
-            cert = fps_prefix_update(cert, j, mb);
+            if constexpr (CERT) cert.update(mb);
             const bool wc = lane < NW && vb == mb;
             const unsigned kk = wc ? __float_as_uint(r0.y) : 0xFFFFFFFFu;
             const unsigned long long wmask = __ballot(wc);
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             fps_emit(a, start_m + cb + tid, start_n, __float_as_int(o.x), o.y, o.z, o.w);
         }
     }
-    if (a.prefix_out && tid == 0) a.prefix_out[blockIdx.x] = cert;
+    if (a.prefix_out && tid == 0) a.prefix_out[blockIdx.x] = CERT ? cert.value(m) : 1;  // not tracked: no claim
     if (dbg && lane == 0) {
         unsigned long long *st = (unsigned long long *)a.tmp;
         atomicAdd(&st[0], st_touched);
@@ -432,7 +432,7 @@ __host__ __device__ inline size_t fps_stream_cloud_bytes(int n_max) {
 
 template <int MODE>
 __global__ __launch_bounds__(kStreamThreads) void fps_bucket_stream_kernel(FpsArgs a) {
-    constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0;
+    constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0, CERT = (MODE & kFpsModeCert) != 0;
     constexpr int NT = kStreamThreads, NW = NT / kWave, NBM = kStreamMaxBuckets;
     // 128 KiB: cell histogram during set-up, then the bucket planes lo[3], hi[3], bmax (float) and bkey (u32)
     __shared__ unsigned lds[kStreamCells];
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kStreamThreads) void fps_bucket_stream_kernel(FpsAr
     fps_segment(a, blockIdx.x, start_n, n, start_m, m);
     if (m <= 0) return;
     if (fps_prefix_shortcut<kStreamThreads>(a, blockIdx.x, start_n, n, start_m, m)) return;
-    int cert = m;
+    FpsPrefixCert cert;
     const float *__restrict__ base = a.xyz + (size_t)start_n * 3;
     const int log2bs = a.ref_log2_block;
     unsigned char *wsb = (unsigned char *)a.ws + (size_t)blockIdx.x * fps_stream_cloud_bytes(a.n_max);
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(kStreamThreads) void fps_bucket_stream_kernel(FpsAr
             pk = c > pk ? c : pk;
         }
         const unsigned long long bmax64 = fps_block_max<NW>(pk, slots, j & 1, wave, lane);
-        cert = fps_prefix_update(cert, j, (unsigned)(bmax64 >> 32));
+        if constexpr (CERT) cert.update((unsigned)(bmax64 >> 32));
         const unsigned key = 0xFFFFFFFFu - (unsigned)bmax64;
         int k = bmax64 == 0ull ? 0 : (TREE ? compat_index(key, log2bs) : (int)key);
         k = __builtin_amdgcn_readfirstlane(k);
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(kStreamThreads) void fps_bucket_stream_kernel(FpsAr
         if (((m - 1) & (NT - 1)) != NT - 1 && cb + tid <= m - 1)
             fps_emit(a, start_m + cb + tid, start_n, hold_k, hold_x, hold_y, hold_z);
     }
-    if (a.prefix_out && tid == 0) a.prefix_out[blockIdx.x] = cert;
+    if (a.prefix_out && tid == 0) a.prefix_out[blockIdx.x] = CERT ? cert.value(m) : 1;  // not tracked: no claim
 }
 
 size_t fps_stream_workspace_bytes(int b, int n_max) {
@@ -675,11 +675,13 @@ size_t fps_stream_workspace_bytes(int b, int n_max) {
 
 int fps_bucket_stream_launch(int mode, int b, int n_max, const FpsArgs &a, hipStream_t stream) {
     if (!a.ws || n_max > kStreamMaxBuckets * kWave || a.ws_bytes < fps_stream_workspace_bytes(b, n_max)) return -1;
-    switch (mode & 3) {
+    switch (mode) {
         case 0: hipLaunchKernelGGL((fps_bucket_stream_kernel<0>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
         case 1: hipLaunchKernelGGL((fps_bucket_stream_kernel<1>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
         case 2: hipLaunchKernelGGL((fps_bucket_stream_kernel<2>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
-        default: hipLaunchKernelGGL((fps_bucket_stream_kernel<3>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((fps_bucket_stream_kernel<3>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((fps_bucket_stream_kernel<4>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
+        default: hipLaunchKernelGGL((fps_bucket_stream_kernel<5>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
     }
     return check_launch("fps_bucket_stream_kernel");
 }
@@ -725,11 +727,13 @@ int fps_bucket_launch(int mode, int b, int n_max, const FpsArgs &a, hipStream_t 
     int min_n = 8192;
     if (const char *e = getenv("TGN_FPS_BUCKET_MIN")) min_n = atoi(e);
     if (n_max < min_n) return -1;
-    switch (mode & 3) {
+    switch (mode) {  // bit 0 FMA, bit 1 tree ties, bit 2 certificate tracking (never with tree ties)
         case 0: return bucket_launch_mode<0>(b, n_max, a, stream);
         case 1: return bucket_launch_mode<1>(b, n_max, a, stream);
         case 2: return bucket_launch_mode<2>(b, n_max, a, stream);
-        default: return bucket_launch_mode<3>(b, n_max, a, stream);
+        case 3: return bucket_launch_mode<3>(b, n_max, a, stream);
+        case 4: return bucket_launch_mode<4>(b, n_max, a, stream);
+        default: return bucket_launch_mode<5>(b, n_max, a, stream);
     }
 }
 

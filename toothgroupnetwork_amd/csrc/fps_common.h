@@ -58,13 +58,26 @@ __device__ __forceinline__ void fps_emit(const FpsArgs &a, int row, int start_n,
 // cloud, hence over the subset, and every earlier position is an already-picked sample at distance exactly 0.  That
 // needs the winning distance d_j of iteration j to be > 0 (not exhausted: no duplicates picked) and < 1e10 (a point
 // with NaN/Inf coordinates never leaves its initial 1e10 and is picked again and again).  The kernels record, per
-// cloud, the first iteration that violates it; a later launch that is handed this certificate (and does not use
+// cloud, the first iteration that violates it (FpsPrefixCert); a later launch that is handed this certificate (and does not use
 // the tree tie order) emits the identity without running; with prefix_ref the kernel first checks that the cloud
 // really is the sequence the certificate was issued for.  vbits = bit pattern of d_j (>= 0: ordered like unsigned).
-__device__ __forceinline__ int fps_prefix_update(int cert, int j, unsigned vbits) {
-    const bool good = vbits != 0u && vbits < 0x501502F9u;  // 0 < d_j < 1e10f
-    return (!good && j < cert) ? j : cert;
-}
+// The winning distance never increases from one iteration to the next (every running minimum only shrinks), so the
+// first violating iteration follows from two wave-uniform accumulators -- two or three scalar instructions per
+// iteration: the largest d_j seen (= d_1; >= 1e10 means a NaN/Inf point) and the number of iterations with d_j > 0.
+// Kernels are instantiated with MODE bit 2 (kFpsModeCert) only when a certificate is wanted: even these few scalar
+// instructions (and two more live SGPRs) cost the 24 000-point kernel 2 % per iteration.
+constexpr int kFpsModeCert = 4;
+struct FpsPrefixCert {
+    unsigned mx = 0u, pos = 0u;
+    __device__ __forceinline__ void update(unsigned vbits) {
+        mx = vbits > mx ? vbits : mx;
+        pos += vbits != 0u ? 1u : 0u;
+    }
+    __device__ __forceinline__ int value(int m) const {
+        const int c = mx >= 0x501502F9u /* 1e10f */ ? 1 : 1 + (int)pos;
+        return c < m ? c : m;
+    }
+};
 template <int NT>
 __device__ __forceinline__ bool fps_prefix_shortcut(const FpsArgs &a, int cloud, int start_n, int n, int start_m, int m) {
     if (!a.prefix_in || (a.flags & TGN_FPS_TREE_TIES)) return false;
