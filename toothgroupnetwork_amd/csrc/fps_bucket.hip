@@ -40,6 +40,10 @@ namespace tgn {
 __device__ __forceinline__ float writelane_f32(float old, float val_uniform, int lane) {
     return lane_id() == lane ? val_uniform : old;
 }
+// HIP's __ballot(int) compiles to select(0/1) + compare-not-zero around the lane mask the predicate already is
+// (two to three extra instructions on a wave that issues one per ~5 cycles); the builtin takes the i1 directly.
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 __device__ __forceinline__ unsigned spread5(unsigned v) {  // abcde -> a00b00c00d00e
     return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6) | ((v & 16u) << 8);
 }
@@ -232,8 +236,10 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
         const float ey = fmaxf(fmaxf(blo1 - qy, qy - bhi1), 0.0f);
         const float ez = fmaxf(fmaxf(blo2 - qz, qz - bhi2), 0.0f);
         const float L = FMA ? dist_direct_fma(ex, ey, ez) : dist_direct_nofma(ex, ey, ez);
-        const bool need = lane < P && !(L >= bmax);
-        const unsigned long long mask = __ballot(need);
+        // lane mask of the compare, restricted to the P metadata lanes by a constant (a ballot of `lane < P && ...`
+        // makes the compiler rebuild the mask through a 0/1 select)
+        constexpr unsigned long long kSlotMask = P >= 64 ? ~0ull : ((1ull << P) - 1ull);
+        const unsigned long long mask = ballot64(!(L >= bmax)) & kSlotMask;
         if (dbg) {
             t1 = clock64();
             st_touched += __popcll(mask);
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
                             // Distances only shrink: unless a point that HELD the bucket's maximum gets closer, the
                             // bucket's maximum and arg-max are unchanged and the 64-lane refresh is skipped.
                             const float bold = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bmax), s));
-                            const bool unchanged = TGN_REFRESH_SKIP && __ballot(d[s] == bold && dd < d[s]) == 0;  // wave-uniform
+                            const bool unchanged = TGN_REFRESH_SKIP && ballot64(d[s] == bold && dd < d[s]) == 0;  // wave-uniform
                             const float nd = vmin_f32(dd, d[s]);  // min(d, tmp[k]) sampling_cuda_kernel.cu:55
                             d[s] = nd;
                             if (dbg && unchanged) ++st_skip;
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
                             const unsigned o = tab[(s * NW + wave) * kWave + lane];
                             if (s == wslot) dirty = true;
                             const float mx = wave_max_f32_dpp(nd);
-                            const unsigned long long eq = __ballot(nd == mx);
+                            const unsigned long long eq = ballot64(nd == mx);
                             bool win = nd == mx;
                             const unsigned ko = TREE ? compat_key((int)o, log2bs) : o;
                             if (__popcll(eq) != 1) {  // exact tie inside the bucket (rare): the smallest tie key wins
@@ -296,7 +302,8 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
         if (dirty) {
             const float v = lane < P ? bmax : -1.0f;
             wm = wave_max_f32_dpp(v);
-            const bool cand = lane < P && v == wm && wm >= 0.0f;
+            const unsigned long long cm = wm >= 0.0f ? (ballot64(v == wm) & kSlotMask) : 0ull;
+            const bool cand = ((cm >> lane) & 1ull) != 0ull;
             // coordinates and tie key of each candidate bucket's arg-max point (one LDS round trip; usually a single lane)
             unsigned kl = 0xFFFFFFFFu;
             float4 pm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -304,11 +311,10 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
                 pm = make_float4(bmeta[0][wave][lane], bmeta[1][wave][lane], bmeta[2][wave][lane], bmeta[3][wave][lane]);
                 kl = __float_as_uint(pm.w);
             }
-            const unsigned long long cm = __ballot(cand);
             int sl = cm ? __builtin_ctzll(cm) : 0;
             if (__popcll(cm) > 1) {
                 const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kl));
-                sl = __builtin_ctzll(__ballot(kl == kmin));
+                sl = __builtin_ctzll(ballot64(kl == kmin));
             }
             wkey = (unsigned)__builtin_amdgcn_readlane((int)kl, sl);
             wslot = sl;
@@ -346,23 +352,27 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             const unsigned vb = __float_as_uint(r0.x);
             unsigned mb = vb;
             // max over lanes 0..NW-1 lands in lane NW-1 after log2(NW) row_shr steps
-            asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
-                         : "+v"(mb));
-            if constexpr (NW > 4) asm volatile("v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(mb));
-            if constexpr (NW > 8) asm volatile("v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(mb));
-            static_assert(NW == 4 || NW == 8 || NW == 16, "wave count");
+            // (one asm statement per wave count: between statements the compiler adds wait states of its own)
+            static_assert(NW == 4 || NW == 8, "wave count");
+            if constexpr (NW == 4)
+                asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                             "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                             : "+v"(mb));
+            else
+                asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                             "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                             "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                             : "+v"(mb));
             mb = (unsigned)__builtin_amdgcn_readlane((int)mb, NW - 1);
             if constexpr (CERT) cert.update(mb);
-            const bool wc = lane < NW && vb == mb;
-            const unsigned kk = wc ? __float_as_uint(r0.y) : 0xFFFFFFFFu;
-            const unsigned long long wmask = __ballot(wc);
+            const unsigned long long wmask = ballot64(vb == mb) & ((1ull << NW) - 1ull);  // lanes 0..NW-1 hold the records
             int wl = __builtin_ctzll(wmask);
-            if (__popcll(wmask) > 1) {
+            if (__popcll(wmask) > 1) {  // equal maxima in several waves (rare): the smallest tie key wins
+                const unsigned kk = ((wmask >> lane) & 1ull) ? __float_as_uint(r0.y) : 0xFFFFFFFFu;
                 const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kk));
-                wl = __builtin_ctzll(__ballot(kk == kmin));
+                wl = __builtin_ctzll(ballot64(kk == kmin));
             }
-            kwin = (unsigned)__builtin_amdgcn_readlane((int)kk, wl);
+            kwin = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(r0.y), wl);
             qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.x), wl));
             qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.y), wl));
             qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.z), wl));
