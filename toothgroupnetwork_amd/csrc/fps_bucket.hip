@@ -219,8 +219,12 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
 
     // cached wave candidate (wave-uniform): value, tie key, coordinates
     float wm = -1.0f, wx = 0.0f, wy = 0.0f, wz = 0.0f;
-    unsigned wkey = 0;
+    unsigned wkey = 0, pub_bits = 0u, pub_key = 0xFFFFFFFFu;
     int wslot = -1;     // slot of the bucket that currently is this wave's candidate
+    // hand-off records: byte offsets of this wave's record (writer) and of record lane % NW (reader), parity 0
+    constexpr unsigned kRecParity = NW * 32u;
+    char *recb = (char *)rec;
+    unsigned wr_off = (unsigned)wave * 32u, rd_off = (unsigned)(lane & (NW - 1)) * 32u;
     bool dirty = true;  // bucket maxima only shrink: the candidate changes only when ITS bucket's arg-max changes
 
     // optional instrumentation (flag 0x100 + tmp): touched-bucket census and per-phase cycles of one wave
@@ -321,6 +325,8 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pm.x), sl));
             wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pm.y), sl));
             wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pm.z), sl));
+            pub_bits = wm < 0.0f ? 0u : __float_as_uint(wm);  // what the hand-off publishes (a wave without points: 0, ~0)
+            pub_key = wm < 0.0f ? 0xFFFFFFFFu : wkey;
             dirty = false;
         }
         if (dbg) t3 = clock64();
@@ -333,9 +339,9 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             qy = wy;
             qz = wz;
         } else {
-            if (lane == 0) {
-                rec[j & 1][wave][0] = make_float4(wm < 0.0f ? 0.0f : wm, __uint_as_float(wm < 0.0f ? 0xFFFFFFFFu : wkey), 0.0f, 0.0f);
-                rec[j & 1][wave][1] = make_float4(wx, wy, wz, 0.0f);
+            if (lane == 0) {  // {value bits, tie key} and {x, y, z}: 8 + 12 bytes of the wave's 32-byte record
+                *(uint2 *)(recb + wr_off) = make_uint2(pub_bits, pub_key);
+                *(float3 *)(recb + wr_off + 16) = make_float3(wx, wy, wz);
             }
             long long tc1 = 0, tc2 = 0;
             if (dbg) tc1 = clock64();
@@ -347,9 +353,11 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             }
             // distances are >= 0: their bit patterns order like unsigned integers
             // every lane reads record lane % NW (no exec juggling); lanes 0..NW-1 are the ones that count
-            const float4 r0 = rec[j & 1][lane & (NW - 1)][0];
-            const float4 r1 = rec[j & 1][lane & (NW - 1)][1];  // same LDS round trip
-            const unsigned vb = __float_as_uint(r0.x);
+            const uint2 r0 = *(const uint2 *)(recb + rd_off);
+            const float3 r1 = *(const float3 *)(recb + rd_off + 16);  // same LDS round trip
+            rd_off ^= kRecParity;  // double-buffered by iteration parity: one barrier per iteration is enough
+            wr_off ^= kRecParity;
+            const unsigned vb = r0.x;
             unsigned mb = vb;
             // max over lanes 0..NW-1 lands in lane NW-1 after log2(NW) row_shr steps
             // (one asm statement per wave count: between statements the compiler adds wait states of its own)
@@ -368,11 +376,11 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             const unsigned long long wmask = ballot64(vb == mb) & ((1ull << NW) - 1ull);  // lanes 0..NW-1 hold the records
             int wl = __builtin_ctzll(wmask);
             if (__popcll(wmask) > 1) {  // equal maxima in several waves (rare): the smallest tie key wins
-                const unsigned kk = ((wmask >> lane) & 1ull) ? __float_as_uint(r0.y) : 0xFFFFFFFFu;
+                const unsigned kk = ((wmask >> lane) & 1ull) ? r0.y : 0xFFFFFFFFu;
                 const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kk));
                 wl = __builtin_ctzll(ballot64(kk == kmin));
             }
-            kwin = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(r0.y), wl);
+            kwin = (unsigned)__builtin_amdgcn_readlane((int)r0.y, wl);
             qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.x), wl));
             qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.y), wl));
             qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.z), wl));
