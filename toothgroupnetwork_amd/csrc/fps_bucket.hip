@@ -236,8 +236,12 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
         long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
         if (dbg) t0 = clock64();
         // ---- A. which of my buckets can the new sample change? (monotone lower bound, exact) -------------
-        const float ex = fmaxf(fmaxf(blo0 - qx, qx - bhi0), 0.0f);
-        const float ey = fmaxf(fmaxf(blo1 - qy, qy - bhi1), 0.0f);
+        // (x, y) as packed fp32 pairs: a lone wave pays per instruction, not per lane-operation
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 qxy = {qx, qy};
+        const f2 lo = f2{blo0, blo1} - qxy, hi = qxy - f2{bhi0, bhi1};
+        const float ex = fmaxf(fmaxf(lo.x, hi.x), 0.0f);
+        const float ey = fmaxf(fmaxf(lo.y, hi.y), 0.0f);
         const float ez = fmaxf(fmaxf(blo2 - qz, qz - bhi2), 0.0f);
         const float L = FMA ? dist_direct_fma(ex, ey, ez) : dist_direct_nofma(ex, ey, ez);
         // lane mask of the compare, restricted to the P metadata lanes by a constant (a ballot of `lane < P && ...`
