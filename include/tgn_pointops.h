@@ -118,16 +118,16 @@ int tgn_furthestsampling_dense_ws(int B, int N, int S, const float *xyz, void *w
  *                 covers the requested sample count (and TGN_FPS_TREE_TIES is not set) the kernel writes the identity
  *                 (indices, new_xyz, prefix_out) and returns -- decided on the device, per cloud, no host sync.
  * The caller vouches for provenance: prefix_in must come from the prefix_out of the launch that produced xyz.
- * Packed form only -- prefix_ref (optional, (n,3) like xyz): the new_xyz that launch wrote; the kernel then takes the
- * shortcut for a cloud only if its coordinates equal prefix_ref bit for bit (for callers that gather p[idx]
- * themselves, blocks.py:70, so that tensor identity is lost).
+ * prefix_ref (optional, same layout as xyz): the new_xyz that launch wrote; the kernel then takes the shortcut for a
+ * cloud only if its coordinates equal prefix_ref bit for bit -- provenance by content, for callers that cannot
+ * vouch for it (the model gathers p[idx] itself, blocks.py:70, or hands tensors through arbitrary code).
  */
 int tgn_furthestsampling_prefix(int b, int n_max, const float *xyz, const int *offset, const int *new_offset,
                                 void *workspace, size_t workspace_bytes, void *idx, float *new_xyz, const int *prefix_in,
                                 const float *prefix_ref, int *prefix_out, int flags, tgn_stream_t stream);
 int tgn_furthestsampling_dense_prefix(int B, int N, int S, const float *xyz, void *workspace, size_t workspace_bytes,
-                                      void *idx, float *new_xyz, const int *prefix_in, int *prefix_out, int flags,
-                                      tgn_stream_t stream);
+                                      void *idx, float *new_xyz, const int *prefix_in, const float *prefix_ref,
+                                      int *prefix_out, int flags, tgn_stream_t stream);
 
 /* kNN (pointops.py:30-45): b segments; idx (m,nsample) int32; dist2 (m,nsample) squared, ascending. */
 int tgn_knnquery(int b, int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,

@@ -28,7 +28,7 @@ def _expected_certificate(seq):
     return m
 
 
-def _fps(dev, xyz, S, cert_in=None, flags=None, want_cert=True):
+def _fps(dev, xyz, S, cert_in=None, flags=None, want_cert=True, ref=None):
     from toothgroupnetwork_amd import _lib
     L = _lib.lib()
     B, N, _ = xyz.shape
@@ -38,7 +38,7 @@ def _fps(dev, xyz, S, cert_in=None, flags=None, want_cert=True):
     nbytes = int(L.tgn_fps_workspace_bytes(B, N))
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
     _lib.check(L.tgn_furthestsampling_dense_prefix(B, N, S, _lib.ptr(xyz), _lib.ptr(ws), nbytes, _lib.ptr(idx),
-                                                   _lib.ptr(new_xyz), _lib.ptr(cert_in), _lib.ptr(cert),
+                                                   _lib.ptr(new_xyz), _lib.ptr(cert_in), _lib.ptr(ref), _lib.ptr(cert),
                                                    _lib.FPS_LOCAL_INDEX if flags is None else flags, _lib.stream()))
     return idx, new_xyz, cert
 
@@ -134,18 +134,34 @@ def test_modules_hand_the_certificate_on_and_results_do_not_change(dev, monkeypa
     nx1, _ = U.sample_and_group(800, 0.1, 8, xyz, None)
     nx2, _ = U.sample_and_group(200, 0.2, 8, nx1, None)
     assert U.fps_prefix_stats["offered"] == 1
+    assert torch.equal(U.farthest_point_sample(nx1, 200)[0], torch.arange(200, device=dev))
     monkeypatch.setattr(U, "FPS_PREFIX", False)
     px1, _ = U.sample_and_group(800, 0.1, 8, xyz, None)
     px2, _ = U.sample_and_group(200, 0.2, 8, px1, None)
     assert torch.equal(nx2, px2)
-    # a tensor that was modified in place after sampling is no longer recognised
+    # provenance is by CONTENT: a tensor modified after sampling is offered the certificate, fails the on-device
+    # comparison and is sampled for real; an untouched copy passes
     monkeypatch.setattr(U, "FPS_PREFIX", True)
     U.fps_prefix_clear()
-    U.fps_prefix_stats["offered"] = 0
     nx1, _ = U.sample_and_group(800, 0.1, 8, xyz, None)
-    nx1.mul_(1.0)
-    U.sample_and_group(200, 0.2, 8, nx1, None)
-    assert U.fps_prefix_stats["offered"] == 0
+    moved = nx1 + torch.randn_like(nx1) * 0.05
+    got = U.farthest_point_sample(moved, 200)
+    U.fps_prefix_clear()
+    monkeypatch.setattr(U, "FPS_PREFIX", False)
+    assert torch.equal(got, U.farthest_point_sample(moved, 200))
+    assert not torch.equal(got[0], torch.arange(200, device=dev))
+
+
+def test_dense_prefix_ref_is_checked_per_cloud(dev, oracle):
+    """one cloud of the batch altered: that cloud runs, the other takes the shortcut, both match the oracle"""
+    x = np.stack([synth.arch_cloud(5000, 21, False), synth.arch_cloud(5000, 22, False)])
+    idx, seq, cert = _fps(dev, T(x, dev), 1000)
+    altered = seq.clone()
+    altered[1, 10:20] = altered[1, 10:20].flip(0)          # same points, different order: no longer the sequence
+    idx2, _, cert2 = _fps(dev, altered, 300, cert_in=cert, ref=seq)
+    want = oracle.farthest_point_sample(altered.cpu().numpy(), 300)
+    assert np.array_equal(idx2.cpu().numpy(), want)
+    assert np.array_equal(want[0], np.arange(300)) and not np.array_equal(want[1], np.arange(300))
 
 
 def test_hotpath_with_prefix_certificates_equals_plain(dev):

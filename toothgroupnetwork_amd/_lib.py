@@ -44,7 +44,7 @@ SIGNATURES = {
     "tgn_furthestsampling_ws": (c_int, [c_int, c_int, _P, _P, _P, _P, c_size_t, _P, _P, c_int, _P]),
     "tgn_furthestsampling_dense_ws": (c_int, [c_int, c_int, c_int, _P, _P, c_size_t, _P, _P, c_int, _P]),
     "tgn_furthestsampling_prefix": (c_int, [c_int, c_int, _P, _P, _P, _P, c_size_t, _P, _P, _P, _P, _P, c_int, _P]),
-    "tgn_furthestsampling_dense_prefix": (c_int, [c_int, c_int, c_int, _P, _P, c_size_t, _P, _P, _P, _P, c_int, _P]),
+    "tgn_furthestsampling_dense_prefix": (c_int, [c_int, c_int, c_int, _P, _P, c_size_t, _P, _P, _P, _P, _P, c_int, _P]),
     "tgn_knnquery": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "tgn_knnquery_workspace_bytes": (c_size_t, [c_int]),
     "tgn_knnquery_ws": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),

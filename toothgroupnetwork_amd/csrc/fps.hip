@@ -358,13 +358,13 @@ TGN_API int tgn_furthestsampling_prefix(int b, int n_max, const float *xyz, cons
 
 TGN_API int tgn_furthestsampling_dense_prefix(int B, int N, int S, const float *xyz, void *workspace,
                                               size_t workspace_bytes, void *idx, float *new_xyz, const int *prefix_in,
-                                              int *prefix_out, int flags, tgn_stream_t stream) {
+                                              const float *prefix_ref, int *prefix_out, int flags, tgn_stream_t stream) {
     if (N < 0 || S < 0) {
         set_error("tgn_furthestsampling_dense_prefix: negative size");
         return TGN_ERR_INVALID_ARGUMENT;
     }
     FpsArgs a{xyz, nullptr, nullptr, N, S, idx, new_xyz, (float *)workspace, workspace, workspace_bytes, N, flags, 0,
-              prefix_in, prefix_out, nullptr};
+              prefix_in, prefix_out, prefix_ref};
     return fps_dispatch(B, N, a, (hipStream_t)stream);
 }
 

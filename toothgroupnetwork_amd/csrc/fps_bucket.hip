@@ -40,10 +40,6 @@ namespace tgn {
 __device__ __forceinline__ float writelane_f32(float old, float val_uniform, int lane) {
     return lane_id() == lane ? val_uniform : old;
 }
-// HIP's __ballot(int) compiles to select(0/1) + compare-not-zero around the lane mask the predicate already is
-// (two to three extra instructions on a wave that issues one per ~5 cycles); the builtin takes the i1 directly.
-__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-
 __device__ __forceinline__ unsigned spread5(unsigned v) {  // abcde -> a00b00c00d00e
     return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6) | ((v & 16u) << 8);
 }

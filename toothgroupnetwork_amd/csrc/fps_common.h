@@ -171,18 +171,23 @@ __device__ __forceinline__ unsigned wave_min_u32_shfl(unsigned v) {
 // values.  One LDS slot per wave, one barrier.  Returns the winning tie key (0xFFFFFFFF if no lane had a value).
 // The common case (a single lane / a single wave holds the maximum) costs one 6-instruction DPP max, a ballot and a
 // readlane per level; exact ties fall back to a key minimum.
+// HIP's __ballot(int) compiles to select(0/1) + compare-not-zero around the lane mask the predicate already is
+// (two to three extra instructions on a wave that issues one per ~5 cycles); the builtin takes the i1 directly, and
+// lane-range restrictions are applied to the 64-bit result as constants.
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 template <int NW>
 __device__ __forceinline__ unsigned fps_block_argmax(float best, unsigned key, unsigned long long (*slots)[NW],
                                                      int parity, int wave, int lane, unsigned &vbits) {
+    static_assert(NW == 1 || NW == 4 || NW == 8 || NW == 16, "wave count");
     const float wm = wave_max_f32_dpp(best);
-    const bool mine = best == wm && wm >= 0.0f;
-    const unsigned long long eq = __ballot(mine);
+    const unsigned long long eq = wm >= 0.0f ? ballot64(best == wm) : 0ull;  // wm is wave-uniform
     unsigned wkey = 0xFFFFFFFFu;
     if (eq) {
         if (__popcll(eq) == 1)
             wkey = (unsigned)__builtin_amdgcn_readlane((int)key, __builtin_ctzll(eq));
         else
-            wkey = wave_min_u32_dpp(mine ? key : 0xFFFFFFFFu);
+            wkey = wave_min_u32_dpp(((eq >> lane) & 1ull) ? key : 0xFFFFFFFFu);
     }
     if constexpr (NW == 1) {
         vbits = wm < 0.0f ? 0u : __float_as_uint(wm);
@@ -191,21 +196,31 @@ __device__ __forceinline__ unsigned fps_block_argmax(float best, unsigned key, u
         // distances are >= 0: their bit patterns order like unsigned integers
         if (lane == 0) slots[parity][wave] = pack64(wm < 0.0f ? 0u : __float_as_uint(wm), wkey);
         __syncthreads();
-        const unsigned long long v = lane < NW ? slots[parity][lane] : pack64(0u, 0xFFFFFFFFu);
+        // every lane reads slot lane % NW (no exec juggling); the max over lanes 0..NW-1 lands in lane NW-1 after
+        // log2(NW) row_shr steps (one asm statement: between statements the compiler adds wait states of its own)
+        const unsigned long long v = slots[parity][lane & (NW - 1)];
         const unsigned vb = (unsigned)(v >> 32), vk = (unsigned)v;
         unsigned mb = vb;
-        asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
-                     : "+v"(mb));
-        mb = (unsigned)__builtin_amdgcn_readlane((int)mb, 15);
+        if constexpr (NW == 4)
+            asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                         : "+v"(mb));
+        else if constexpr (NW == 8)
+            asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                         : "+v"(mb));
+        else
+            asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                         : "+v"(mb));
+        mb = (unsigned)__builtin_amdgcn_readlane((int)mb, NW - 1);
         vbits = mb;
-        const bool wc = lane < NW && vb == mb;
-        const unsigned kk = wc ? vk : 0xFFFFFFFFu;
-        const unsigned long long wmask = __ballot(wc);
-        if (__popcll(wmask) == 1) return (unsigned)__builtin_amdgcn_readlane((int)kk, __builtin_ctzll(wmask));
-        return wave_min_u32_dpp(kk);
+        const unsigned long long wmask = ballot64(vb == mb) & ((1ull << NW) - 1ull);
+        if (__popcll(wmask) == 1) return (unsigned)__builtin_amdgcn_readlane((int)vk, __builtin_ctzll(wmask));
+        return wave_min_u32_dpp(((wmask >> lane) & 1ull) ? vk : 0xFFFFFFFFu);
     }
 }
 

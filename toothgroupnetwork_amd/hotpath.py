@@ -132,7 +132,7 @@ class HotPath:
                                                       ptr(lv["new_xyz"]), _lib.FPS_LOCAL_INDEX, st), "fps")
         cert_in = levels[i - 1]["cert"] if i > 0 else None   # level i samples level i-1's new_xyz
         return check(L.tgn_furthestsampling_dense_prefix(self.B, lv["N"], lv["S"], ptr(cur_xyz), None, 0, ptr(lv["fps_idx"]),
-                                                         ptr(lv["new_xyz"]), ptr(cert_in), ptr(lv["cert"]),
+                                                         ptr(lv["new_xyz"]), ptr(cert_in), None, ptr(lv["cert"]),
                                                          _lib.FPS_LOCAL_INDEX, st), "fps")
 
     def _run_pipelined(self, xyz, feats, inputs_on_current_stream=True):

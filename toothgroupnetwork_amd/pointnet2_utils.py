@@ -126,49 +126,25 @@ def index_points(points, idx):
         idx = idx.long()
     points = _f32c(points)
     out = _IndexPoints.apply(points, idx.contiguous())
-    _fps_prefix_follow(points, idx, out)
     return out
 
 
 # ---------------------------------------------------------------------------------------------
 # FPS of an FPS result is the identity (include/tgn_pointops.h, tgn_furthestsampling_dense_prefix).  Every
-# set-abstraction level after the first samples the previous level's new_xyz (pointnet2_utils.py:160 /:276), so
-# the kernel that produced new_xyz also leaves a per-cloud certificate, and the next FPS over that very tensor is handed
-# it; the decision (identity or real run) is taken on the device, per cloud.  Provenance is tracked by tensor identity:
-# (storage pointer, version counter, shape), with the tensors kept alive so that a pointer cannot be recycled.
-# TGN_FPS_PREFIX=0 turns the whole mechanism off.
+# set-abstraction level after the first samples the previous level's new_xyz (pointnet2_utils.py:160 /:276), so the
+# kernel that produced new_xyz also leaves a per-cloud certificate.  A later FPS whose input has the shape of a recent
+# result is offered that result and its certificate; the kernel compares the input with the stored coordinates bit for
+# bit, per cloud, and only then writes 0..S-1 instead of iterating -- provenance by content, nothing is assumed about
+# how the tensor travelled (module round trips, index_points(xyz, fps_idx), copies).  TGN_FPS_PREFIX=0 turns it off.
 # ---------------------------------------------------------------------------------------------
 FPS_PREFIX = os.environ.get("TGN_FPS_PREFIX", "1") != "0"
-_FPS_MEMO_CAP = 8
-_fps_seq_memo = {}   # key(new_xyz tensor)  -> (tensor, certificate (B,) int32)
-_fps_idx_memo = {}   # key(fps index tensor) -> (tensor, key(xyz it indexes), certificate)
+_FPS_RESULTS_CAP = 8
+_fps_results = []    # (B, S, device, new_xyz (B,S,3), certificate (B,) int32), most recent last
 fps_prefix_stats = {"offered": 0}
 
 
-def _tkey(t):
-    return (t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device.index)
-
-
-def _memo_put(memo, key, value):
-    memo.pop(key, None)
-    memo[key] = value
-    while len(memo) > _FPS_MEMO_CAP:
-        memo.pop(next(iter(memo)))
-
-
 def fps_prefix_clear():
-    _fps_seq_memo.clear()
-    _fps_idx_memo.clear()
-
-
-def _fps_prefix_follow(points, idx, out):
-    """index_points(xyz, fps_idx) of an index tensor that farthest_point_sample returned for this xyz yields the FPS
-    sequence itself (the reference's own way of getting new_xyz, pointnet2_utils.py:161): pass the certificate on."""
-    if not FPS_PREFIX or not _fps_idx_memo or idx.dim() != 2 or out.shape[-1] != 3:
-        return
-    hit = _fps_idx_memo.get(_tkey(idx))
-    if hit is not None and hit[1] == _tkey(points):
-        _memo_put(_fps_seq_memo, _tkey(out), (out, hit[2]))
+    del _fps_results[:]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -179,29 +155,31 @@ def _fps_dense(xyz, npoint, want_coords=False, cuda_compat=False):
     npoint = as_int(npoint)
     xyz = _f32c(xyz.detach())
     B, N, _ = xyz.shape
+    use_prefix = FPS_PREFIX and not cuda_compat      # the tree tie order of cuda-compat breaks the identity
     idx = torch.empty(B, npoint, dtype=torch.int64, device=xyz.device)
-    new_xyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=xyz.device) if want_coords else None
+    new_xyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=xyz.device) if (want_coords or use_prefix) else None
     if B == 0 or npoint == 0:
-        return idx, new_xyz
+        return idx, (new_xyz if want_coords else None)
     from .pointops import fps_workspace
     ws, nbytes = fps_workspace(B, N, B * N, xyz.device)
     flags = _lib.FPS_LOCAL_INDEX | _lib.FPS_INDEX64 | (_lib.FPS_CUDA_COMPAT if cuda_compat else 0)
-    use_prefix = FPS_PREFIX and not cuda_compat      # the tree tie order of cuda-compat breaks the identity
-    cert_in = cert_out = None
+    cert_in = ref = cert_out = None
     if use_prefix:
-        hit = _fps_seq_memo.get(_tkey(xyz))
-        if hit is not None:
-            cert_in = hit[1]
-            fps_prefix_stats["offered"] += 1
+        for k in range(len(_fps_results) - 1, -1, -1):
+            rB, rS, rdev, rxyz, rcert = _fps_results[k]
+            if rB == B and rS == N and rdev == xyz.device:
+                cert_in, ref = rcert, rxyz
+                fps_prefix_stats["offered"] += 1
+                break
         cert_out = torch.empty(B, dtype=torch.int32, device=xyz.device)
     check(lib().tgn_furthestsampling_dense_prefix(B, N, npoint, ptr(xyz), ptr(ws), nbytes, ptr(idx), ptr(new_xyz),
-                                                  ptr(cert_in), ptr(cert_out), flags, stream()),
+                                                  ptr(cert_in), ptr(ref), ptr(cert_out), flags, stream()),
           "tgn_furthestsampling_dense")
     if use_prefix:
-        if new_xyz is not None:
-            _memo_put(_fps_seq_memo, _tkey(new_xyz), (new_xyz, cert_out))
-        _memo_put(_fps_idx_memo, _tkey(idx), (idx, _tkey(xyz), cert_out))
-    return idx, new_xyz
+        # the stored coordinates must stay what the kernel wrote: a private copy if the caller gets the tensor too
+        _fps_results.append((B, npoint, xyz.device, new_xyz.clone() if want_coords else new_xyz, cert_out))
+        del _fps_results[:-_FPS_RESULTS_CAP]
+    return idx, (new_xyz if want_coords else None)
 
 
 def farthest_point_sample(xyz, npoint):

@@ -96,7 +96,7 @@ def fps_with_coords(xyz, offset, new_offset, cuda_compat=False):
                                             ptr(new_xyz), ptr(cert_in), ptr(ref), ptr(cert_out), flags, stream()),
           "tgn_furthestsampling")
     if use_prefix:
-        _fps_results.append((noff_h, xyz.device, new_xyz, cert_out))
+        _fps_results.append((noff_h, xyz.device, new_xyz.clone(), cert_out))  # private copy: the caller may write to its own
         del _fps_results[:-_FPS_RESULTS_CAP]
     return idx, new_xyz
 
