@@ -106,6 +106,12 @@ def test_gather_family_random_shapes(dev, oracle, seed):
     c = wc * int(rng.choice([1, 3, 5, 16, 33]))
     f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(dev)
     npy = lambda t: t.detach().cpu().numpy()
+
+    def close(got, want):
+        # backward passes accumulate with fp32 atomics in arbitrary order (up to m*ns terms into one row when n is
+        # tiny): the tolerance follows the magnitude of the sums
+        tol = 2e-5 * max(1.0, float(np.abs(want).max()))
+        np.testing.assert_allclose(got, want, atol=tol, rtol=1e-4)
     # grouping: (n, c) rows gathered by (m, ns)
     feat = f(n, c).requires_grad_()
     idx = torch.from_numpy(rng.integers(0, n, (m, ns)).astype(np.int32)).to(dev)
@@ -113,7 +119,7 @@ def test_gather_family_random_shapes(dev, oracle, seed):
     assert np.array_equal(npy(out), oracle.grouping_forward(npy(feat), npy(idx)))
     go = f(m, ns, c)
     out.backward(go)
-    np.testing.assert_allclose(npy(feat.grad), oracle.grouping_backward(npy(go), npy(idx), n), atol=2e-5, rtol=1e-5)
+    close(npy(feat.grad), oracle.grouping_backward(npy(go), npy(idx), n))
     # subtraction / aggregation: idx is (n, ns) over the same n rows
     idx2 = torch.from_numpy(rng.integers(0, n, (n, ns)).astype(np.int32)).to(dev)
     a, b = f(n, c).requires_grad_(), f(n, c).requires_grad_()
@@ -122,14 +128,14 @@ def test_gather_family_random_shapes(dev, oracle, seed):
     go = f(n, ns, c)
     out.backward(go)
     g1, g2 = oracle.subtraction_backward(npy(idx2), npy(go))
-    np.testing.assert_allclose(npy(a.grad), g1, atol=2e-5, rtol=1e-5)
-    np.testing.assert_allclose(npy(b.grad), g2, atol=2e-5, rtol=1e-5)
+    close(npy(a.grad), g1)
+    close(npy(b.grad), g2)
     x, pos, w = f(n, c).requires_grad_(), f(n, ns, c).requires_grad_(), f(n, ns, wc).requires_grad_()
     out = P.aggregation(x, pos, w, idx2)
-    np.testing.assert_allclose(npy(out), oracle.aggregation_forward(npy(x), npy(pos), npy(w), npy(idx2)), atol=2e-5, rtol=1e-5)
+    close(npy(out), oracle.aggregation_forward(npy(x), npy(pos), npy(w), npy(idx2)))
     go = f(n, c)
     out.backward(go)
     gi, gp, gw = oracle.aggregation_backward(npy(x), npy(pos), npy(w), npy(idx2), npy(go))
-    np.testing.assert_allclose(npy(x.grad), gi, atol=1e-4, rtol=1e-4)
-    np.testing.assert_allclose(npy(pos.grad), gp, atol=2e-5, rtol=1e-5)
-    np.testing.assert_allclose(npy(w.grad), gw, atol=1e-4, rtol=1e-4)
+    close(npy(x.grad), gi)
+    close(npy(pos.grad), gp)
+    close(npy(w.grad), gw)
