@@ -87,6 +87,7 @@ def main():
                     "grouping of step k on two HIP streams (double-buffered); 0: one stream")
     ap.add_argument("--fps-prefix", type=int, default=0, help="1: levels 2 and 3 use the FPS-of-an-FPS-result identity "
                     "(exact, certificate checked on the device) instead of iterating; reported separately, never the headline")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra with_fps_prefix_identity measurement (profiling runs)")
     args = ap.parse_args()
 
     rank, local_rank, world, device = sharding.init_from_env()
@@ -176,7 +177,7 @@ def main():
                                  "unit": "GB/s", "frac": galgo / (avg[gk] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "traffic": (pmc[gk]["fetch"] + pmc[gk]["write"]) if gk in pmc and B == 256 else None,
                                  "algorithmic_bytes_per_launch": galgo, "avg_launch_ms": avg[gk]}
-    if world == 1 and not args.fps_prefix:
+    if world == 1 and not args.fps_prefix and not args.no_alt:
         # the same steps with levels 2 and 3 answered by the FPS-of-an-FPS-result identity (exact):
         # reported next to the headline, never as the headline
         del hp

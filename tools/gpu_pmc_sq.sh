@@ -10,7 +10,7 @@ for SET in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" \
            "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM"; do
   i=$((i+1))
   (cd /tmp && timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcs_$i -o pmc -- \
-      python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-meshes 0 --no-kernel-timing --pipeline 0 > $GRAFT_REPO_ROOT/gpurun_out/pmcs_$i.log 2>&1)
+      python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-meshes 0 --no-alt --no-kernel-timing --pipeline 0 > $GRAFT_REPO_ROOT/gpurun_out/pmcs_$i.log 2>&1)
 done
 python - <<'PY'
 import csv, glob, collections
