@@ -55,15 +55,19 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
     constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0, CERT = (MODE & kFpsModeCert) != 0;
     constexpr int NW = NT / kWave;
     constexpr int CAP = NT * P;
-    constexpr int M = next_pow2(CAP);  // sort size
-    constexpr int PER = M / NT;
     static_assert(P <= kWave, "bucket metadata lives in lanes 0..P-1");
-    static_assert(M <= 32768, "15-bit local indices");
-    __shared__ unsigned sortbuf[M];  // keys, then (aliased) the u16 sorted-position -> point-index table
+    static_assert(CAP <= 32768, "15-bit local indices");
+    // Set-up: 32 768 Z-order cells, two 16-bit counters per word (a cloud has < 65 536 points); once the points are
+    // placed the same 64 KiB hold the result staging buffer and the bucket arg-max planes.
+    constexpr int kCellWords = 16384;
+    __shared__ unsigned cells[kCellWords];
+    __shared__ unsigned short tab[CAP];  // sorted position -> local point index (0xFFFF = padding)
     __shared__ float red[6][NW];
+    __shared__ int wave_tot[NW];
     __shared__ float4 rec[2][NW][2];  // per wave: {value, tie key} and {x, y, z} of its candidate
-    __shared__ float4 outbuf[NT];      // results of the current chunk of NT iterations
-    __shared__ float bmeta[4][NW][P];  // per bucket: x, y, z, lane of the point holding its largest min-distance
+    float4 *outbuf = (float4 *)cells;                                  // [NT]: results of the current chunk of NT iterations
+    float (*bmeta)[NW][P] = (float (*)[NW][P])(cells + NT * 4);        // [4][NW][P]: per bucket x, y, z, tie key of its arg-max
+    static_assert((NT * 4 + 4 * NW * P) <= kCellWords, "aliased buffers fit");
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -112,50 +116,60 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
         gscale[c] = (ext > 0.0f && ext < 3.0e38f) ? 32.0f / ext : 0.0f;
     }
 
-    // ---- 2. sort keys: (15-bit Z-order cell code << 15) | local index ; padding sorts last --------------
-    for (int i = tid; i < M; i += NT) {
-        unsigned key = 0xFFFFFFFFu;
-        if (i < n) {
-            unsigned cc[3];
+    // ---- 2. counting sort by 15-bit Z-order cell (LDS atomics; the order inside a cell is arbitrary -- it only decides
+    //         which of two neighbouring buckets a point lands in, never a result) -------------------------------------
+    auto cell_of = [&](int i) -> unsigned {
+        unsigned cc[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float t = (base[(size_t)i * 3 + c] - glo[c]) * gscale[c];
-                t = fminf(fmaxf(t, 0.0f), 31.0f);  // NaN -> 0
-                cc[c] = (unsigned)(int)t;
-            }
-            const unsigned code = spread5(cc[0]) | (spread5(cc[1]) << 1) | (spread5(cc[2]) << 2);
-            key = (code << 15) | (unsigned)i;
+        for (int c = 0; c < 3; ++c) {
+            float t = (base[(size_t)i * 3 + c] - glo[c]) * gscale[c];
+            t = fminf(fmaxf(t, 0.0f), 31.0f);  // NaN -> 0
+            cc[c] = (unsigned)(int)t;
         }
-        sortbuf[i] = key;
+        return spread5(cc[0]) | (spread5(cc[1]) << 1) | (spread5(cc[2]) << 2);
+    };
+    for (int i = tid; i < kCellWords; i += NT) cells[i] = 0u;
+    for (int i = n + tid; i < CAP; i += NT) tab[i] = (unsigned short)0xFFFF;
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+        const unsigned code = cell_of(i);
+        atomicAdd(&cells[code >> 1], 1u << ((code & 1u) << 4));
     }
     __syncthreads();
-    // ---- 3. bitonic sort in LDS ---------------------------------------------------------------------------
-    for (int k = 2; k <= M; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < M / 2; t += NT) {
-                const int i = 2 * t - (t & (j - 1));
-                const int l = i + j;
-                const unsigned va = sortbuf[i], vb = sortbuf[l];
-                const bool up = (i & k) == 0;
-                if ((va > vb) == up) {
-                    sortbuf[i] = vb;
-                    sortbuf[l] = va;
-                }
-            }
-            __syncthreads();
+    {   // exclusive prefix over the 32 768 counters: thread t owns words [t*W, (t+1)*W)
+        constexpr int W = kCellWords / NT;
+        unsigned sum = 0;
+#pragma unroll 4
+        for (int i = 0; i < W; ++i) {
+            const unsigned w = cells[tid * W + i];
+            sum += (w & 0xFFFFu) + (w >> 16);
+        }
+        unsigned incl = sum;  // inclusive scan over the wave, then over the waves
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const unsigned t = (unsigned)__shfl_up((int)incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == kWave - 1) wave_tot[wave] = (int)incl;
+        __syncthreads();
+        unsigned run = incl - sum;
+        for (int w = 0; w < wave; ++w) run += (unsigned)wave_tot[w];
+#pragma unroll 4
+        for (int i = 0; i < W; ++i) {
+            const unsigned w = cells[tid * W + i];
+            const unsigned lo = w & 0xFFFFu, hi = w >> 16;
+            cells[tid * W + i] = run | ((run + lo) << 16);  // start offsets (< 65 536 each)
+            run += lo + hi;
         }
     }
-    // ---- 4. compact to the u16 table tab[sorted position] = local point index (0xFFFF = padding) ---------
-    unsigned short *tab = (unsigned short *)sortbuf;
-    {
-        unsigned r[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) r[i] = sortbuf[tid * PER + i];
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < PER; ++i) tab[tid * PER + i] = r[i] == 0xFFFFFFFFu ? (unsigned short)0xFFFF : (unsigned short)(r[i] & 0x7FFFu);
-        __syncthreads();
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+        const unsigned code = cell_of(i);
+        const unsigned sh = (code & 1u) << 4;
+        const unsigned old = atomicAdd(&cells[code >> 1], 1u << sh);  // cursor of the cell; never carries into its neighbour
+        tab[(old >> sh) & 0xFFFFu] = (unsigned short)i;
     }
+    __syncthreads();
 
     // ---- 5. my P points.  Z-order bucket b (sorted positions [64b, 64b+64)) goes to wave b % NW, slot b / NW:
     //         neighbouring buckets -- the ones a new sample touches together -- sit in DIFFERENT waves, so
