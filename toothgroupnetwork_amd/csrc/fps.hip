@@ -185,9 +185,10 @@ struct FpsConfig {
     int nt, p;
 };
 
-// Ordered by capacity.  Small clouds use few waves (no cross-wave hand-off at NT=64).
+// Ordered by capacity; of two shapes with the same capacity the first is taken.  Fewer waves mean a cheaper hand-off:
+// measured per iteration at 4096 points 256x16 0.71 us, 512x8 0.73, 1024x4 0.74; at 2048 points 256x8 0.55, 512x8 0.73.
 #define TGN_FPS_CONFIGS(X) \
-    X(64, 1) X(64, 2) X(64, 4) X(64, 8) X(64, 16) X(256, 8) X(512, 8) X(256, 16) \
+    X(64, 1) X(64, 2) X(64, 4) X(64, 8) X(64, 16) X(256, 8) X(256, 16) X(512, 8) \
     X(512, 16) X(512, 24) X(512, 32) X(1024, 24) X(512, 48) X(512, 56)
 
 static const FpsConfig kConfigs[] = {
