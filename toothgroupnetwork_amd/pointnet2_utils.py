@@ -385,6 +385,12 @@ def _can_fuse(module, *tensors):
     return True
 
 
+def _fuse_pays(N, S, K, c_in, c1):
+    """The fused first layer trades the grouped tensor (S*K rows of c_in) for a per-point one (N rows of c1): worth it
+    once the former is the larger (sa1 of the reference net, c_in = 9 -> 128 channels: it is not; measured 0.89x)."""
+    return S * K * c_in > N * c1
+
+
 def sa_first_layer(xyz, new_xyz, points, idx, conv, bn, xyz_first, reduce_max=False):
     """relu(bn(conv(grouped))) of the FIRST shared-MLP layer without ever building `grouped`
     (pointnet2_utils.py:162-169 + 229-233, or 281-292 for Msg).  The 1x1 convolution commutes with the gather:
@@ -450,7 +456,9 @@ class PointNetSetAbstraction(nn.Module):
         xyz = xyz.permute(0, 2, 1)
         if points is not None:
             points = points.permute(0, 2, 1)
-        if not self.group_all and _can_fuse(self, xyz, points) and len(self.mlp_convs) > 0:
+        if (not self.group_all and len(self.mlp_convs) > 0 and _can_fuse(self, xyz, points)
+                and _fuse_pays(xyz.shape[1], self.npoint, self.nsample, 3 + (0 if points is None else points.shape[2]),
+                               self.mlp_convs[0].out_channels)):
             # eval fast path: FPS (+coordinates) -> ball query -> fused first layer; `grouped` is never built
             xyz_c = _f32c(xyz)
             points_c = None if points is None else _f32c(points)
@@ -512,7 +520,8 @@ class PointNetSetAbstractionMsg(nn.Module):
         for i, radius in enumerate(self.radius_list):
             K = self.nsample_list[i]
             group_idx = query_ball_point(radius, K, xyz_c, new_xyz)
-            if fuse:
+            if fuse and _fuse_pays(xyz_c.shape[1], S, K, 3 + (0 if points_c is None else points_c.shape[2]),
+                                   self.conv_blocks[i][0].out_channels):
                 convs, bns = self.conv_blocks[i], self.bn_blocks[i]
                 single = len(convs) == 1
                 y = sa_first_layer(xyz_c, new_xyz, points_c, group_idx, convs[0], bns[0], xyz_first=False,
