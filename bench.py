@@ -35,9 +35,8 @@ from toothgroupnetwork_amd import hotpath, sharding, synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured-achievable
 
 
-def make_inputs(B, device, seed):
+def make_inputs(B, device, seed, shape):
     """B synthetic 24 000-point scans (xyz + normals) and synthetic level-2/3 features, resident in HBM."""
-    shape = hotpath.SHAPE_A
     n_unique = min(B, 16)  # 16 distinct arch scans, tiled: generation cost stays bounded
     scans = synth.scan_batch(n_unique, shape["n"], "arch", seed=seed)
     scans = np.concatenate([scans] * ((B + n_unique - 1) // n_unique), axis=0)[:B]
@@ -51,27 +50,28 @@ def make_inputs(B, device, seed):
     return xyz, feats, scans
 
 
-def cpu_baseline(scans, budget_meshes):
+def cpu_baseline(scans, budget_meshes, shape):
     """The oracle (C port of the reference algorithm) on a bounded sample, all host cores (OpenMP)."""
     from oracle import cpu as O
-    shape = hotpath.SHAPE_A
     cores = O.num_threads()
     sample = scans[:budget_meshes]
     t0 = time.perf_counter()
     xyz = np.ascontiguousarray(sample[:, :, :3])
     pts = sample
     rng = np.random.default_rng(0)
-    for S, r, K, D in zip(shape["npoint"], shape["radius"], shape["nsample"], shape["d"]):
+    xyz_first = shape.get("xyz_first", True)
+    for li, (S, r, K, D) in enumerate(zip(shape["npoint"], shape["radius"], shape["nsample"], shape["d"])):
         fidx = O.farthest_point_sample(xyz, S)
         new_xyz = O.index_points(xyz, fidx)
-        gidx = O.query_ball_point(r, K, xyz, new_xyz)
-        O.group_points(xyz, new_xyz, pts, gidx, xyz_first=True)
+        for rb, kb in hotpath._branches(r, K):
+            gidx = O.query_ball_point(rb, kb, xyz, new_xyz)
+            O.group_points(xyz, new_xyz, pts, gidx, xyz_first=xyz_first)
         xyz = np.ascontiguousarray(new_xyz)
-        nxt = shape["d"][shape["npoint"].index(S) + 1] if S != shape["npoint"][-1] else 0
+        nxt = shape["d"][li + 1] if li + 1 < len(shape["d"]) else 0
         pts = rng.standard_normal((sample.shape[0], S, nxt), dtype=np.float32) if nxt else None
     dt = time.perf_counter() - t0
     return {"value": sample.shape[0] / dt, "unit": "meshes/s", "cores": cores, "kind": "port",
-            "sample": f"{sample.shape[0]} scans x Shape A (3 levels) through oracle/pointops_oracle.c, "
+            "sample": f"{sample.shape[0]} scans x {len(shape['npoint'])} levels through oracle/pointops_oracle.c, "
                       f"{cores} OpenMP threads, {dt:.1f} s"}
 
 
@@ -87,6 +87,8 @@ def main():
                     "grouping of step k on two HIP streams (double-buffered); 0: one stream")
     ap.add_argument("--fps-prefix", type=int, default=0, help="1: levels 2 and 3 use the FPS-of-an-FPS-result identity "
                     "(exact, certificate checked on the device) instead of iterating; reported separately, never the headline")
+    ap.add_argument("--shape", default="A", choices=["A", "B"], help="A: the headline configuration (BASELINE.json config 2); "
+                    "B: what the reference net instantiates (multi-scale grouping, SURVEY.md 8) -- not the headline")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra with_fps_prefix_identity measurement (profiling runs)")
     args = ap.parse_args()
 
@@ -97,8 +99,9 @@ def main():
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     B = args.batch
-    xyz, feats, scans = make_inputs(B, device, seed=100 + rank)
-    hp = hotpath.HotPath(B, device, pipeline=bool(args.pipeline), fps_prefix=bool(args.fps_prefix))
+    shape = hotpath.SHAPE_A if args.shape == "A" else hotpath.SHAPE_B
+    xyz, feats, scans = make_inputs(B, device, seed=100 + rank, shape=shape)
+    hp = hotpath.HotPath(B, device, shape=shape, pipeline=bool(args.pipeline), fps_prefix=bool(args.fps_prefix))
     for _ in range(max(args.warmup, 0)):
         hp.run(xyz, feats, inputs_on_current_stream=False)   # the synthetic scans are resident before any step
     torch.cuda.synchronize()
@@ -117,7 +120,7 @@ def main():
 
     total_meshes = B * args.steps * world
     value = total_meshes / elapsed
-    bytes_per_mesh, per_level = hotpath.algorithmic_bytes(**{k: hotpath.SHAPE_A[k] for k in ("n", "npoint", "nsample", "d")})
+    bytes_per_mesh, per_level = hotpath.algorithmic_bytes(**shape)
 
     out = {
         "metric": "meshes/sec (24k-pt FPS+ball_query+group fwd)",
@@ -132,8 +135,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "shape_A: 24000-pt scans, npoint=[4096,1024,256], nsample=32, radii=[0.05,0.1,0.2], "
-                               "D=[6,128,512]; FPS+ball_query+group forward, grouped tensors materialised",
+        "config": {"workload": ("shape_A: 24000-pt scans, npoint=[4096,1024,256], nsample=32, radii=[0.05,0.1,0.2], "
+                                "D=[6,128,512]; FPS+ball_query+group forward, grouped tensors materialised") if args.shape == "A" else
+                               ("shape_B (NOT the headline configuration): 24000-pt scans, npoint=[1024,512,256], multi-scale "
+                                "radii [[.025,.05],[.05,.1],[.1,.2]], nsample [32,64], D=[6,256,1024]; FPS+ball_query+group forward"),
                    "meshes_per_step_per_gpu": B, "sharding": f"independent meshes x {world} ranks, no data-path collective",
                    "index_dtype": "int32",
                    "fps_levels_2_3": "identity shortcut (FPS of an FPS result; certificate checked on device)"
@@ -159,7 +164,7 @@ def main():
                                    "(the cloud lives in VGPRs); the HBM fraction is reported because the metric asks for it"}
         out["kernel_ms_per_step"] = {k: round(v, 4) for k, v in sorted(avg.items())}
         if kind == "fps":
-            S = hotpath.SHAPE_A["npoint"][lvl]
+            S = shape["npoint"][lvl]
             out["roofline"]["us_per_fps_iteration"] = 1e3 * avg[dom] / max(S - 1, 1)
         # HBM bytes per launch from the PMC passes committed under profiles/ (tools/gpu_pmc.sh; same workload)
         pmc = {}
@@ -167,7 +172,7 @@ def main():
             pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
         except Exception:
             pass
-        if dom in pmc and B == 256:
+        if dom in pmc and B == 256 and args.shape == "A":
             out["roofline"]["traffic"] = pmc[dom]["fetch"] + pmc[dom]["write"]
         # the HBM-bound kernel of the path, for reference next to the (latency-bound) dominant one
         gk = max((k for k in avg if k.startswith("group")), key=lambda k: avg[k])
@@ -175,14 +180,14 @@ def main():
         galgo = per_level[gl]["group"] * B
         out["roofline_group"] = {"kernel": gk, "bound": "hbm", "achieved": galgo / (avg[gk] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": galgo / (avg[gk] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "traffic": (pmc[gk]["fetch"] + pmc[gk]["write"]) if gk in pmc and B == 256 else None,
+                                 "traffic": (pmc[gk]["fetch"] + pmc[gk]["write"]) if gk in pmc and B == 256 and args.shape == "A" else None,
                                  "algorithmic_bytes_per_launch": galgo, "avg_launch_ms": avg[gk]}
     if world == 1 and not args.fps_prefix and not args.no_alt:
         # the same steps with levels 2 and 3 answered by the FPS-of-an-FPS-result identity (exact):
         # reported next to the headline, never as the headline
         del hp
         torch.cuda.empty_cache()
-        hp2 = hotpath.HotPath(B, device, pipeline=bool(args.pipeline), fps_prefix=True)
+        hp2 = hotpath.HotPath(B, device, shape=shape, pipeline=bool(args.pipeline), fps_prefix=True)
         for _ in range(max(args.warmup, 1)):
             hp2.run(xyz, feats, inputs_on_current_stream=False)
         torch.cuda.synchronize()
@@ -199,7 +204,7 @@ def main():
         from oracle import cpu as O
         budget = args.cpu_meshes if args.cpu_meshes > 0 else max(8, 2 * O.num_threads())
         out["cpu_baseline"] = cpu_baseline(scans if scans.shape[0] >= budget else
-                                           np.concatenate([scans] * (budget // scans.shape[0] + 1))[:budget], budget)
+                                           np.concatenate([scans] * (budget // scans.shape[0] + 1))[:budget], budget, shape)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))

@@ -228,3 +228,30 @@ def test_full_size_knn_and_three_nn_properties(dev):
     sup = xyz[::24].contiguous().unsqueeze(0)                 # 1000 support points
     d, i = U.three_nn(xyz.unsqueeze(0), sup)
     assert (d[..., 1:] >= d[..., :-1]).all() and i.max() < 1000
+
+
+def test_hotpath_multi_scale_grouping_matches_the_operators(dev):
+    """Shape-B style plan (two radii per level, [features, centred xyz] order) against the drop-in operators."""
+    from toothgroupnetwork_amd import hotpath, pointnet2_utils as U
+    shape = dict(n=5000, npoint=[512, 128], radius=[[0.05, 0.1], [0.1, 0.2]], nsample=[[16, 32], [16, 32]], d=[6, 40],
+                 xyz_first=False)
+    B = 3
+    pts = T(synth.scan_batch(B, 5000, "arch", 31), dev)
+    xyz = pts[:, :, :3].contiguous()
+    feats = [pts, torch.randn(B, 512, 40, device=dev)]
+    for pipeline in (False, True):
+        hp = hotpath.HotPath(B, dev, shape=shape, pipeline=pipeline)
+        for _ in range(3):
+            levels = hp.run(xyz, feats)
+        torch.cuda.synchronize()
+        cur = xyz
+        for i, lv in enumerate(levels):
+            fidx = U.farthest_point_sample(cur, lv["S"])
+            assert torch.equal(lv["fps_idx"].long(), fidx)
+            new_xyz = U.index_points(cur, fidx)
+            assert torch.equal(lv["new_xyz"], new_xyz)
+            for br, (r, k) in zip(lv["branches"], hotpath._branches(shape["radius"][i], shape["nsample"][i])):
+                gi = U.query_ball_point(r, k, cur, new_xyz)
+                assert torch.equal(br["group_idx"].long(), gi)
+                assert torch.equal(br["grouped"], U.group_points(cur, new_xyz, feats[i], gi, xyz_first=False))
+            cur = new_xyz

@@ -92,3 +92,11 @@ def test_synthetic_scans_have_the_documented_density():
     d = ((pts[:200, None, :3] - pts[None, :, :3]) ** 2).sum(-1)
     per_ball = (d <= 0.05 ** 2).sum(1).mean()
     assert 20 <= per_ball <= 90, per_ball  # r=0.05 balls hold a few dozen points
+
+
+def test_algorithmic_bytes_match_the_survey():
+    """compulsory HBM bytes per scan of the two benchmark shapes"""
+    from toothgroupnetwork_amd import hotpath
+    assert hotpath.algorithmic_bytes(**hotpath.SHAPE_A)[0] == 46109952
+    assert hotpath.algorithmic_bytes(**hotpath.SHAPE_B)[0] == 165863680
+    assert hotpath.algorithmic_bytes(**hotpath.SHAPE_A, fused=True)[0] < 13_000_000

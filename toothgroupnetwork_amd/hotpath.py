@@ -15,18 +15,31 @@ from . import _lib
 from ._lib import check, lib, ptr
 
 SHAPE_A = dict(n=24000, npoint=[4096, 1024, 256], radius=[0.05, 0.1, 0.2], nsample=[32, 32, 32], d=[6, 128, 512])
+# Shape B of SURVEY.md section 8: what the reference instantiates (models/modules/pointnet_pp.py:13-15, scale 4) --
+# multi-scale grouping, two radii per level, grouped layout [features, centred xyz] (pointnet2_utils.py:285)
+SHAPE_B = dict(n=24000, npoint=[1024, 512, 256], radius=[[0.025, 0.05], [0.05, 0.1], [0.1, 0.2]],
+               nsample=[[32, 64], [32, 64], [32, 64]], d=[6, 256, 1024], xyz_first=False)
 
 
-def algorithmic_bytes(n, npoint, nsample, d, fused=False):
+def _branches(radius, nsample):
+    """per-level (radius, nsample) pairs: scalars are one branch, lists are multi-scale grouping"""
+    rs = list(radius) if isinstance(radius, (list, tuple)) else [radius]
+    ks = list(nsample) if isinstance(nsample, (list, tuple)) else [nsample] * len(rs)
+    return list(zip(rs, ks))
+
+
+def algorithmic_bytes(n, npoint, nsample, d, fused=False, radius=None, **_):
     """Compulsory HBM bytes per scan (inputs read once, outputs written once; fp32 data, int32 indices),
-    per level: FPS = 12N + 4S ; ball = 12N + 12S + 4SK ; group = 4SK + 4N(3+D) + 12S + 4SK(3+D)
-    (BASELINE.md section 4).  Returns (total, per_level list of dicts)."""
+    per level: FPS = 12N + 4S ; per (radius, K) branch: ball = 12N + 12S + 4SK ; group = 4SK + 4N(3+D) + 12S + 4SK(3+D)
+    (Shape A 46 109 952 B, Shape B 165 863 680 B).
+    Returns (total, per_level list of dicts)."""
     levels = []
     N = n
-    for S, K, D in zip(npoint, nsample, d):
+    for i, (S, D) in enumerate(zip(npoint, d)):
+        ks = [k for _, k in _branches(radius[i] if radius is not None else 0.0, nsample[i])]
         fps = 12 * N + 4 * S
-        ball = 12 * N + 12 * S + 4 * S * K
-        group = 4 * S * K + 4 * N * (3 + D) + 12 * S + (0 if fused else 4 * S * K * (3 + D))
+        ball = sum(12 * N + 12 * S + 4 * S * K for K in ks)
+        group = sum(4 * S * K + 4 * N * (3 + D) + 12 * S + (0 if fused else 4 * S * K * (3 + D)) for K in ks)
         levels.append(dict(fps=fps, ball=ball, group=group, total=fps + ball + group))
         N = S
     return sum(l["total"] for l in levels), levels
@@ -48,7 +61,7 @@ class HotPath:
         # is the identity, include/tgn_pointops.h): levels > 0 then return 0..S-1 without iterating, decided per cloud
         # on the device.  Off by default: the headline benchmark runs every level's sampling for real.
         self.fps_prefix = bool(fps_prefix)
-        self.xyz_first = xyz_first
+        self.xyz_first = shape.get("xyz_first", xyz_first)
         self.L = lib()
         self.pipeline = pipeline
         self.sets = [self._alloc(B, device, shape, index_dtype) for _ in range(2 if pipeline else 1)]
@@ -68,19 +81,30 @@ class HotPath:
         N = shape["n"]
         f32 = dict(dtype=torch.float32, device=device)
         for S, r, K, D in zip(shape["npoint"], shape["radius"], shape["nsample"], shape["d"]):
-            lv = dict(N=N, S=S, K=K, D=D,
-                      r2=float(torch.tensor(float(r) ** 2, dtype=torch.float32).item()),
+            lv = dict(N=N, S=S, D=D,
                       fps_idx=torch.empty(B, S, dtype=torch.int32, device=device),
                       new_xyz=torch.empty(B, S, 3, **f32),
-                      group_idx=torch.empty(B, S, K, dtype=index_dtype, device=device),
-                      grouped=torch.empty(B, S, K, 3 + D, **f32),
-                      cert=torch.empty(B, dtype=torch.int32, device=device))
+                      cert=torch.empty(B, dtype=torch.int32, device=device), branches=[])
             nbytes = int(self.L.tgn_ball_query_workspace_bytes(B, N, S))
-            lv["ws_bytes"] = nbytes
-            lv["ws"] = torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None
+            for rb, kb in _branches(r, K):   # one ball query + grouping per radius (multi-scale grouping: several)
+                lv["branches"].append(dict(
+                    K=kb, r2=float(torch.tensor(float(rb) ** 2, dtype=torch.float32).item()),
+                    group_idx=torch.empty(B, S, kb, dtype=index_dtype, device=device),
+                    grouped=torch.empty(B, S, kb, 3 + D, **f32), ws_bytes=nbytes,
+                    ws=torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None))
+            lv.update({k: lv["branches"][0][k] for k in ("K", "r2", "group_idx", "grouped", "ws", "ws_bytes")})
             levels.append(lv)
             N = S
         return levels
+
+    def _ball(self, lv, br, cur_xyz, st):
+        return check(self.L.tgn_ball_query(self.B, lv["N"], lv["S"], br["K"], br["r2"], ptr(cur_xyz), ptr(lv["new_xyz"]),
+                                           ptr(br["group_idx"]), self.idx64, ptr(br["ws"]), br["ws_bytes"], st), "ball_query")
+
+    def _group(self, lv, br, cur_xyz, pts, st):
+        return check(self.L.tgn_group_points(self.B, lv["N"], lv["S"], br["K"], lv["D"], ptr(cur_xyz), ptr(lv["new_xyz"]),
+                                             ptr(pts), ptr(br["group_idx"]), self.idx64, int(self.xyz_first),
+                                             ptr(br["grouped"]), st), "group_points")
 
     def enable_kernel_timing(self, steps):
         """HIP events on the launch stream around each kernel class (start/stop per step)."""
@@ -114,12 +138,8 @@ class HotPath:
             B, N, S, K, D = self.B, lv["N"], lv["S"], lv["K"], lv["D"]
             pts = feats[i]
             self._timed(f"fps_l{i + 1}", lambda: self._fps(i, lv, cur_xyz, self.levels, st))
-            self._timed(f"ball_l{i + 1}", lambda: check(L.tgn_ball_query(
-                B, N, S, K, lv["r2"], ptr(cur_xyz), ptr(lv["new_xyz"]), ptr(lv["group_idx"]), self.idx64,
-                ptr(lv["ws"]), lv["ws_bytes"], st), "ball_query"))
-            self._timed(f"group_l{i + 1}", lambda: check(L.tgn_group_points(
-                B, N, S, K, D, ptr(cur_xyz), ptr(lv["new_xyz"]), ptr(pts), ptr(lv["group_idx"]), self.idx64,
-                int(self.xyz_first), ptr(lv["grouped"]), st), "group_points"))
+            self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, cur_xyz, st) for br in lv["branches"]])
+            self._timed(f"group_l{i + 1}", lambda: [self._group(lv, br, cur_xyz, pts, st) for br in lv["branches"]])
             cur_xyz = lv["new_xyz"]
         if self.events is not None:
             self._step += 1
@@ -156,18 +176,14 @@ class HotPath:
         for i, lv in enumerate(levels):
             N, S, K = lv["N"], lv["S"], lv["K"]
             self._timed(f"fps_l{i + 1}", lambda: self._fps(i, lv, cur_xyz, levels, pf), sf)
-            self._timed(f"ball_l{i + 1}", lambda: check(L.tgn_ball_query(
-                B, N, S, K, lv["r2"], ptr(cur_xyz), ptr(lv["new_xyz"]), ptr(lv["group_idx"]), self.idx64,
-                ptr(lv["ws"]), lv["ws_bytes"], pf), "ball_query"), sf)
+            self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, cur_xyz, pf) for br in lv["branches"]], sf)
             self.ev_fps[p][i].record(sf)
             cur_xyz = lv["new_xyz"]
         cur_xyz = xyz
         for i, lv in enumerate(levels):
             N, S, K, D = lv["N"], lv["S"], lv["K"], lv["D"]
             sg.wait_event(self.ev_fps[p][i])
-            self._timed(f"group_l{i + 1}", lambda: check(L.tgn_group_points(
-                B, N, S, K, D, ptr(cur_xyz), ptr(lv["new_xyz"]), ptr(feats[i]), ptr(lv["group_idx"]), self.idx64,
-                int(self.xyz_first), ptr(lv["grouped"]), pg), "group_points"), sg)
+            self._timed(f"group_l{i + 1}", lambda: [self._group(lv, br, cur_xyz, feats[i], pg) for br in lv["branches"]], sg)
             cur_xyz = lv["new_xyz"]
         self.ev_done[p].record(sg)
         cur.wait_event(self.ev_done[p])     # the caller's stream sees this step's results
