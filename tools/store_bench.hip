@@ -249,6 +249,11 @@ int main(int argc, char **argv) {
         if (run2<28>("proxy: 512 MB, buffer store sc1 nt", out, big, idx, queries, S, K, C, win, blocks)) return 1;
         if (run2<29>("proxy: 512 MB, buffer store sc1 sc0 nt", out, big, idx, queries, S, K, C, win, blocks)) return 1;
         if (run2<5>("proxy: (k,c) arithmetic, 512 MB, prefetch", out, big, idx, queries, S, K, C, win, blocks)) return 1;
+        // per-scan window size (256 distinct windows): how much of it survives in L2 beside the store stream?
+        if (run2<0>("proxy: 256 windows of 0.25 MB", out, big, idx, queries, S, K, C, win / 8, blocks)) return 1;
+        if (run2<0>("proxy: 256 windows of 0.5 MB", out, big, idx, queries, S, K, C, win / 4, blocks)) return 1;
+        if (run2<0>("proxy: 256 windows of 1 MB", out, big, idx, queries, S, K, C, win / 2, blocks)) return 1;
+        if (run2<0>("proxy: 256 windows of 2 MB", out, big, idx, queries, S, K, C, win, blocks)) return 1;
         // same loop, 4 MiB window shared by all clouds: is it the source footprint?
         if (run2<0>("proxy: (k,c) arithmetic, 4 MiB source", out, big, idx, queries, 1 << 30, K, C, 1u << 20, blocks)) return 1;
     }
