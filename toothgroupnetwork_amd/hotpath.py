@@ -127,9 +127,12 @@ class HotPath:
     def run(self, xyz, feats, inputs_on_current_stream=True):
         """xyz: (B, N, 3) fp32 contiguous; feats: list of per-level feature tensors (B, N_l, D_l).
         Results land in self.levels[l]['grouped'] etc. (pipelined: self.sets[step parity]).  Asynchronous.
-        Pipelined mode: inputs_on_current_stream=False tells the planner that the inputs were complete before
-        an earlier step was enqueued (e.g. a resident dataset), so this step need not wait for the caller's stream
-        -- which itself waits for the previous step's results -- and consecutive steps can overlap."""
+        Pipelined mode: the results of a call live in one of two buffer sets and are overwritten by the call after
+        next.  By default every call first waits for the caller's stream, which orders it after whatever the caller
+        has enqueued there -- producing the inputs, reading earlier results.  inputs_on_current_stream=False drops
+        that wait (the inputs were complete long ago, e.g. a resident dataset), so that this step does not wait for
+        the previous step's results and consecutive steps overlap; the caller then has to make sure on its own that
+        its reads of step k's results are done before it issues call k+2 (tools/pipeline_stress.py)."""
         if self.pipeline:
             return self._run_pipelined(xyz, feats, inputs_on_current_stream)
         L, st = self.L, _lib.stream()
