@@ -141,6 +141,17 @@ size_t tgn_knnquery_workspace_bytes(int m);
 int tgn_knnquery_ws(int b, int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
                     const int *new_offset, int *idx, float *dist2, void *workspace, size_t workspace_bytes,
                     tgn_stream_t stream);
+/*
+ * The same result again through per-segment uniform grids (cell size ~ the k-neighbour radius of a scan surface): a
+ * query looks at the 3x3x3 cells around it instead of the whole segment and widens the block only if the (k+1)-th
+ * distance does not lie inside the covered radius.  n = total number of points (rows of xyz).  Pays from a few
+ * thousand points per segment up; small or degenerate segments are scanned linearly inside the same launch, and
+ * nsample > 63 or too small a workspace fall back to tgn_knnquery_ws.  (24 000 x 24 000, k = 36: see DESIGN.md.)
+ */
+size_t tgn_knnquery_grid_workspace_bytes(int b, int n, int m);
+int tgn_knnquery_grid(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
+                      const int *new_offset, int *idx, float *dist2, void *workspace, size_t workspace_bytes,
+                      tgn_stream_t stream);
 
 int tgn_grouping_forward(int m, int nsample, int c, const float *input, const int *idx, float *output,
                          tgn_stream_t stream);

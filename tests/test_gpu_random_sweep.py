@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from toothgroupnetwork_amd import synth
+
 pytestmark = pytest.mark.gpu
 
 
@@ -139,3 +141,57 @@ def test_gather_family_random_shapes(dev, oracle, seed):
     close(npy(x.grad), gi)
     close(npy(pos.grad), gp)
     close(npy(w.grad), gw)
+
+
+def _knn_grid(dev, k, xyz, q, off, noff):
+    from toothgroupnetwork_amd import _lib
+    L = _lib.lib()
+    b, n, m = len(off), xyz.shape[0], q.shape[0]
+    X, Q, O, NO = T(xyz, dev), T(q, dev), T(off, dev), T(noff, dev)
+    idx = torch.full((m, k), -1, dtype=torch.int32, device=dev)
+    d2 = torch.full((m, k), -1.0, device=dev)
+    nbytes = int(L.tgn_knnquery_grid_workspace_bytes(b, n, m))
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    _lib.check(L.tgn_knnquery_grid(b, n, m, k, _lib.ptr(X), _lib.ptr(Q), _lib.ptr(O), _lib.ptr(NO), _lib.ptr(idx),
+                                   _lib.ptr(d2), _lib.ptr(ws), nbytes, _lib.stream()))
+    return idx.cpu().numpy(), np.sqrt(d2.cpu().numpy())
+
+
+@pytest.mark.parametrize("case", ["arch24k", "volume", "quantised", "ragged", "outside", "degenerate"])
+@pytest.mark.parametrize("k", [1, 16, 36, 63])
+def test_knn_grid_path_equals_the_heap_order(dev, oracle, case, k):
+    """tgn_knnquery_grid against the oracle's verbatim heap: surfaces, volume-filling clouds (the cell-size guess is too
+    small: wider blocks), exact ties, ragged batches with tiny segments, queries far outside the box, degenerate clouds."""
+    rng = np.random.default_rng(hash(case) % 1000 + k)
+    if case == "arch24k":
+        segs = [synth.arch_cloud(24000, 5, False)]
+        qs = [segs[0][::5]]
+    elif case == "volume":
+        segs = [rng.uniform(-1, 1, size=(15000, 3)).astype(np.float32)]
+        qs = [segs[0][::6]]
+    elif case == "quantised":
+        segs = [(rng.integers(-20, 21, size=(9000, 3)) / 16.0).astype(np.float32)]
+        qs = [segs[0][::4]]
+    elif case == "ragged":
+        segs = [synth.arch_cloud(12000, 1, False), synth.uniform_cloud(300, 2), synth.arch_cloud(6000, 3, False),
+                synth.uniform_cloud(1, 4), synth.uniform_cloud(40, 5)]
+        qs = [s[::7][:400] if len(s) > 7 else s for s in segs]
+    elif case == "outside":
+        segs = [synth.arch_cloud(8000, 9, False), synth.arch_cloud(5000, 10, False)]
+        far = np.array([[30, 0, 0], [0, -50, 2], [1e3, 1e3, 1e3], [0.2, 0.1, 5.0]], np.float32)
+        qs = [np.concatenate([s[::50], far, s[:3] + 0.013]) for s in segs]
+    else:
+        flat = synth.uniform_cloud(5000, 11)
+        flat[:, 2] = 0.5                                   # zero extent in z
+        same = np.full((4000, 3), 0.25, np.float32)        # a single point, 4000 times
+        nanc = synth.arch_cloud(6000, 12, False)
+        nanc[100] = np.nan
+        segs = [flat, same, nanc]
+        qs = [s[::9] for s in segs]
+    xyz, q = np.concatenate(segs), np.concatenate(qs)
+    off = np.cumsum([len(s) for s in segs]).astype(np.int32)
+    noff = np.cumsum([len(s) for s in qs]).astype(np.int32)
+    gi, gd = _knn_grid(dev, k, xyz, q, off, noff)
+    oi, od = oracle.knnquery(k, xyz, q, off, noff)
+    assert np.array_equal(gi, oi), case
+    assert np.array_equal(gd, od, equal_nan=True)

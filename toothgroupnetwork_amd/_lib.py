@@ -48,6 +48,8 @@ SIGNATURES = {
     "tgn_knnquery": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "tgn_knnquery_workspace_bytes": (c_size_t, [c_int]),
     "tgn_knnquery_ws": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "tgn_knnquery_grid_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "tgn_knnquery_grid": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "tgn_grouping_forward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P]),
     "tgn_grouping_backward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P]),
     "tgn_interpolation_forward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P]),

@@ -5,6 +5,7 @@
 // three_nn   : the square_distance + full sort + [:3] of PointNetFeaturePropagation
 //              (pointnet2_utils.py:333-335) as a running top-3 by (distance, index).
 #include "tgn_common.h"
+#include <stdlib.h>
 
 namespace tgn {
 
@@ -169,6 +170,323 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(int b, int m, int k, cons
         const bool tie = lane < k && ld[j] == nd && li[j] != ni;
         if (__any(tie) && lane == 0) redo[1 + atomicAdd(&redo[0], 1)] = q;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grid kNN for large segments.  The brute-force kernel above evaluates every (query, point) pair (576 M at 24 000^2);
+// on a scan surface the k nearest neighbours sit in the 3x3x3 cells around the query once the cell size is about the
+// k-neighbour radius.  Per segment a uniform grid is built in LDS (bounding box -> histogram with LDS atomics -> scan ->
+// scatter of 16-byte (x, y, z, index) records sorted by cell); a query wave scans the (2r+1)^2 x-runs of cells of the
+// block of radius r around its cell with the same insertion into the lane-sorted (k+1)-list, and is done when the
+// (k+1)-th distance lies inside the radius the block is guaranteed to cover (r cells, minus a margin for the rounding of
+// the cell coordinates); otherwise the block radius doubles and the query starts over.  Distances are the same
+// unfused expression on the same operands, candidates merely arrive in another order: wherever the k+1 smallest
+// distances are distinct the result is the brute-force one, and queries with exact ties go to the heap kernel just
+// like there.  Degenerate or tiny segments (flagged by the build) are scanned linearly by their query waves.
+// ---------------------------------------------------------------------------------------------
+constexpr int kKnnCells = 16384;
+constexpr int kKnnBuildThreads = 1024;
+
+__device__ __forceinline__ float wave_min_f32_x(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32_x(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+struct KnnGridHeader {  // one per segment, 64 bytes
+    float lo[3];
+    float inv_h;
+    int g[3];
+    int use_scan;
+    float h;
+    int pad[7];
+};
+
+__host__ __device__ inline size_t knn_grid_off_headers(int m) { return (((size_t)m + 1) * sizeof(int) + 63) / 64 * 64; }
+__host__ __device__ inline size_t knn_grid_off_cells(int b, int m) { return knn_grid_off_headers(m) + (size_t)b * sizeof(KnnGridHeader); }
+__host__ __device__ inline size_t knn_grid_off_records(int b, int m) {
+    return knn_grid_off_cells(b, m) + (size_t)b * (kKnnCells + 4) * sizeof(int);
+}
+
+__device__ __forceinline__ int knn_cell(float p, float lo, float inv_h, int g) {
+    float t = (p - lo) * inv_h;           // the same expression for points and queries
+    t = fminf(fmaxf(t, 0.0f), (float)(g - 1));  // NaN -> 0; queries outside the box go to the border cell
+    return (int)t;
+}
+
+__global__ __launch_bounds__(kKnnBuildThreads) void knn_grid_build_kernel(int b_total, int m, int k, float scale, const float *__restrict__ xyz,
+                                                                          const int *__restrict__ offset,
+                                                                          unsigned char *__restrict__ ws) {
+    __shared__ int cnt[kKnnCells];
+    __shared__ float red[7][kKnnBuildThreads / kWave];
+    __shared__ int wave_tot[kKnnBuildThreads / kWave];
+    __shared__ KnnGridHeader hdr_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int st = b ? offset[b - 1] : 0, n = offset[b] - st;
+    const float *__restrict__ pts = xyz + (size_t)st * 3;
+    KnnGridHeader *hdr = (KnnGridHeader *)(ws + knn_grid_off_headers(m)) + b;
+    int *cell_start = (int *)(ws + knn_grid_off_cells(b_total, m)) + (size_t)b * (kKnnCells + 4);
+    float4 *rec = (float4 *)(ws + knn_grid_off_records(b_total, m)) + st;
+
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float bad = 0.0f;
+    for (int i = tid; i < n; i += kKnnBuildThreads) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = pts[(size_t)i * 3 + a];
+            if (!(fabsf(v) <= 1.0e18f)) bad = 1.0f;  // NaN, Inf or so large that squared distances overflow
+            lo[a] = fminf(lo[a], v);
+            hi[a] = fmaxf(hi[a], v);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float l = wave_min_f32_x(lo[a]), h = wave_max_f32_x(hi[a]);
+        if (lane == 0) {
+            red[a][wave] = l;
+            red[3 + a][wave] = h;
+        }
+    }
+    {
+        const float bb = wave_max_f32_x(bad);
+        if (lane == 0) red[6][wave] = bb;
+    }
+    for (int i = tid; i < kKnnCells; i += kKnnBuildThreads) cnt[i] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        KnnGridHeader h;
+        float ext[3], any_bad = 0.0f;
+        for (int a = 0; a < 3; ++a) {
+            float l = INFINITY, u = -INFINITY;
+            for (int w = 0; w < kKnnBuildThreads / kWave; ++w) {
+                l = fminf(l, red[a][w]);
+                u = fmaxf(u, red[3 + a][w]);
+            }
+            h.lo[a] = l;
+            ext[a] = u - l;
+        }
+        for (int w = 0; w < kKnnBuildThreads / kWave; ++w) any_bad = fmaxf(any_bad, red[6][w]);
+        // cell size ~ radius that holds k points of a SURFACE of area xy + yz + zx (half the box surface: a thin sheet
+        // gives its own area); too small a guess only costs a second, larger block for some queries
+        const float area = ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2];
+        float hcell = scale * sqrtf(fmaxf(area, 0.0f) * (float)(k + 1) / (3.14159265f * fmaxf((float)n, 1.0f)));
+        const float emax = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
+        hcell = fmaxf(hcell, emax * (1.0f / 4096.0f));
+        int g[3] = {1, 1, 1};
+        bool ok = any_bad == 0.0f && n >= 512 && hcell > 0.0f && hcell < INFINITY;
+        if (ok) {
+            for (int it = 0; it < 80; ++it) {
+                const float inv = 1.0f / hcell;
+                long long cells = 1;
+                for (int a = 0; a < 3; ++a) {
+                    const float t = ext[a] * inv;
+                    g[a] = (t < 1.0e6f) ? (int)t + 1 : 1000001;
+                    cells *= g[a];
+                }
+                if (cells <= kKnnCells) break;
+                hcell *= 1.1f;
+            }
+            long long cells = (long long)g[0] * g[1] * g[2];
+            ok = cells <= kKnnCells && cells >= 8;
+        }
+        h.h = hcell;
+        h.inv_h = ok ? 1.0f / hcell : 0.0f;
+        for (int a = 0; a < 3; ++a) h.g[a] = ok ? g[a] : 1;
+        h.use_scan = ok ? 0 : 1;
+        for (int i = 0; i < 7; ++i) h.pad[i] = 0;
+        hdr_s = h;
+        *hdr = h;
+    }
+    __syncthreads();
+    const KnnGridHeader h = hdr_s;
+    if (h.use_scan) return;
+    for (int i = tid; i < n; i += kKnnBuildThreads) {
+        const int cx = knn_cell(pts[(size_t)i * 3 + 0], h.lo[0], h.inv_h, h.g[0]);
+        const int cy = knn_cell(pts[(size_t)i * 3 + 1], h.lo[1], h.inv_h, h.g[1]);
+        const int cz = knn_cell(pts[(size_t)i * 3 + 2], h.lo[2], h.inv_h, h.g[2]);
+        atomicAdd(&cnt[(cz * h.g[1] + cy) * h.g[0] + cx], 1);
+    }
+    __syncthreads();
+    constexpr int PER = kKnnCells / kKnnBuildThreads;
+    int local[PER];
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        local[i] = sum;
+        sum += cnt[tid * PER + i];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == kWave - 1) wave_tot[wave] = incl;
+    __syncthreads();
+    int wave_base = 0;
+    for (int w = 0; w < wave; ++w) wave_base += wave_tot[w];
+    const int thread_base = wave_base + incl - sum;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int v = thread_base + local[i];
+        cell_start[tid * PER + i] = v;
+        cnt[tid * PER + i] = v;
+    }
+    if (tid == kKnnBuildThreads - 1) cell_start[kKnnCells] = thread_base + sum;
+    __syncthreads();
+    for (int i = tid; i < n; i += kKnnBuildThreads) {
+        const float px = pts[(size_t)i * 3 + 0], py = pts[(size_t)i * 3 + 1], pz = pts[(size_t)i * 3 + 2];
+        const int cx = knn_cell(px, h.lo[0], h.inv_h, h.g[0]);
+        const int cy = knn_cell(py, h.lo[1], h.inv_h, h.g[1]);
+        const int cz = knn_cell(pz, h.lo[2], h.inv_h, h.g[2]);
+        const int pos = atomicAdd(&cnt[(cz * h.g[1] + cy) * h.g[0] + cx], 1);
+        rec[pos] = make_float4(px, py, pz, __int_as_float(st + i));  // the packed (global) point index
+    }
+}
+
+// insert candidate (dn, in) into the lane-sorted list (entries <= dn stay in front), as in knn_wave_kernel
+__device__ __forceinline__ void knn_insert(float &ld, int &li, float &tau, float dn, int in, int k, int lane) {
+    // lanes 0..k hold the list: the lane mask is applied to the ballot as a (wave-uniform) constant, and the shifted-in
+    // value of lane 0 is never used, so the DPP moves need no defined "old" operand
+    const unsigned long long kmask = (k >= 63) ? ~0ull : ((2ull << k) - 1ull);
+    const int pos = __popcll(__builtin_amdgcn_ballot_w64(ld <= dn) & kmask);
+    const float sd = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ld), __float_as_int(ld), 0x138, 0xF, 0xF, false));
+    const int si = __builtin_amdgcn_update_dpp(li, li, 0x138, 0xF, 0xF, false);
+    ld = lane < pos ? ld : (lane == pos ? dn : sd);
+    li = lane < pos ? li : (lane == pos ? in : si);
+    tau = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ld), k));
+}
+
+__global__ __launch_bounds__(256) void knn_grid_query_kernel(int b, int m, int k, const float *__restrict__ xyz,
+                                                              const float *__restrict__ new_xyz,
+                                                              const int *__restrict__ offset,
+                                                              const int *__restrict__ new_offset,
+                                                              const unsigned char *__restrict__ ws, int *__restrict__ idx,
+                                                              float *__restrict__ dist2, int *__restrict__ redo) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int q = blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    if (q >= m) return;
+    int bt = 0;  // get_bt_idx, knnquery_cuda_kernel.cu:51-62
+    while (bt < b - 1 && !(q < new_offset[bt])) ++bt;
+    const int st = bt == 0 ? 0 : offset[bt - 1], en = offset[bt];
+    const float qx = new_xyz[(size_t)q * 3 + 0], qy = new_xyz[(size_t)q * 3 + 1], qz = new_xyz[(size_t)q * 3 + 2];
+    const KnnGridHeader *hdr = (const KnnGridHeader *)(ws + knn_grid_off_headers(m)) + bt;
+    float ld = 1e10f, tau = 1e10f;  // knnquery_cuda_kernel.cu:88-91
+    int li = st;
+    const bool q_ok = fabsf(qx) <= 1.0e18f && fabsf(qy) <= 1.0e18f && fabsf(qz) <= 1.0e18f;
+    if (hdr->use_scan || !q_ok) {
+        for (int base = st; base < en; base += kWave) {  // linear scan of the segment, ascending index
+            const int i = base + lane;
+            float d2 = 0.0f;
+            if (i < en) {
+                const float ex = qx - xyz[(size_t)i * 3 + 0], ey = qy - xyz[(size_t)i * 3 + 1], ez = qz - xyz[(size_t)i * 3 + 2];
+                d2 = dist_direct_nofma(ex, ey, ez);
+            }
+            unsigned long long mask = __ballot(i < en && d2 < tau);
+            while (mask) {
+                const int src = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const float dn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), src));
+                if (!(dn < tau)) continue;
+                knn_insert(ld, li, tau, dn, base + src, k, lane);
+            }
+        }
+    } else {
+        const int *__restrict__ cell_start = (const int *)(ws + knn_grid_off_cells(b, m)) + (size_t)bt * (kKnnCells + 4);
+        const float4 *__restrict__ rec = (const float4 *)(ws + knn_grid_off_records(b, m)) + st;
+        const int gx = hdr->g[0], gy = hdr->g[1], gz = hdr->g[2];
+        const float inv_h = hdr->inv_h, h = hdr->h;
+        const int cx = knn_cell(qx, hdr->lo[0], inv_h, gx), cy = knn_cell(qy, hdr->lo[1], inv_h, gy),
+                  cz = knn_cell(qz, hdr->lo[2], inv_h, gz);
+        // a query outside the box sits in a border cell although it is farther away: what a block of radius r covers
+        // is measured from the box then (all points are inside it)
+        const float ox = fmaxf(fmaxf(hdr->lo[0] - qx, qx - (hdr->lo[0] + (float)gx * h)), 0.0f);
+        const float oy = fmaxf(fmaxf(hdr->lo[1] - qy, qy - (hdr->lo[1] + (float)gy * h)), 0.0f);
+        const float oz = fmaxf(fmaxf(hdr->lo[2] - qz, qz - (hdr->lo[2] + (float)gz * h)), 0.0f);
+        const float outside = fmaxf(ox, fmaxf(oy, oz));
+        // blocks of radius 1, 2, 4, ...: a wider block only adds its SHELL (the cells of the previous block are not
+        // visited again), so the list and its threshold carry over
+        for (int r = 1, rp = -1;; rp = r, r *= 2) {
+            const int x0 = max(cx - r, 0), x1 = min(cx + r, gx - 1);
+            const int side = 2 * r + 1, nruns = side * side;
+            for (int t0 = 0; t0 < nruns; t0 += kWave) {
+                // lane t: one (dy, dz) run of the block; inside the previous block's (dy, dz) range only the
+                // two x-pieces left and right of it are new
+                int rs[2] = {0, 0}, re[2] = {0, 0};
+                const int t = t0 + lane;
+                if (t < nruns) {
+                    const int tt = (t + nruns / 2) % nruns;  // the query's own run first: the threshold drops at once
+                    const int dy = (tt % side) - r, dz = (tt / side) - r;
+                    const int yy = cy + dy, zz = cz + dz;
+                    if (yy >= 0 && yy < gy && zz >= 0 && zz < gz) {
+                        const int c0 = (zz * gy + yy) * gx;
+                        if (rp >= 0 && abs(dy) <= rp && abs(dz) <= rp) {
+                            const int l1 = min(cx - rp - 1, gx - 1), r0 = max(cx + rp + 1, 0);
+                            if (x0 <= l1) {
+                                rs[0] = cell_start[c0 + x0];
+                                re[0] = cell_start[c0 + l1 + 1];
+                            }
+                            if (r0 <= x1) {
+                                rs[1] = cell_start[c0 + r0];
+                                re[1] = cell_start[c0 + x1 + 1];
+                            }
+                        } else {
+                            rs[0] = cell_start[c0 + x0];
+                            re[0] = cell_start[c0 + x1 + 1];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int part = 0; part < 2; ++part) {
+                    unsigned long long live = __ballot(re[part] > rs[part]);
+                    while (live) {  // wave-uniform: the non-empty runs of this chunk
+                        const int rl = __builtin_ctzll(live);
+                        live &= live - 1;
+                        const int a = __builtin_amdgcn_readlane(rs[part], rl), e = __builtin_amdgcn_readlane(re[part], rl);
+                        for (int j0 = a; j0 < e; j0 += kWave) {
+                            const int j = j0 + lane;
+                            float d2 = 0.0f;
+                            int pi = 0;
+                            if (j < e) {
+                                const float4 p = rec[j];
+                                const float ex = qx - p.x, ey = qy - p.y, ez = qz - p.z;
+                                d2 = dist_direct_nofma(ex, ey, ez);  // knnquery_cuda_kernel.cu:96
+                                pi = __float_as_int(p.w);
+                            }
+                            unsigned long long mask = __ballot(j < e && d2 < tau);
+                            while (mask) {
+                                const int src = __builtin_ctzll(mask);
+                                mask &= mask - 1;
+                                const float dn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), src));
+                                if (!(dn < tau)) continue;
+                                knn_insert(ld, li, tau, dn, __builtin_amdgcn_readlane(pi, src), k, lane);
+                            }
+                        }
+                    }
+                }
+            }
+            const bool whole = x0 == 0 && x1 == gx - 1 && cy - r <= 0 && cy + r >= gy - 1 && cz - r <= 0 && cz + r >= gz - 1;
+            if (whole) break;
+            // every point within (r cells) of the query's cell boundary has been seen; 0.999 absorbs the rounding of
+            // the cell coordinates, `outside` the distance of a query beyond the box to its (border) cell
+            const float cover = (float)r * h * 0.999f - outside;
+            if (cover > 0.0f && tau < cover * cover) break;
+        }
+    }
+    if (lane < k) {
+        idx[(size_t)q * k + lane] = li;
+        dist2[(size_t)q * k + lane] = ld;
+    }
+    const float nd = __shfl_down(ld, 1);
+    const int ni = __shfl_down(li, 1);
+    const bool tie = lane < k && ld == nd && li != ni;
+    if (__any(tie) && lane == 0) redo[1 + atomicAdd(&redo[0], 1)] = q;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -413,6 +731,39 @@ TGN_API int tgn_knnquery_ws(int b, int m, int nsample, const float *xyz, const f
                        new_offset, idx, dist2, redo);
     if (int rc = check_launch("knn_wave_kernel")) return rc;
     // queries with bit-exact distance ties: exact heap order (usually none; the grid is sized for all of them)
+    return knn_heap_launch(b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, redo, st);
+}
+
+TGN_API size_t tgn_knnquery_grid_workspace_bytes(int b, int n, int m) {
+    if (b <= 0 || n <= 0 || m <= 0) return 0;
+    return knn_grid_off_records(b, m) + (size_t)n * sizeof(float4);
+}
+
+TGN_API int tgn_knnquery_grid(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
+                              const int *new_offset, int *idx, float *dist2, void *workspace, size_t workspace_bytes,
+                              tgn_stream_t stream) {
+    if (m <= 0 || nsample <= 0) return TGN_OK;
+    if (b <= 0 || n < 0 || !xyz || !new_xyz || !offset || !new_offset || !idx || !dist2) {
+        set_error("tgn_knnquery_grid: bad argument");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    // the grids only pay for big segments and need the (k+1)-list in one wave; otherwise the plain kernels
+    if (nsample > kWave - 1 || !workspace || workspace_bytes < tgn_knnquery_grid_workspace_bytes(b, n, m) || b > 4096)
+        return tgn_knnquery_ws(b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, workspace, workspace_bytes, stream);
+    hipStream_t st = (hipStream_t)stream;
+    int *redo = (int *)workspace;
+    if (hipMemsetAsync(redo, 0, sizeof(int), st) != hipSuccess) {
+        set_error("tgn_knnquery_grid: hipMemsetAsync failed");
+        return TGN_ERR_LAUNCH;
+    }
+    float scale = 1.0f;  // cell size relative to the estimated k-neighbour radius (TGN_KNN_GRID_SCALE: experiments)
+    if (const char *e = getenv("TGN_KNN_GRID_SCALE")) scale = (float)atof(e);
+    hipLaunchKernelGGL(knn_grid_build_kernel, dim3(b), dim3(kKnnBuildThreads), 0, st, b, m, nsample, scale, xyz, offset,
+                       (unsigned char *)workspace);
+    if (int rc = check_launch("knn_grid_build_kernel")) return rc;
+    hipLaunchKernelGGL(knn_grid_query_kernel, dim3((m + 3) / 4), dim3(256), 0, st, b, m, nsample, xyz, new_xyz, offset,
+                       new_offset, (const unsigned char *)workspace, idx, dist2, redo);
+    if (int rc = check_launch("knn_grid_query_kernel")) return rc;
     return knn_heap_launch(b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, redo, st);
 }
 

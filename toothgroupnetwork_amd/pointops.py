@@ -133,11 +133,23 @@ def _knn_raw(nsample, xyz, new_xyz, offset, new_offset):
     m = new_xyz.shape[0]
     idx = torch.empty(m, nsample, dtype=torch.int32, device=xyz.device)
     dist2 = torch.empty(m, nsample, dtype=torch.float32, device=xyz.device)
+    b, n = offset.shape[0], xyz.shape[0]
+    if KNN_GRID and nsample <= 63 and b > 0 and n >= KNN_GRID_MIN_POINTS * b:
+        # big segments: per-segment grids, a query looks at the cells around it (same result)
+        nbytes = int(lib().tgn_knnquery_grid_workspace_bytes(b, n, m))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device) if nbytes else None
+        check(lib().tgn_knnquery_grid(b, n, m, nsample, ptr(xyz), ptr(new_xyz), ptr(offset), ptr(new_offset),
+                                      ptr(idx), ptr(dist2), ptr(ws), nbytes, stream()), "tgn_knnquery")
+        return idx, dist2
     nbytes = int(lib().tgn_knnquery_workspace_bytes(m))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device) if nbytes else None
-    check(lib().tgn_knnquery_ws(offset.shape[0], m, nsample, ptr(xyz), ptr(new_xyz), ptr(offset), ptr(new_offset),
+    check(lib().tgn_knnquery_ws(b, m, nsample, ptr(xyz), ptr(new_xyz), ptr(offset), ptr(new_offset),
                                 ptr(idx), ptr(dist2), ptr(ws), nbytes, stream()), "tgn_knnquery")
     return idx, dist2
+
+
+KNN_GRID = os.environ.get("TGN_KNN_GRID", "1") != "0"
+KNN_GRID_MIN_POINTS = int(os.environ.get("TGN_KNN_GRID_MIN", "3000"))   # average points per segment
 
 
 # kNN memo.  The reference recomputes identical neighbour lists again and again: PointTransformerLayer calls
