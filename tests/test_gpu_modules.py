@@ -255,3 +255,33 @@ def test_hotpath_multi_scale_grouping_matches_the_operators(dev):
                 assert torch.equal(br["group_idx"].long(), gi)
                 assert torch.equal(br["grouped"], U.group_points(cur, new_xyz, feats[i], gi, xyz_first=False))
             cur = new_xyz
+
+
+def test_pipelined_schedule_at_full_size_matches_one_stream(dev):
+    """256 scans of 24 000 points (the benchmark configuration), two different resident batches, overlapping pairs of
+    steps on the two streams: every result set must carry the one-stream checksums (tools/pipeline_stress.py, shorter)."""
+    from toothgroupnetwork_amd import hotpath
+    B = 256
+    batches = []
+    for s in range(2):
+        pts = torch.from_numpy(synth.scan_batch(4, 24000, "arch", 700 + s)).to(dev).repeat(B // 4, 1, 1).contiguous()
+        feats = [pts, torch.randn(B, 4096, 128, device=dev), torch.randn(B, 1024, 512, device=dev)]
+        batches.append((pts[:, :, :3].contiguous(), feats))
+    ref = hotpath.HotPath(B, dev)
+    sums = []
+    for xyz, feats in batches:
+        lv = ref.run(xyz, feats)
+        sums.append([(int(l["fps_idx"].long().sum()), int(l["group_idx"].long().sum()), float(l["grouped"].double().sum())) for l in lv])
+    del ref
+    torch.cuda.empty_cache()
+    hp = hotpath.HotPath(B, dev, pipeline=True)
+    for pair in range(6):
+        outs = []
+        for step in (2 * pair, 2 * pair + 1):
+            which = (step + pair) % 2
+            outs.append((hp.run(*batches[which], inputs_on_current_stream=False), sums[which]))
+        torch.cuda.synchronize()
+        for lv, want in outs:
+            for l, (a, b, c) in zip(lv, want):
+                assert int(l["fps_idx"].long().sum()) == a and int(l["group_idx"].long().sum()) == b
+                assert float(l["grouped"].double().sum()) == c
