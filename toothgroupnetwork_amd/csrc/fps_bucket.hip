@@ -37,9 +37,12 @@
 namespace tgn {
 
 // deposit a wave-uniform value into one lane of a per-lane register (the metadata lane of a bucket)
-__device__ __forceinline__ float writelane_f32(float old, float val_uniform, int lane) {
-    return lane_id() == lane ? val_uniform : old;
-}
+// (one v_writelane_b32: a select would need a lane mask per slot -- 2 x 48 SGPRs, spilled to VGPR lanes)
+#define TGN_WRITELANE_F32(reg, val_uniform, lane_const)                                              \
+    do {                                                                                               \
+        const int wl_bits_ = __builtin_amdgcn_readfirstlane(__float_as_int(val_uniform));              \
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(reg) : "s"(wl_bits_), "i"(lane_const));      \
+    } while (0)
 __device__ __forceinline__ unsigned spread5(unsigned v) {  // abcde -> a00b00c00d00e
     return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6) | ((v & 16u) << 8);
 }
@@ -197,13 +200,13 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
         const float l1 = wave_min_f32_dpp(valid ? y[s] : INFINITY), h1 = wave_max_f32_dpp(valid ? y[s] : -INFINITY);
         const float l2 = wave_min_f32_dpp(valid ? z[s] : INFINITY), h2 = wave_max_f32_dpp(valid ? z[s] : -INFINITY);
         const float any = wave_max_f32_dpp(d[s]);
-        blo0 = writelane_f32(blo0, l0, s);
-        blo1 = writelane_f32(blo1, l1, s);
-        blo2 = writelane_f32(blo2, l2, s);
-        bhi0 = writelane_f32(bhi0, h0, s);
-        bhi1 = writelane_f32(bhi1, h1, s);
-        bhi2 = writelane_f32(bhi2, h2, s);
-        bmax = writelane_f32(bmax, any, s);  // 1e10 if the bucket holds a real point, else -1
+        TGN_WRITELANE_F32(blo0, l0, s);
+        TGN_WRITELANE_F32(blo1, l1, s);
+        TGN_WRITELANE_F32(blo2, l2, s);
+        TGN_WRITELANE_F32(bhi0, h0, s);
+        TGN_WRITELANE_F32(bhi1, h1, s);
+        TGN_WRITELANE_F32(bhi2, h2, s);
+        TGN_WRITELANE_F32(bmax, any, s);  // 1e10 if the bucket holds a real point, else -1
         // initial arg-max of the bucket: all real points sit at 1e10, the smallest tie key wins
         const unsigned o = tab[(s * NW + wave) * kWave + lane];
         const unsigned kl = valid ? (TREE ? compat_key((int)o, log2bs) : o) : 0xFFFFFFFFu;

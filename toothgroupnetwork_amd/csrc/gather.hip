@@ -170,24 +170,23 @@ __global__ __launch_bounds__(256) void aggregation_bwd_kernel(long long rows, in
 }
 
 // ---- pointnet2_utils composites -------------------------------------------------------------------
-// group_points: one wave per query (b,s).  The wave's output, K rows of C = 3+D floats, is ONE contiguous
-// region of K*C floats, so lanes walk the flattened (k,c) space four elements at a time and store 16 B
-// each (1 KiB per wave-instruction, fully coalesced) however odd C is (9, 131, 515 at Shape A).  The
-// neighbour indices of the query sit in LDS; (k,c) of a lane's first element comes from one magic-number
-// division, the other three by increment-and-wrap.
+// group_points: one wave per query (b,s).  The wave's output, K rows of C = 3+D floats, is ONE contiguous region of
+// K*C floats: lanes walk the flattened (k,c) space, 64 consecutive floats per step, however odd C is (9, 131, 515
+// at Shape A) -- gathers and stores are both lane-contiguous (a lane-strided gather touches 4x the cache lines and is
+// address-path bound at ~2 TB/s; 16-B stores through an LDS transpose measured slower than 4-B ones).  The
+// neighbour row offsets and the centred coordinates of the query sit in per-wave LDS tables.
+// 24 VGPRs on purpose: beside an FPS workgroup (2 waves x 232 of a SIMD's 512 registers) TWO waves of this kernel
+// fit per SIMD (bench.py --pipeline; tests/test_build_resources.py guards both numbers).
 constexpr int kGroupMaxK = 128;
 
-template <typename IdxT, int VEC>
-__global__ __launch_bounds__(256) void group_points_kernel(long long queries, int N, int S, int K, int D,
-                                                            unsigned magicC, const float *__restrict__ xyz,
-                                                            const float *__restrict__ new_xyz,
-                                                            const float *__restrict__ points,
-                                                            const IdxT *__restrict__ idx, int xyz_first,
-                                                            float *__restrict__ out, int *__restrict__ err) {
+template <typename IdxT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(24))) void group_points_kernel(
+    long long queries, int N, int S, int K, int D, unsigned magicC, const float *__restrict__ xyz,
+    const float *__restrict__ new_xyz, const float *__restrict__ points, const IdxT *__restrict__ idx, int xyz_first,
+    float *__restrict__ out, int *__restrict__ err) {
     // per wave and neighbour k: element offset of its feature row, and its centred coordinates
     __shared__ unsigned sfb[4][kGroupMaxK];
     __shared__ float srel[4][kGroupMaxK * 3];
-    __shared__ __attribute__((aligned(16))) float stage[4][kWave * 4];  // per-wave transpose buffer
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: q and its pointers live in SGPRs
     const int C = 3 + D;
@@ -221,48 +220,20 @@ __global__ __launch_bounds__(256) void group_points_kernel(long long queries, in
         if (__any(bad) && lane == 0) atomicOr(err, 1);
         // (the same wave wrote the tables: LDS operations of one wave complete in order, no barrier needed)
         float *__restrict__ dst = out + (size_t)q * total;
-        if constexpr (VEC == 4) {
-            // 256 elements per step: the four gathers of a lane are LANE-CONTIGUOUS (load u covers elements
-            // e0+64u .. e0+64u+63: two cache lines per wave-instruction; a lane-strided gather touches eight and
-            // is address-path bound at ~2 TB/s), the wave transposes them through LDS, and every lane stores the
-            // 16 contiguous bytes it then owns (total % 4 == 0 here).
-            for (int e0 = 0; e0 < total; e0 += kWave * 4) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int e = e0 + u * kWave + lane;
-                    float val = 0.0f;
-                    if (e < total) {
-                        const unsigned k = __umulhi((unsigned)e, magicC);  // e / C (exact for e < 2^32 / C)
-                        const unsigned c = (unsigned)e - k * (unsigned)C;
-                        const unsigned cx = c - xo;  // 0..2 inside the coordinate triple
-                        const bool isx = cx < 3u;
-                        const float rel = srel[wv][k * 3 + (isx ? cx : 0u)];
-                        const float ld = points[sfb[wv][k] + (isx ? 0u : c - fo)];
-                        val = isx ? rel : ld;
-                    }
-                    stage[wv][u * kWave + lane] = val;
-                }
-                const int e = e0 + lane * 4;
-                if (e < total) *(float4 *)(dst + e) = *(const float4 *)&stage[wv][lane * 4];
-            }
-        } else {
-            // lane-contiguous gathers AND stores (256 contiguous, 128-B aligned bytes per wave-instruction).
-            // What bounds it (tools/store_bench.hip, tools/gpu_pmc_group.sh; profiles/r01_store_bench.txt): not the
-            // (k, c) arithmetic and not loads in flight (unrolling x2..x8, or a wave-uniform row loop with scalar row
-            // bases and 16-B buffer loads/stores, measured the same or slower) but L2 read misses under the streaming
-            // store: 36 % of the gather requests miss a 4 MB L2 that 17 MB of output per scan flow through, while a
-            // source that stays L2/MALL resident lets the identical loop run at 5 TB/s.  At 26 VGPRs a wave of this
-            // kernel fits beside the FPS workgroup that owns 94 % of a CU's registers (bench.py --pipeline).
+        // What bounds it (tools/store_bench.hip, tools/gpu_pmc_group.sh; profiles/r01_store_bench.txt): not the
+        // (k, c) arithmetic and not loads in flight (unrolling x2..x8, or a wave-uniform row loop with scalar row
+        // bases and 16-B buffer loads/stores, measured the same or slower) but L2 read misses under the streaming
+        // store: 36 % of the gather requests miss a 4 MB L2 that 17 MB of output per scan flow through, while a
+        // source that stays L2/MALL resident lets the identical loop run at 5 TB/s.
 #pragma unroll 1
-            for (int e = lane; e < total; e += kWave) {
-                const unsigned k = __umulhi((unsigned)e, magicC);
-                const unsigned c = (unsigned)e - k * (unsigned)C;
-                const unsigned cx = c - xo;
-                const bool isx = cx < 3u;
-                const float rel = srel[wv][k * 3 + (isx ? cx : 0u)];
-                const float ld = points[sfb[wv][k] + (isx ? 0u : c - fo)];
-                dst[e] = isx ? rel : ld;
-            }
+        for (int e = lane; e < total; e += kWave) {
+            const unsigned k = __umulhi((unsigned)e, magicC);  // e / C (exact for e < 2^32 / C)
+            const unsigned c = (unsigned)e - k * (unsigned)C;
+            const unsigned cx = c - xo;  // 0..2 inside the coordinate triple
+            const bool isx = cx < 3u;
+            const float rel = srel[wv][k * 3 + (isx ? cx : 0u)];
+            const float ld = points[sfb[wv][k] + (isx ? 0u : c - fo)];
+            dst[e] = isx ? rel : ld;
         }
     }
 }
@@ -506,18 +477,13 @@ TGN_API int tgn_group_points(int B, int N, int S, int K, int D, const float *xyz
     const unsigned magicC = (unsigned)((0x100000000ULL + C - 1) / C);
     long long blocks = ((queries + 3) / 4 + 7) / 8 * 8;  // one query per wave, grid a multiple of the 8 XCDs
     if (blocks > (1LL << 30)) blocks = 1LL << 30;
-    const char *ev = getenv("TGN_GROUP_VEC1");  // experiments: "0" selects the LDS-transposed 16-B store path
-    const bool vec4 = ((long long)K * C) % 4 == 0 && (ev && ev[0] == '0');  // default: 4-B path (measured faster)
     const float *pts = points ? points : xyz;
-#define TGN_GP_LAUNCH(IT, VEC)                                                                                  \
-    hipLaunchKernelGGL((group_points_kernel<IT, VEC>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, \
-                       queries, N, S, K, D, magicC, xyz, new_xyz, pts, (const IT *)idx, xyz_first, out, err)
-    if (idx_is_int64) {
-        if (vec4) TGN_GP_LAUNCH(long long, 4); else TGN_GP_LAUNCH(long long, 1);
-    } else {
-        if (vec4) TGN_GP_LAUNCH(int, 4); else TGN_GP_LAUNCH(int, 1);
-    }
-#undef TGN_GP_LAUNCH
+    if (idx_is_int64)
+        hipLaunchKernelGGL((group_points_kernel<long long>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           queries, N, S, K, D, magicC, xyz, new_xyz, pts, (const long long *)idx, xyz_first, out, err);
+    else
+        hipLaunchKernelGGL((group_points_kernel<int>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, queries,
+                           N, S, K, D, magicC, xyz, new_xyz, pts, (const int *)idx, xyz_first, out, err);
     return check_launch("group_points_kernel");
 }
 
