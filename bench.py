@@ -89,6 +89,9 @@ def main():
                     "(exact, certificate checked on the device) instead of iterating; reported separately, never the headline")
     ap.add_argument("--shape", default="A", choices=["A", "B"], help="A: the headline configuration (BASELINE.json config 2); "
                     "B: what the reference net instantiates (multi-scale grouping, SURVEY.md 8) -- not the headline")
+    ap.add_argument("--group-impl", type=int, default=0, help="grouping kernel: 0 choose, 1 = 4-B stores, 2 = 16-B stores through LDS")
+    ap.add_argument("--group-policy", type=int, default=-1, help="cache policy of the 16-B grouping stores (0 plain, 2 nt, 16 sc1; -1 default)")
+    ap.add_argument("--group-max-blocks", type=int, default=-1, help="grid bound of the grouping kernel (-1: 512 when pipelined, else none)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra with_fps_prefix_identity measurement (profiling runs)")
     args = ap.parse_args()
 
@@ -101,7 +104,9 @@ def main():
     B = args.batch
     shape = hotpath.SHAPE_A if args.shape == "A" else hotpath.SHAPE_B
     xyz, feats, scans = make_inputs(B, device, seed=100 + rank, shape=shape)
-    hp = hotpath.HotPath(B, device, shape=shape, pipeline=bool(args.pipeline), fps_prefix=bool(args.fps_prefix))
+    gopts = dict(group_impl=args.group_impl, group_policy=args.group_policy,
+                 group_max_blocks=None if args.group_max_blocks < 0 else args.group_max_blocks)
+    hp = hotpath.HotPath(B, device, shape=shape, pipeline=bool(args.pipeline), fps_prefix=bool(args.fps_prefix), **gopts)
     for _ in range(max(args.warmup, 0)):
         hp.run(xyz, feats, inputs_on_current_stream=False)   # the synthetic scans are resident before any step
     torch.cuda.synchronize()
@@ -187,7 +192,7 @@ def main():
         # reported next to the headline, never as the headline
         del hp
         torch.cuda.empty_cache()
-        hp2 = hotpath.HotPath(B, device, shape=shape, pipeline=bool(args.pipeline), fps_prefix=True)
+        hp2 = hotpath.HotPath(B, device, shape=shape, pipeline=bool(args.pipeline), fps_prefix=True, **gopts)
         for _ in range(max(args.warmup, 1)):
             hp2.run(xyz, feats, inputs_on_current_stream=False)
         torch.cuda.synchronize()

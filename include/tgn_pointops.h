@@ -45,8 +45,17 @@ typedef void *tgn_stream_t; /* a hipStream_t; NULL = the null stream */
 #define TGN_FPS_CUDA_COMPAT (TGN_FPS_FMA | TGN_FPS_TREE_TIES)
 
 const char *tgn_version(void);
-const char *tgn_last_error(void);
+const char *tgn_last_error(void);     /* per host thread */
+/* Stream of the section-1 entry points (which have no stream argument); per host thread, default NULL. */
 void tgn_set_default_stream(tgn_stream_t stream);
+/*
+ * FPS arithmetic of furthestsampling_cuda_launcher (which has no flags argument): any of TGN_FPS_TREE_TIES |
+ * TGN_FPS_FMA.  Process-wide; initialised from the environment (TGN_FPS_TIES=first|tree, TGN_FPS_FMA=0|1), default 0 =
+ * first-index ties, unfused distance.  TGN_FPS_TREE_TIES reproduces the tie order of the reference kernel's
+ * shared-memory tree (sampling_cuda_kernel.cu:5-10,64-123) and is pinned against that kernel (oracle/_ref).
+ */
+void tgn_set_fps_mode(int flags);
+int tgn_get_fps_mode(void);
 
 /* ------------------------------------------------------------------------------------------
  * 1. The reference's C ABI, verbatim (each line cites the declaration it replaces).
@@ -193,6 +202,15 @@ int tgn_ball_query(int B, int N, int S, int nsample, float r2, const float *xyz,
 int tgn_group_points(int B, int N, int S, int K, int D, const float *xyz, const float *new_xyz, const float *points,
                      const void *idx, int idx_is_int64, int xyz_first, float *out, tgn_stream_t stream);
 /*
+ * The same with the launch knobs exposed.  impl: 0 = choose, 1 = 4-B stores, 2 = 16-B stores through LDS (needs
+ * K*(3+D) % 4 == 0).  store_policy: cache-policy bits of the 16-B output stores (0 plain, 2 nt, 16 sc1 = write-through,
+ * the output lines do not stay in L2; -1 = default).  max_blocks: upper bound on the grid (0 = none) for callers
+ * that overlap the grouping with a kernel that needs most of every CU (the FPS level-1 workgroups).
+ */
+int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *xyz, const float *new_xyz,
+                        const float *points, const void *idx, int idx_is_int64, int xyz_first, float *out, int impl,
+                        int store_policy, int max_blocks, tgn_stream_t stream);
+/*
  * Fused first layer of a set-abstraction shared MLP, eval mode (pointnet2_utils.py:229-236, 281-294): the 1x1
  * convolution commutes with the gather, so the caller transforms the POINTS once (A = scale*(W_p*points + W_x*xyz),
  * (B,N,C)) and folds bias / BatchNorm / the centre term into Cst (B,S,C); this writes
@@ -219,9 +237,11 @@ int tgn_three_nn(int B, int N, int S, const float *xyz1, const float *xyz2, floa
 int tgn_three_interpolate(int B, int N, int S, int C, const float *points2, const float *dist, const void *idx,
                           int idx_is_int64, float *out, float *weight, tgn_stream_t stream);
 /*
- * tgn_group_points / tgn_gather_points skip rows whose index is outside [0,N) (the reference's advanced
- * indexing would raise there, e.g. an empty ball yields index N) and latch a device-side flag.  This
- * returns 1 and clears the flag if that happened since the last call; it synchronises `stream`.
+ * Gather indices follow torch's advanced indexing (pointnet2_utils.py:56-60): negative values wrap (k + N); an
+ * index still outside [0,N) -- where the reference raises, e.g. an empty ball yields index N -- makes
+ * tgn_gather_points write a zero row and tgn_group_points / tgn_sa_* read point 0, and latches a flag in the
+ * current device's memory.  This returns 1 and clears the flag if that happened on the current device since the
+ * last call; it synchronises `stream`.  (The Python operators call it and raise IndexError.)
  */
 int tgn_take_index_error(tgn_stream_t stream);
 

@@ -23,6 +23,12 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_r2():
+    """More outputs of the reference's own Python on CPU (tests/golden/make_golden_r2.py)."""
+    return dict(np.load(os.path.join(GOLDEN, "reference_cpu_r2.npz")))
+
+
+@pytest.fixture(scope="session")
 def regression():
     """Oracle-generated vectors for the CUDA-only operators (parity unpinned)."""
     return dict(np.load(os.path.join(GOLDEN, "oracle_regression.npz")))

@@ -106,26 +106,34 @@ def test_resample_fps_and_batched_preprocess(dev, oracle):
         resample.fps(meshes[0][:100], 200)
 
 
-def test_farthest_point_sample_np_random_start(dev):
-    from toothgroupnetwork_amd import pointnet2_utils as U
-    xyz = np.stack([synth.uniform_cloud(500, 1), synth.uniform_cloud(500, 2)])
-    torch.manual_seed(5)
-    idx = U.farthest_point_sample_np(xyz, 50)
-    assert idx.shape == (2, 50) and idx.dtype == np.int64
-    torch.manual_seed(5)
-    starts = torch.randint(0, 500, (2,)).numpy()
-    assert np.array_equal(idx[:, 0], starts)
-    for b in range(2):  # a valid FPS sequence from that start
-        d = np.full(500, np.inf)
-        for j in range(1, 50):
-            d = np.minimum(d, ((xyz[b] - xyz[b, idx[b, j - 1]]) ** 2).sum(1))
-            assert d[idx[b, j]] >= d.max() * (1 - 1e-5)
+def test_farthest_point_sample_np_random_start_matches_the_reference(dev, golden_r2):
+    """farthest_point_sample_np (pointnet2_utils.py:103-118): with the torch RNG seeded like the golden run, the random
+    starts and every index equal the reference's torch-CPU loop -- clouds with exact ties, duplicated vertices and an
+    exhausted cloud included (tests/golden/make_golden_r2.py)."""
+    from toothgroupnetwork_amd import _lib, pointnet2_utils as U
+    g = golden_r2
+    for name in ("arch", "lattice", "dupverts"):
+        xyz = g[f"fpsnp_{name}_xyz"]
+        for seed, npoint in ((1, 256), (2, 64)):
+            torch.manual_seed(seed)
+            idx = U.farthest_point_sample_np(xyz, npoint)
+            assert idx.dtype == np.int64 and np.array_equal(idx, g[f"fpsnp_{name}_{seed}_idx"]), (name, seed)
+    torch.manual_seed(7)
+    assert np.array_equal(U.farthest_point_sample_np(g["fpsnp_few_xyz"], 12), g["fpsnp_few_idx"])
+    # the function is torch-CPU semantics by definition: the kernels' tie-order switch does not reach it
+    prev = _lib.set_fps_mode(ties="tree")
+    try:
+        torch.manual_seed(1)
+        assert np.array_equal(U.farthest_point_sample_np(g["fpsnp_lattice_xyz"], 256), g["fpsnp_lattice_1_idx"])
+        assert _lib.get_fps_mode()[0] == "tree"
+    finally:
+        _lib.set_fps_mode(*prev)
 
 
 # ------------------------------------------------------------- full size (BASELINE.json shapes)
 def test_full_size_shape_a_properties(dev, oracle):
-    """24 000-point scans, npoint=[4096,1024,256], nsample=32, radii [0.05,0.1,0.2]: properties that do not
-    need the (slow) CPU oracle at full size, plus an exact oracle check of level 1 on one scan."""
+    """24 000-point scans, npoint=[4096,1024,256], nsample=32, radii [0.05,0.1,0.2]: size-independent properties on
+    every scan, plus an exact oracle check of FPS, ball query and grouping at all three levels on one scan."""
     from toothgroupnetwork_amd import pointnet2_utils as U
     scans = synth.scan_batch(3, 24000, "arch", seed=20)
     xyz = T(scans[:, :, :3], dev)
@@ -172,11 +180,17 @@ def test_full_size_shape_a_properties(dev, oracle):
         bi = torch.arange(3, device=dev).view(3, 1, 1)
         assert torch.equal(grouped[..., :3], cur_xyz[bi, gidx] - new_xyz.unsqueeze(2))
         assert torch.equal(grouped[..., 3:], cur_pts[bi, gidx])
-        if lvl == 0:
-            o_f = oracle.farthest_point_sample(scans[:1, :, :3], S)
-            assert np.array_equal(f[:1], o_f)
-            o_g = oracle.query_ball_point(r, K, scans[:1, :, :3], new_xyz[:1].cpu().numpy())
-            assert np.array_equal(g[:1], o_g)
+        # scan 0 against the CPU oracle at EVERY level (D = 6, 128, 512: the widths bench.py times): sampled
+        # indices, ball-query rows and the grouped tensor, bit for bit
+        cx0 = cur_xyz[:1].cpu().numpy()
+        o_f = oracle.farthest_point_sample(cx0, S)
+        assert np.array_equal(f[:1], o_f), lvl
+        o_new = oracle.index_points(cx0, o_f)
+        assert np.array_equal(new_xyz[:1].cpu().numpy(), o_new), lvl
+        o_g = oracle.query_ball_point(r, K, cx0, o_new)
+        assert np.array_equal(g[:1], o_g), lvl
+        o_grouped = oracle.group_points(cx0, o_new, cur_pts[:1].cpu().numpy(), o_g, True)
+        assert np.array_equal(grouped[:1].cpu().numpy(), o_grouped), lvl
         D_next = [128, 512, 0][lvl]
         cur_xyz = new_xyz.contiguous()
         if D_next:
@@ -257,9 +271,25 @@ def test_hotpath_multi_scale_grouping_matches_the_operators(dev):
             cur = new_xyz
 
 
-def test_pipelined_schedule_at_full_size_matches_one_stream(dev):
+def _oracle_chain(oracle, xyz0, feats0, shape):
+    """FPS -> ball query -> group of ONE scan through the CPU oracle, level by level (xyz0 (N,3), feats0[l] (N_l,D_l))."""
+    out = []
+    cur = xyz0[None]
+    for S, r, K, f in zip(shape["npoint"], shape["radius"], shape["nsample"], feats0):
+        fidx = oracle.farthest_point_sample(cur, S)
+        new_xyz = oracle.index_points(cur, fidx)
+        gidx = oracle.query_ball_point(r, K, cur, new_xyz)
+        grouped = oracle.group_points(cur, new_xyz, f[None], gidx, shape.get("xyz_first", True))
+        out.append(dict(fps_idx=fidx[0], new_xyz=new_xyz[0], group_idx=gidx[0], grouped=grouped[0]))
+        cur = new_xyz
+    return out
+
+
+def test_pipelined_schedule_at_full_size_matches_one_stream(dev, oracle):
     """256 scans of 24 000 points (the benchmark configuration), two different resident batches, overlapping pairs of
-    steps on the two streams: every result set must carry the one-stream checksums (tools/pipeline_stress.py, shorter)."""
+    steps on the two streams: every result set must carry the one-stream checksums (tools/pipeline_stress.py, shorter),
+    and two scans of every batch -- the first and one in the middle -- must equal the CPU ORACLE's chain bit for bit
+    at all three levels (so neither schedule is only compared with the other)."""
     from toothgroupnetwork_amd import hotpath
     B = 256
     batches = []
@@ -267,10 +297,24 @@ def test_pipelined_schedule_at_full_size_matches_one_stream(dev):
         pts = torch.from_numpy(synth.scan_batch(4, 24000, "arch", 700 + s)).to(dev).repeat(B // 4, 1, 1).contiguous()
         feats = [pts, torch.randn(B, 4096, 128, device=dev), torch.randn(B, 1024, 512, device=dev)]
         batches.append((pts[:, :, :3].contiguous(), feats))
+    probes = (0, 133)
+    want_oracle = [{b: _oracle_chain(oracle, xyz[b].cpu().numpy(), [f[b].cpu().numpy() for f in feats], hotpath.SHAPE_A)
+                    for b in probes} for xyz, feats in batches]
+
+    def check_against_oracle(levels, which, tag):
+        for b in probes:
+            for li, (l, o) in enumerate(zip(levels, want_oracle[which][b])):
+                assert np.array_equal(l["fps_idx"][b].cpu().numpy(), o["fps_idx"]), (tag, b, li, "fps")
+                assert np.array_equal(l["new_xyz"][b].cpu().numpy(), o["new_xyz"]), (tag, b, li, "new_xyz")
+                assert np.array_equal(l["group_idx"][b].cpu().numpy(), o["group_idx"]), (tag, b, li, "ball")
+                assert np.array_equal(l["grouped"][b].cpu().numpy(), o["grouped"]), (tag, b, li, "group")
+
     ref = hotpath.HotPath(B, dev)
     sums = []
-    for xyz, feats in batches:
+    for which, (xyz, feats) in enumerate(batches):
         lv = ref.run(xyz, feats)
+        torch.cuda.synchronize()
+        check_against_oracle(lv, which, "one stream")
         sums.append([(int(l["fps_idx"].long().sum()), int(l["group_idx"].long().sum()), float(l["grouped"].double().sum())) for l in lv])
     del ref
     torch.cuda.empty_cache()
@@ -279,9 +323,11 @@ def test_pipelined_schedule_at_full_size_matches_one_stream(dev):
         outs = []
         for step in (2 * pair, 2 * pair + 1):
             which = (step + pair) % 2
-            outs.append((hp.run(*batches[which], inputs_on_current_stream=False), sums[which]))
+            outs.append((hp.run(*batches[which], inputs_on_current_stream=False), sums[which], which))
         torch.cuda.synchronize()
-        for lv, want in outs:
+        for lv, want, which in outs:
             for l, (a, b, c) in zip(lv, want):
                 assert int(l["fps_idx"].long().sum()) == a and int(l["group_idx"].long().sum()) == b
                 assert float(l["grouped"].double().sum()) == c
+            if pair in (0, 5):
+                check_against_oracle(lv, which, f"pipelined pair {pair}")

@@ -171,6 +171,41 @@ def test_fps_vs_reference_kernel_on_this_gpu(dev, regression):
         assert torch.equal(out, ref)
 
 
+def test_fps_tree_tie_order_is_selectable_from_python_and_matches_the_reference_kernel(dev, regression):
+    """set_fps_mode(ties='tree') / TGN_FPS_TIES=tree make pointops.furthestsampling, pointnet2_utils.farthest_point_sample,
+    gen_utils-style resampling and the pointops_cuda shim sample the way the reference's own kernel does
+    (sampling_cuda_kernel.cu:5-10,64-123, compiled for gfx950 as oracle/_ref) -- duplicated vertices included."""
+    from oracle import ref_gpu
+    if not ref_gpu.available():
+        pytest.skip("oracle/_ref not built")
+    import pointops_cuda
+    from toothgroupnetwork_amd import _lib, pointnet2_utils as U, pointops as P, resample
+    dup = synth.lattice_cloud(12, dup=100, seed=3)                      # exact distance ties
+    scan = synth.arch_cloud(24000, 9, False)
+    scan[5000:5400] = scan[100:500]                                     # duplicated vertices, as raw scans have
+    prev = _lib.set_fps_mode(ties="tree")
+    try:
+        assert _lib.get_fps_mode() == ("tree", False) and _lib.lib().tgn_get_fps_mode() == _lib.FPS_TREE_TIES
+        differs = False
+        for xyz_np, m in ((dup, 700), (scan, 2048)):
+            n = xyz_np.shape[0]
+            xyz, off, noff = T(xyz_np, dev), T(np.array([n], np.int32), dev), T(np.array([m], np.int32), dev)
+            ref = ref_gpu.furthestsampling(xyz, off, noff)
+            assert torch.equal(P.furthestsampling(xyz, off, noff), ref)
+            assert torch.equal(U.farthest_point_sample(xyz[None], m)[0], ref.long())
+            assert np.array_equal(resample.fps(xyz_np.astype(np.float64), m), ref.cpu().numpy())
+            idx = torch.zeros(m, dtype=torch.int32, device=dev)
+            pointops_cuda.furthestsampling_cuda(1, n, xyz, off, noff, torch.full((n,), 1e10, device=dev), idx)
+            assert torch.equal(idx, ref)
+            _lib.set_fps_mode(ties="first")
+            differs |= not torch.equal(P.furthestsampling(xyz, off, noff), ref)
+            _lib.set_fps_mode(ties="tree")
+        assert differs, "the tie order must matter on clouds with duplicated vertices"
+    finally:
+        _lib.set_fps_mode(*prev)
+    assert _lib.lib().tgn_get_fps_mode() == _lib.fps_flags()
+
+
 # ------------------------------------------------------------------------------ square_distance
 def test_square_distance_matches_golden_bit_exact(dev, golden):
     from toothgroupnetwork_amd import pointnet2_utils as U
@@ -264,10 +299,12 @@ def test_group_points_orders_and_index_points(dev, oracle):
     assert np.array_equal(got.cpu().numpy(), oracle.index_points(pts, idx))
 
 
-@pytest.mark.parametrize("D,K", [(64, 32), (128, 32), (131, 7), (200, 33), (256, 64), (512, 32), (320, 128), (66, 1)])
-def test_group_points_wide_rows(dev, oracle, D, K):
-    """D >= 64 takes the row kernel (buffer loads/stores of 1, 2 or 4 floats per lane): every width, K not a multiple
-    of the rows in flight, K > 64 (second index register), both channel orders, both index types, a bad index."""
+@pytest.mark.parametrize("D,K", [(64, 32), (128, 32), (131, 7), (200, 33), (256, 64), (512, 32), (320, 128), (66, 1),
+                                 (61, 4), (62, 8), (125, 36), (129, 24), (509, 32), (1024, 64), (6, 32), (13, 16), (1, 64)])
+def test_group_points_wide_rows(dev, oracle, D, K, monkeypatch):
+    """every row width class of the grouping kernels: rows shorter and longer than a 64-float sub-step, K*(3+D) a
+    multiple of 4 (16-B store kernel) or not (4-B kernel), K > 64, both channel orders, both index types, negative
+    (wrapping) indices and an out-of-range one."""
     from toothgroupnetwork_amd import _lib, pointnet2_utils as U
     rng = np.random.default_rng(D * 1000 + K)
     B, N, S = 2, 300, 37
@@ -281,22 +318,63 @@ def test_group_points_wide_rows(dev, oracle, D, K):
             got = U.group_points(T(xyz, dev), T(new_xyz, dev), T(pts, dev), T(idx.astype(dt), dev), xyz_first=xyz_first)
             assert np.array_equal(got.cpu().numpy(), want)
     assert _lib.lib().tgn_take_index_error(_lib.stream()) == 0
+    # negative indices wrap like torch's advanced indexing (reference pointnet2_utils.py:56-60)
+    neg = idx.copy()
+    neg[0, 3, 0] -= N
+    neg[1, 7, K - 1] -= N
+    got = U.group_points(T(xyz, dev), T(new_xyz, dev), T(pts, dev), T(neg, dev))
+    assert np.array_equal(got.cpu().numpy(), oracle.group_points(xyz, new_xyz, pts, idx, True))
+    # out of range: IndexError like the reference (the empty-ball marker N)
     bad = idx.copy()
-    bad[1, 5, K // 2] = N                              # the empty-ball marker: row filled from point 0, error word set
+    bad[1, 5, K // 2] = N
+    with pytest.raises(IndexError):
+        U.group_points(T(xyz, dev), T(new_xyz, dev), T(pts, dev), T(bad, dev))
+    assert _lib.lib().tgn_take_index_error(_lib.stream()) == 0      # raising consumed the flag
+    # TGN_INDEX_CHECK=off: no sync, no exception; the row is filled from point 0 and the flag stays readable
+    monkeypatch.setattr(_lib, "INDEX_CHECK", "off")
     got = U.group_points(T(xyz, dev), T(new_xyz, dev), T(pts, dev), T(bad, dev))
-    assert _lib.lib().tgn_take_index_error(_lib.stream()) == 1
+    assert _lib.take_index_error() and not _lib.take_index_error()
     bad[1, 5, K // 2] = 0
     assert np.array_equal(got.cpu().numpy(), oracle.group_points(xyz, new_xyz, pts, bad, True))
 
 
-def test_group_points_empty_ball_is_reported(dev):
+@pytest.mark.parametrize("impl,policy", [(1, -1), (2, 0), (2, 2), (2, 16), (2, 17), (2, 18)])
+@pytest.mark.parametrize("N,S,K,D", [(4096, 1024, 32, 128), (1024, 256, 32, 512), (3000, 500, 32, 6), (777, 99, 64, 253)])
+def test_group_points_every_kernel_variant(dev, oracle, impl, policy, N, S, K, D):
+    """tgn_group_points_ex: the 4-B kernel and the 16-B kernel with each store policy, bounded and unbounded grids,
+    must write the same bytes as the oracle (sample_and_group, pointnet2_utils.py:162-169)."""
+    from toothgroupnetwork_amd import _lib
+    rng = np.random.default_rng(N + K + D)
+    B = 9
+    xyz = rng.normal(size=(B, N, 3)).astype(np.float32)
+    pts = rng.normal(size=(B, N, D)).astype(np.float32)
+    new_xyz = xyz[:, :S].copy()
+    idx = rng.integers(0, N, size=(B, S, K)).astype(np.int32)
+    want = oracle.group_points(xyz, new_xyz, pts, idx.astype(np.int64), True)
+    L = _lib.lib()
+    tx, tn, tp, ti = T(xyz, dev), T(new_xyz, dev), T(pts, dev), T(idx, dev)
+    for max_blocks in (0, 256, 8):
+        out = torch.full((B, S, K, 3 + D), float("nan"), device=dev)
+        _lib.check(L.tgn_group_points_ex(B, N, S, K, D, _lib.ptr(tx), _lib.ptr(tn), _lib.ptr(tp), _lib.ptr(ti), 0, 1,
+                                         _lib.ptr(out), impl, policy, max_blocks, _lib.stream()))
+        assert np.array_equal(out.cpu().numpy(), want), (impl, policy, max_blocks)
+
+
+def test_group_points_empty_ball_raises_like_the_reference(dev):
     from toothgroupnetwork_amd import _lib, pointnet2_utils as U
     xyz = T(synth.uniform_cloud(64, 1)[None], dev)
     far = torch.full((1, 1, 3), 30.0, device=dev)
-    idx = U.query_ball_point(0.1, 4, xyz, far)          # all N: out of range, the reference would raise
-    U.group_points(xyz, far, None, idx)
-    assert _lib.lib().tgn_take_index_error(_lib.stream()) == 1
+    idx = U.query_ball_point(0.1, 4, xyz, far)          # all N: out of range, the reference raises (:136-141 -> :56-60)
+    with pytest.raises(IndexError):
+        U.group_points(xyz, far, None, idx)
+    with pytest.raises(IndexError):
+        U.index_points(xyz, idx)
+    with pytest.raises(IndexError):
+        U.index_points(xyz, idx - 200)                  # below -N
     assert _lib.lib().tgn_take_index_error(_lib.stream()) == 0
+    # index_points wraps negative indices
+    neg = torch.tensor([[-1, -64, 5]], device=dev)
+    assert torch.equal(U.index_points(xyz, neg), xyz[:, [63, 0, 5]])
 
 
 def test_grouping_autograd_matches_torch_indexing(dev):

@@ -25,6 +25,8 @@ SIGNATURES = {
     "tgn_version": (ctypes.c_char_p, []),
     "tgn_last_error": (ctypes.c_char_p, []),
     "tgn_set_default_stream": (None, [_P]),
+    "tgn_set_fps_mode": (None, [c_int]),
+    "tgn_get_fps_mode": (c_int, []),
     # section 1: the reference's launchers
     "furthestsampling_cuda_launcher": (None, [c_int, c_int, _P, _P, _P, _P, _P]),
     "knnquery_cuda_launcher": (None, [c_int, c_int, _P, _P, _P, _P, _P, _P]),
@@ -62,6 +64,7 @@ SIGNATURES = {
     "tgn_ball_query_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "tgn_ball_query": (c_int, [c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "tgn_group_points": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "tgn_group_points_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, c_int, c_int, c_int, _P]),
     "tgn_sa_first_layer": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P]),
     "tgn_sa_first_layer_max": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P]),
     "tgn_gather_points": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P]),
@@ -77,6 +80,45 @@ FPS_LOCAL_INDEX = 2
 FPS_INDEX64 = 4
 FPS_TREE_TIES = 8
 FPS_CUDA_COMPAT = FPS_FMA | FPS_TREE_TIES
+
+
+# Which farthest-point-sampling arithmetic the Python operators ask for:
+#   ties  'first' (default): equal distances -> lowest point index, what torch-CPU's farthest_point_sample_np does
+#                 (pointnet2_utils.py:103-118) -- the canonical mode, pinned against the reference's torch code;
+#         'tree': equal distances resolved like the reference CUDA kernel's shared-memory tree
+#                 (sampling_cuda_kernel.cu:5-10,64-123) -- pinned against that kernel compiled for gfx950 (oracle/_ref);
+#   fma   False (default): d = ((dx*dx)+(dy*dy))+(dz*dz), the source order of sampling_cuda_kernel.cu:54;
+#         True: fma(dz,dz,fma(dy,dy,dx*dx)), nvcc's presumed contraction (parity unpinned: no CUDA device here).
+# Environment: TGN_FPS_TIES=first|tree, TGN_FPS_FMA=0|1; or set_fps_mode() at run time.
+_fps_mode = {"ties": os.environ.get("TGN_FPS_TIES", "first").lower(), "fma": os.environ.get("TGN_FPS_FMA", "0") == "1"}
+
+
+def set_fps_mode(ties=None, fma=None):
+    """Select the FPS tie order ('first' | 'tree') and distance contraction used by pointops.furthestsampling,
+    pointnet2_utils.farthest_point_sample and the modules built on them.  Returns the previous (ties, fma)."""
+    prev = (_fps_mode["ties"], _fps_mode["fma"])
+    if ties is not None:
+        if ties not in ("first", "tree"):
+            raise ValueError("ties must be 'first' or 'tree'")
+        _fps_mode["ties"] = ties
+    if fma is not None:
+        _fps_mode["fma"] = bool(fma)
+    if _lib is not None or os.path.exists(LIB_PATH):
+        lib().tgn_set_fps_mode(fps_flags())   # the reference-signature launcher (pointops_cuda shim) follows too
+    return prev
+
+
+def get_fps_mode():
+    return _fps_mode["ties"], _fps_mode["fma"]
+
+
+def fps_flags(cuda_compat=False):
+    """Flag bits of tgn_furthestsampling* for the current mode; cuda_compat=True forces tree ties + FMA."""
+    if cuda_compat:
+        return FPS_CUDA_COMPAT
+    if _fps_mode["ties"] not in ("first", "tree"):
+        raise ValueError(f"TGN_FPS_TIES={_fps_mode['ties']!r}: expected 'first' or 'tree'")
+    return (FPS_TREE_TIES if _fps_mode["ties"] == "tree" else 0) | (FPS_FMA if _fps_mode["fma"] else 0)
 
 
 class TgnLibraryError(RuntimeError):
@@ -123,6 +165,26 @@ def require_cuda(*tensors):
             raise RuntimeError(
                 "toothgroupnetwork_amd operators run only on a ROCm GPU (got a CPU tensor); "
                 "there is deliberately no CPU fallback -- the CPU restatement lives in oracle/ and is test-only.")
+
+
+# What the gather family does about an index outside [-N, N) -- where the reference's advanced indexing raises
+# (pointnet2_utils.py:56-60; an empty ball yields index N, :136-141).  The kernels latch a per-device flag;
+#   TGN_INDEX_CHECK=sync (default): index_points / group_points read the flag after their launch (one 4-byte
+#       device->host copy + stream sync) and raise IndexError like the reference's CPU path;
+#   TGN_INDEX_CHECK=off: no check, no sync (rows with a bad index are filled from point 0 / zeros);
+#       take_index_error() can be called by hand at any synchronisation point.
+INDEX_CHECK = os.environ.get("TGN_INDEX_CHECK", "sync").lower()
+
+
+def take_index_error():
+    """True (and the flag is cleared) if a gather on the current device saw an out-of-range index since the last call."""
+    return bool(lib().tgn_take_index_error(stream()))
+
+
+def raise_on_index_error(what):
+    if INDEX_CHECK != "off" and take_index_error():
+        raise IndexError(f"{what}: index out of range for the gathered dimension "
+                         "(the reference's advanced indexing raises here too, pointnet2_utils.py:56-60)")
 
 
 def as_int(v):

@@ -24,6 +24,9 @@
 //   which is what oracle/_ref is and what the GPU tests pin this kernel against.
 #include "fps_common.h"
 
+#include <atomic>
+#include <stdlib.h>
+
 #include <stdlib.h>
 #include <string.h>
 
@@ -369,8 +372,32 @@ TGN_API int tgn_furthestsampling_dense_prefix(int B, int N, int S, const float *
     return fps_dispatch(B, N, a, (hipStream_t)stream);
 }
 
-// Reference ABI (sampling_cuda_kernel.h:13): global int32 indices, canonical arithmetic, default stream.
+// Tie order / contraction of the reference-signature entry point (it has no flags argument): TGN_FPS_TREE_TIES and
+// TGN_FPS_FMA bits, initialised from the environment (TGN_FPS_TIES=first|tree, TGN_FPS_FMA=0|1) and settable at run time.
+static std::atomic<int> g_fps_legacy_flags{-1};
+
+static int fps_legacy_flags() {
+    int f = g_fps_legacy_flags.load(std::memory_order_relaxed);
+    if (f < 0) {
+        f = 0;
+        const char *t = getenv("TGN_FPS_TIES");
+        if (t && (t[0] == 't' || t[0] == 'T')) f |= TGN_FPS_TREE_TIES;
+        const char *m = getenv("TGN_FPS_FMA");
+        if (m && m[0] == '1') f |= TGN_FPS_FMA;
+        g_fps_legacy_flags.store(f, std::memory_order_relaxed);
+    }
+    return f;
+}
+
+TGN_API void tgn_set_fps_mode(int flags) {
+    g_fps_legacy_flags.store(flags & (TGN_FPS_TREE_TIES | TGN_FPS_FMA), std::memory_order_relaxed);
+}
+TGN_API int tgn_get_fps_mode(void) { return fps_legacy_flags(); }
+
+// Reference ABI (sampling_cuda_kernel.h:13): global int32 indices, default stream; arithmetic per tgn_set_fps_mode
+// (default: the canonical first-index tie order, unfused distance).
 TGN_API void furthestsampling_cuda_launcher(int b, int n, const float *xyz, const int *offset, const int *new_offset,
                                             float *tmp, int *idx) {
-    (void)tgn_furthestsampling(b, n, xyz, offset, new_offset, tmp, idx, nullptr, 0, (tgn_stream_t)default_stream());
+    (void)tgn_furthestsampling(b, n, xyz, offset, new_offset, tmp, idx, nullptr, fps_legacy_flags(),
+                               (tgn_stream_t)default_stream());
 }

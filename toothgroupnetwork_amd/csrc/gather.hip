@@ -169,74 +169,8 @@ __global__ __launch_bounds__(256) void aggregation_bwd_kernel(long long rows, in
     }
 }
 
-// ---- pointnet2_utils composites -------------------------------------------------------------------
-// group_points: one wave per query (b,s).  The wave's output, K rows of C = 3+D floats, is ONE contiguous region of
-// K*C floats: lanes walk the flattened (k,c) space, 64 consecutive floats per step, however odd C is (9, 131, 515
-// at Shape A) -- gathers and stores are both lane-contiguous (a lane-strided gather touches 4x the cache lines and is
-// address-path bound at ~2 TB/s; 16-B stores through an LDS transpose measured slower than 4-B ones).  The
-// neighbour row offsets and the centred coordinates of the query sit in per-wave LDS tables.
-// 24 VGPRs on purpose: beside an FPS workgroup (2 waves x 232 of a SIMD's 512 registers) TWO waves of this kernel
-// fit per SIMD (bench.py --pipeline; tests/test_build_resources.py guards both numbers).
+// ---- pointnet2_utils composites (group_points lives in group.hip) ---------------------------------
 constexpr int kGroupMaxK = 128;
-
-template <typename IdxT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(24))) void group_points_kernel(
-    long long queries, int N, int S, int K, int D, unsigned magicC, const float *__restrict__ xyz,
-    const float *__restrict__ new_xyz, const float *__restrict__ points, const IdxT *__restrict__ idx, int xyz_first,
-    float *__restrict__ out, int *__restrict__ err) {
-    // per wave and neighbour k: element offset of its feature row, and its centred coordinates
-    __shared__ unsigned sfb[4][kGroupMaxK];
-    __shared__ float srel[4][kGroupMaxK * 3];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: q and its pointers live in SGPRs
-    const int C = 3 + D;
-    const unsigned xo = xyz_first ? 0 : D;   // first channel of the relative coordinates
-    const unsigned fo = xyz_first ? 3 : 0;   // first channel of the features
-    const int total = K * C;
-    // XCD-aware block order: hardware block i runs on XCD i % 8 (observed dispatch; speed only).  Logical
-    // block ids are laid out so that every XCD walks ONE contiguous range of queries, i.e. all queries of a
-    // scan hit the same XCD's L2, where the scan's feature rows (re-read ~S*K/N times) stay resident.
-    const unsigned nb = gridDim.x;  // multiple of 8
-    const unsigned lb = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
-    for (long long q = (long long)lb * 4 + wv; q < queries; q += (long long)nb * 4) {
-        const int b = (int)(q / S);
-        const float cq0 = new_xyz[q * 3 + 0], cq1 = new_xyz[q * 3 + 1], cq2 = new_xyz[q * 3 + 2];
-        const size_t pbase = (size_t)b * N;
-        bool bad = false;
-        const IdxT *__restrict__ qidx = idx + q * K;  // wave-uniform
-        for (int k = lane; k < K; k += kWave) {
-            const long long v64 = (long long)qidx[k];
-            unsigned v = (unsigned)v64;
-            if (v64 < 0 || v64 >= N) {  // empty ball -> index N: the reference's advanced indexing raises;
-                bad = true;             // here the row is filled from point 0 and the error word is set
-                v = 0;
-            }
-            const unsigned pv = (unsigned)pbase + v;  // B*N*max(D,3) < 2^32 is checked by the launcher
-            sfb[wv][k] = pv * (unsigned)D;
-            srel[wv][k * 3 + 0] = xyz[pv * 3u + 0u] - cq0;
-            srel[wv][k * 3 + 1] = xyz[pv * 3u + 1u] - cq1;
-            srel[wv][k * 3 + 2] = xyz[pv * 3u + 2u] - cq2;
-        }
-        if (__any(bad) && lane == 0) atomicOr(err, 1);
-        // (the same wave wrote the tables: LDS operations of one wave complete in order, no barrier needed)
-        float *__restrict__ dst = out + (size_t)q * total;
-        // What bounds it (tools/store_bench.hip, tools/gpu_pmc_group.sh; profiles/r01_store_bench.txt): not the
-        // (k, c) arithmetic and not loads in flight (unrolling x2..x8, or a wave-uniform row loop with scalar row
-        // bases and 16-B buffer loads/stores, measured the same or slower) but L2 read misses under the streaming
-        // store: 36 % of the gather requests miss a 4 MB L2 that 17 MB of output per scan flow through, while a
-        // source that stays L2/MALL resident lets the identical loop run at 5 TB/s.
-#pragma unroll 1
-        for (int e = lane; e < total; e += kWave) {
-            const unsigned k = __umulhi((unsigned)e, magicC);  // e / C (exact for e < 2^32 / C)
-            const unsigned c = (unsigned)e - k * (unsigned)C;
-            const unsigned cx = c - xo;  // 0..2 inside the coordinate triple
-            const bool isx = cx < 3u;
-            const float rel = srel[wv][k * 3 + (isx ? cx : 0u)];
-            const float ld = points[sfb[wv][k] + (isx ? 0u : c - fo)];
-            dst[e] = isx ? rel : ld;
-        }
-    }
-}
 
 // Set-abstraction first layer, fused.  A 1x1 convolution commutes with the gather:
 //   W * [points[idx], xyz[idx] - c] + b  ==  (W_p*points + W_x*xyz)[idx] - W_x*c + b
@@ -263,15 +197,15 @@ __global__ __launch_bounds__(256) void sa_first_layer_kernel(long long queries, 
         const IdxT *__restrict__ qidx = idx + q * K;
         bool bad = false;
         for (int k = lane; k < K; k += kWave) {
-            const long long v64 = (long long)qidx[k];
-            unsigned v = (unsigned)v64;
+            long long v64 = (long long)qidx[k];
+            if (v64 < 0) v64 += N;
             if (v64 < 0 || v64 >= N) {
                 bad = true;
-                v = 0;
+                v64 = 0;
             }
-            sfb[wv][k] = ((unsigned)pbase + v) * (unsigned)C;
+            sfb[wv][k] = ((unsigned)pbase + (unsigned)v64) * (unsigned)C;
         }
-        if (__any(bad) && lane == 0) atomicOr(err, 1);
+        if (err && __any(bad) && lane == 0) atomicOr(err, 1);
         const float *__restrict__ cst = Cst + (size_t)q * C;
         if constexpr (MAXK) {
             float *__restrict__ dst = out + (size_t)q * C;
@@ -302,13 +236,15 @@ __global__ __launch_bounds__(256) void gather_points_kernel(long long rows, int 
                                                              int *__restrict__ err) {
     TGN_ROW_LOOP(rows) {  // r = b*M + j
         const int b = (int)(r / M);
-        const long long k = (long long)idx[r];
-        if (k < 0 || k >= N) {
-            if (tx == 0) atomicOr(err, 1);
+        long long k = (long long)idx[r];
+        if (k < 0) k += N;  // torch's advanced indexing wraps negative indices (pointnet2_utils.py:56-60)
+        float *dst = out + (size_t)r * C;
+        if (k < 0 || k >= N) {  // the reference raises here: the row is zero-filled and the error word latched
+            if (err && tx == 0) atomicOr(err, 1);
+            for (int ci = tx; ci < C; ci += cx) dst[ci] = 0.0f;
             continue;
         }
         const float *src = points + ((size_t)b * N + k) * C;
-        float *dst = out + (size_t)r * C;
         for (int ci = tx; ci < C; ci += cx) dst[ci] = src[ci];
     }
 }
@@ -320,7 +256,8 @@ __global__ __launch_bounds__(256) void scatter_add_points_kernel(long long rows,
                                                                   float *__restrict__ grad_points) {
     TGN_ROW_LOOP(rows) {
         const int b = (int)(r / M);
-        const long long k = (long long)idx[r];
+        long long k = (long long)idx[r];
+        if (k < 0) k += N;
         if (k < 0 || k >= N) continue;
         float *dst = grad_points + ((size_t)b * N + k) * C;
         const float *src = grad_out + (size_t)r * C;
@@ -354,16 +291,6 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(long long rows, 
         for (int ci = tx; ci < C; ci += cx)
             dst[ci] = ((f0[ci] * w0) + (f1[ci] * w1)) + (f2[ci] * w2);
     }
-}
-
-// device-side error word for out-of-range gather indices (async; checked by tgn_take_index_error)
-static int *index_error_word() {
-    static int *w = nullptr;
-    if (!w) {
-        if (hipMalloc((void **)&w, sizeof(int)) != hipSuccess) return nullptr;
-        (void)hipMemset(w, 0, sizeof(int));
-    }
-    return w;
 }
 
 }  // namespace tgn
@@ -457,36 +384,6 @@ TGN_API int tgn_aggregation_backward(int n, int nsample, int c, int w_c, const f
     return check_launch("aggregation_bwd_kernel");
 }
 
-TGN_API int tgn_group_points(int B, int N, int S, int K, int D, const float *xyz, const float *new_xyz,
-                             const float *points, const void *idx, int idx_is_int64, int xyz_first, float *out,
-                             tgn_stream_t stream) {
-    const long long queries = (long long)B * S;
-    if (queries <= 0 || K <= 0) return TGN_OK;
-    if (!xyz || !new_xyz || !idx || !out) {
-        set_error("tgn_group_points: null pointer");
-        return TGN_ERR_INVALID_ARGUMENT;
-    }
-    if (!points) D = 0;
-    if (K > kGroupMaxK || D < 0 || (long long)K * (3 + D) >= (1LL << 31) / (3 + D) ||
-        (long long)B * N * (D > 3 ? D : 3) >= (1LL << 32)) {
-        set_error("tgn_group_points: nsample %d / channels %d out of the supported range", K, 3 + D);
-        return TGN_ERR_UNSUPPORTED;
-    }
-    int *err = index_error_word();
-    const int C = 3 + D;
-    const unsigned magicC = (unsigned)((0x100000000ULL + C - 1) / C);
-    long long blocks = ((queries + 3) / 4 + 7) / 8 * 8;  // one query per wave, grid a multiple of the 8 XCDs
-    if (blocks > (1LL << 30)) blocks = 1LL << 30;
-    const float *pts = points ? points : xyz;
-    if (idx_is_int64)
-        hipLaunchKernelGGL((group_points_kernel<long long>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                           queries, N, S, K, D, magicC, xyz, new_xyz, pts, (const long long *)idx, xyz_first, out, err);
-    else
-        hipLaunchKernelGGL((group_points_kernel<int>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, queries,
-                           N, S, K, D, magicC, xyz, new_xyz, pts, (const int *)idx, xyz_first, out, err);
-    return check_launch("group_points_kernel");
-}
-
 static int sa_first_layer_launch(int B, int N, int S, int K, int C, const float *A, const float *Cst, const void *idx,
                                  int idx_is_int64, int relu, float *out, bool maxk, hipStream_t st) {
     const long long queries = (long long)B * S;
@@ -500,6 +397,10 @@ static int sa_first_layer_launch(int B, int N, int S, int K, int C, const float 
         return TGN_ERR_UNSUPPORTED;
     }
     int *err = index_error_word();
+    if (C == 1) {  // e / C as umulhi(e, ceil(2^32 / C)) needs the magic to fit 32 bits
+        set_error("tgn_sa_first_layer: a single output channel is not supported by the fused kernel");
+        return TGN_ERR_UNSUPPORTED;
+    }
     const unsigned magicC = (unsigned)((0x100000000ULL + C - 1) / C);
     const long long blocks = ((queries + 3) / 4 + 7) / 8 * 8;
 #define TGN_SA_LAUNCH(IT, MK)                                                                                     \
@@ -565,18 +466,6 @@ TGN_API int tgn_three_interpolate(int B, int N, int S, int C, const float *point
         hipLaunchKernelGGL((three_interpolate_kernel<int>), dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, N, S,
                            C, s.cx_log2, points2, dist, (const int *)idx, out, weight);
     return check_launch("three_interpolate_kernel");
-}
-
-// Returns 1 (and clears the flag) if any gather since the last call saw an out-of-range index.
-// Synchronises the stream: the host wrapper calls it only where the reference itself would raise.
-extern "C" __attribute__((visibility("default"))) int tgn_take_index_error(tgn_stream_t stream) {
-    int *w = index_error_word();
-    if (!w) return 0;
-    int h = 0;
-    if (hipMemcpyAsync(&h, w, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return 0;
-    (void)hipStreamSynchronize((hipStream_t)stream);
-    if (h) (void)hipMemsetAsync(w, 0, sizeof(int), (hipStream_t)stream);
-    return h;
 }
 
 // ---- reference ABI (default stream, void) ---------------------------------------------------------

@@ -17,6 +17,7 @@ constexpr int kWave = 64;
 
 void set_error(const char *fmt, ...);
 hipStream_t default_stream();
+int *index_error_word();  // per-device error word of the gather family (capi.hip); nullptr if it cannot be allocated
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

@@ -55,8 +55,13 @@ class HotPath:
     ball query / grouping of level l of the same step, and step k-2's consumers before step k's producers."""
 
     def __init__(self, B, device, shape=SHAPE_A, xyz_first=True, index_dtype=torch.int32, pipeline=False,
-                 fps_prefix=False):
+                 fps_prefix=False, group_impl=0, group_policy=-1, group_max_blocks=None):
         self.B, self.device, self.shape = B, device, shape
+        # launch knobs of the grouping kernel (include/tgn_pointops.h, tgn_group_points_ex).  In the two-stream schedule
+        # its grid is bounded so that an FPS level-1 workgroup (which needs an almost empty CU) always finds room:
+        # 512 blocks = 2 per CU = 2 waves per SIMD, what fits beside 2 x 232 VGPRs of FPS.
+        self.group_impl, self.group_policy = int(group_impl), int(group_policy)
+        self.group_max_blocks = int(group_max_blocks) if group_max_blocks is not None else (512 if pipeline else 0)
         # fps_prefix: hand every FPS level the certificate of the level that produced its input (FPS of an FPS result
         # is the identity, include/tgn_pointops.h): levels > 0 then return 0..S-1 without iterating, decided per cloud
         # on the device.  Off by default: the headline benchmark runs every level's sampling for real.
@@ -102,9 +107,10 @@ class HotPath:
                                            ptr(br["group_idx"]), self.idx64, ptr(br["ws"]), br["ws_bytes"], st), "ball_query")
 
     def _group(self, lv, br, cur_xyz, pts, st):
-        return check(self.L.tgn_group_points(self.B, lv["N"], lv["S"], br["K"], lv["D"], ptr(cur_xyz), ptr(lv["new_xyz"]),
-                                             ptr(pts), ptr(br["group_idx"]), self.idx64, int(self.xyz_first),
-                                             ptr(br["grouped"]), st), "group_points")
+        return check(self.L.tgn_group_points_ex(self.B, lv["N"], lv["S"], br["K"], lv["D"], ptr(cur_xyz), ptr(lv["new_xyz"]),
+                                                ptr(pts), ptr(br["group_idx"]), self.idx64, int(self.xyz_first),
+                                                ptr(br["grouped"]), self.group_impl, self.group_policy,
+                                                self.group_max_blocks, st), "group_points")
 
     def enable_kernel_timing(self, steps):
         """HIP events on the launch stream around each kernel class (start/stop per step)."""

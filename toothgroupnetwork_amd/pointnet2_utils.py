@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from . import _lib
+from ._fps_prefix import PrefixBook
 from ._lib import as_int, check, lib, ptr, require_cuda, stream
 
 _fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
@@ -56,6 +57,8 @@ class _SquareDistance3(Function):
     def forward(ctx, src, dst):
         src, dst = _f32c(src), _f32c(dst)
         B, N, _ = src.shape
+        if dst.shape[0] != B:
+            raise RuntimeError(f"square_distance: batch sizes differ ({B} vs {dst.shape[0]})")
         M = dst.shape[1]
         out = torch.empty(B, N, M, dtype=torch.float32, device=src.device)
         check(lib().tgn_square_distance(B, N, M, ptr(src), ptr(dst), ptr(out), stream()), "square_distance")
@@ -102,6 +105,7 @@ class _IndexPoints(Function):
         out = torch.empty(tuple(idx.shape) + (C,), dtype=torch.float32, device=points.device)
         check(lib().tgn_gather_points(B, N, M, C, ptr(points), ptr(idx), int(idx.dtype == torch.int64), ptr(out),
                                       stream()), "gather_points")
+        _lib.raise_on_index_error("index_points")
         ctx.shape = (B, N, M, C)
         ctx.save_for_backward(idx)
         return out
@@ -120,7 +124,10 @@ class _IndexPoints(Function):
 
 def index_points(points, idx):
     """points (B,N,C) gathered with idx (B,S) or (B,S,K) (int64/int32, per-cloud indices) -> (B,S[,K],C);
-    differentiable w.r.t. points (scatter-add backward)."""
+    differentiable w.r.t. points (scatter-add backward).  Negative indices wrap and an index outside [-N, N) raises
+    IndexError, as torch's advanced indexing does in the reference (pointnet2_utils.py:56-60); the check costs one
+    stream synchronisation per call (TGN_INDEX_CHECK=off drops it: such rows are then zero-filled and
+    _lib.take_index_error() reports them)."""
     require_cuda(points, idx)
     if idx.dtype not in (torch.int64, torch.int32):
         idx = idx.long()
@@ -138,13 +145,12 @@ def index_points(points, idx):
 # how the tensor travelled (module round trips, index_points(xyz, fps_idx), copies).  TGN_FPS_PREFIX=0 turns it off.
 # ---------------------------------------------------------------------------------------------
 FPS_PREFIX = os.environ.get("TGN_FPS_PREFIX", "1") != "0"
-_FPS_RESULTS_CAP = 8
-_fps_results = []    # (B, S, device, new_xyz (B,S,3), certificate (B,) int32), most recent last
-fps_prefix_stats = {"offered": 0}
+_fps_book = PrefixBook()
+fps_prefix_stats = _fps_book.stats
 
 
 def fps_prefix_clear():
-    del _fps_results[:]
+    _fps_book.clear()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -155,54 +161,62 @@ def _fps_dense(xyz, npoint, want_coords=False, cuda_compat=False):
     npoint = as_int(npoint)
     xyz = _f32c(xyz.detach())
     B, N, _ = xyz.shape
-    use_prefix = FPS_PREFIX and not cuda_compat      # the tree tie order of cuda-compat breaks the identity
+    mode = _lib.fps_flags(cuda_compat)
+    use_prefix = FPS_PREFIX and not (mode & _lib.FPS_TREE_TIES)   # the tree tie order breaks the identity
     idx = torch.empty(B, npoint, dtype=torch.int64, device=xyz.device)
     new_xyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=xyz.device) if (want_coords or use_prefix) else None
     if B == 0 or npoint == 0:
         return idx, (new_xyz if want_coords else None)
     from .pointops import fps_workspace
     ws, nbytes = fps_workspace(B, N, B * N, xyz.device)
-    flags = _lib.FPS_LOCAL_INDEX | _lib.FPS_INDEX64 | (_lib.FPS_CUDA_COMPAT if cuda_compat else 0)
+    flags = _lib.FPS_LOCAL_INDEX | _lib.FPS_INDEX64 | mode
     cert_in = ref = cert_out = None
     if use_prefix:
-        for k in range(len(_fps_results) - 1, -1, -1):
-            rB, rS, rdev, rxyz, rcert = _fps_results[k]
-            if rB == B and rS == N and rdev == xyz.device:
-                cert_in, ref = rcert, rxyz
-                fps_prefix_stats["offered"] += 1
-                break
+        cert_in, ref = _fps_book.offer((B, N, mode), xyz.device)
         cert_out = torch.empty(B, dtype=torch.int32, device=xyz.device)
     check(lib().tgn_furthestsampling_dense_prefix(B, N, npoint, ptr(xyz), ptr(ws), nbytes, ptr(idx), ptr(new_xyz),
                                                   ptr(cert_in), ptr(ref), ptr(cert_out), flags, stream()),
           "tgn_furthestsampling_dense")
     if use_prefix:
-        # the stored coordinates must stay what the kernel wrote: a private copy if the caller gets the tensor too
-        _fps_results.append((B, npoint, xyz.device, new_xyz.clone() if want_coords else new_xyz, cert_out))
-        del _fps_results[:-_FPS_RESULTS_CAP]
+        _fps_book.record((B, npoint, mode), xyz.device, new_xyz, cert_out, shared=want_coords)
     return idx, (new_xyz if want_coords else None)
 
 
 def farthest_point_sample(xyz, npoint):
     """(B,N,3) -> (B,npoint) int64 indices local to each cloud; the first sample is point 0, as in the kernel the
-    reference calls (pointnet2_utils.py:87-98 / sampling_cuda_kernel.cu:39)."""
+    reference calls (pointnet2_utils.py:87-98 / sampling_cuda_kernel.cu:39).  Tie order / contraction follow
+    _lib.set_fps_mode() (TGN_FPS_TIES, TGN_FPS_FMA): 'first' = torch-CPU semantics (default), 'tree' = the
+    reference CUDA kernel's reduction order."""
     return _fps_dense(xyz, npoint)[0]
 
 
 def farthest_point_sample_np(xyz, npoint):
-    """numpy in / numpy out variant with a RANDOM first sample (pointnet2_utils.py:103-118).
+    """numpy in / numpy out variant with a RANDOM first sample (pointnet2_utils.py:103-118), indices bit-identical
+    to the reference's torch-CPU loop for the same torch RNG state -- ties included.
 
-    The random start is drawn with torch.randint like the reference; the cloud is then rotated so that
-    the start sits at index 0, sampled on the GPU, and the indices are mapped back."""
+    The start is drawn with the reference's own call, torch.randint(0, N, (B,), dtype=torch.long) (:109).  The GPU
+    kernel always starts at a cloud's first point, so each cloud is sampled as [p_start, p_0, ..., p_{N-1}]: the copy
+    in front makes p_start the first sample, every later arg-max sees the original points in their original order
+    (first-index ties as in torch.max, :117), and the copy itself sits at distance 0 like p_start.  Index 0 of the
+    padded cloud maps back to `start` for the first sample and to point 0 afterwards (an exhausted or all-NaN cloud,
+    where torch.max returns index 0)."""
     xyz_t = torch.from_numpy(np.ascontiguousarray(xyz, dtype=np.float32))
     B, N, _ = xyz_t.shape
     farthest = torch.randint(0, N, (B,), dtype=torch.long)
-    dev = torch.device("cuda")
-    ar = torch.arange(N).unsqueeze(0)
-    perm = (ar + farthest.unsqueeze(1)) % N  # perm[b, 0] = start
-    rolled = torch.gather(xyz_t, 1, perm.unsqueeze(-1).expand(B, N, 3)).to(dev)
-    idx = farthest_point_sample(rolled, npoint).cpu()
-    # NOTE: ties are broken by lowest ROTATED index; identical to the reference whenever distances are distinct.
-    return torch.gather(perm, 1, idx).numpy()
+    first = torch.gather(xyz_t, 1, farthest.view(B, 1, 1).expand(B, 1, 3))
+    padded = torch.cat([first, xyz_t], dim=1).to(torch.device("cuda"))
+    prev = _lib.get_fps_mode()
+    if prev != ("first", False):        # this function IS the torch-CPU semantics, whatever mode the kernels are in
+        _lib.set_fps_mode("first", False)
+    try:
+        idx = _fps_dense(padded, npoint)[0].cpu() - 1
+    finally:
+        if prev != ("first", False):
+            _lib.set_fps_mode(*prev)
+    if idx.shape[1] > 0:
+        idx[:, 0] = farthest
+    idx.clamp_(min=0)
+    return idx.numpy()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -255,6 +269,7 @@ class _GroupPoints(Function):
         check(lib().tgn_group_points(B, N, S, K, D, ptr(xyz), ptr(new_xyz), ptr(points), ptr(idx),
                                      int(idx.dtype == torch.int64), int(xyz_first), ptr(out), stream()),
               "group_points")
+        _lib.raise_on_index_error("group_points")
         ctx.dims = (B, N, S, K, D, bool(xyz_first))
         ctx.save_for_backward(idx)
         return out
@@ -283,8 +298,10 @@ class _GroupPoints(Function):
 
 
 def group_points(xyz, new_xyz, points, idx, xyz_first=True):
-    """Fused gather + centre + concat. Raises IndexError where the reference's indexing would
-    (an empty ball yields index N, pointnet2_utils.py:136-141)."""
+    """Fused gather + centre + concat: (B,S,K,3+D) = [xyz[idx]-new_xyz, points[idx]] (xyz_first, reference :162-169)
+    or [points[idx], xyz[idx]-new_xyz] (:281-285).  Raises IndexError where the reference's indexing would -- an
+    empty ball yields index N (pointnet2_utils.py:136-141) -- after one stream synchronisation per call;
+    TGN_INDEX_CHECK=off drops check and sync (rows with a bad index are then filled from point 0)."""
     require_cuda(xyz, new_xyz, idx)
     out = _GroupPoints.apply(_f32c(xyz), _f32c(new_xyz), None if points is None else _f32c(points),
                              idx.contiguous(), bool(xyz_first))
@@ -342,8 +359,8 @@ class _ThreeInterpolate(Function):
         N = dist.shape[1]
         out = torch.empty(B, N, C, dtype=torch.float32, device=points2.device)
         weight = torch.empty(B, N, 3, dtype=torch.float32, device=points2.device)
-        check(lib().tgn_three_interpolate(B, N, S, C, ptr(points2), ptr(dist), ptr(idx), 1, ptr(out), ptr(weight),
-                                          stream()), "three_interpolate")
+        check(lib().tgn_three_interpolate(B, N, S, C, ptr(points2), ptr(dist), ptr(idx), int(idx.dtype == torch.int64),
+                                          ptr(out), ptr(weight), stream()), "three_interpolate")
         ctx.dims = (B, N, S, C)
         ctx.save_for_backward(idx, weight)
         return out
@@ -365,7 +382,9 @@ class _ThreeInterpolate(Function):
 def three_interpolate(points2, dist, idx):
     """inverse-(squared)-distance weighted sum of the 3 neighbours (pointnet2_utils.py:337-340) -> (B,N,C)."""
     require_cuda(points2, dist, idx)
-    return _ThreeInterpolate.apply(_f32c(points2), dist.contiguous(), idx.contiguous())
+    if idx.dtype not in (torch.int64, torch.int32):
+        idx = idx.long()
+    return _ThreeInterpolate.apply(_f32c(points2), _f32c(dist), idx.contiguous())
 
 
 # ---------------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
+from ._fps_prefix import PrefixBook
 from ._lib import as_int, check, lib, ptr, require_cuda, stream
 
 _fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
@@ -50,13 +51,12 @@ def fps_workspace(b, n_max, n_total, device):
 
 
 FPS_PREFIX = os.environ.get("TGN_FPS_PREFIX", "1") != "0"
-_FPS_RESULTS_CAP = 8
-_fps_results = []     # (new_offset as a host list, device, new_xyz (m,3), certificate (b,) int32), most recent last
-fps_prefix_stats = {"offered": 0}
+_fps_book = PrefixBook()
+fps_prefix_stats = _fps_book.stats
 
 
 def fps_prefix_clear():
-    del _fps_results[:]
+    _fps_book.clear()
 
 
 def fps_with_coords(xyz, offset, new_offset, cuda_compat=False):
@@ -77,27 +77,21 @@ def fps_with_coords(xyz, offset, new_offset, cuda_compat=False):
     idx = torch.empty(m, dtype=torch.int32, device=xyz.device)
     new_xyz = torch.empty(m, 3, dtype=torch.float32, device=xyz.device)
     ws, nbytes = fps_workspace(b, n_max, xyz.shape[0], xyz.device)
-    flags = _lib.FPS_CUDA_COMPAT if cuda_compat else 0
+    flags = _lib.fps_flags(cuda_compat)
     # FPS of an FPS result is the identity (include/tgn_pointops.h).  The reference's transition-down chain gathers
     # n_p = p[idx] itself (blocks.py:70) and samples n_p at the next level, so provenance is established by CONTENT:
     # a previous result with the same segment layout is offered as prefix_ref and the kernel takes the shortcut for a
     # cloud only if its coordinates equal that result bit for bit.
-    use_prefix = FPS_PREFIX and not cuda_compat
+    use_prefix = FPS_PREFIX and not (flags & _lib.FPS_TREE_TIES)
     cert_in = ref = cert_out = None
     if use_prefix:
-        for k in range(len(_fps_results) - 1, -1, -1):
-            r_noff, r_dev, r_xyz, r_cert = _fps_results[k]
-            if r_noff == off_h and r_dev == xyz.device and r_xyz.shape[0] == xyz.shape[0]:
-                cert_in, ref = r_cert, r_xyz
-                fps_prefix_stats["offered"] += 1
-                break
+        cert_in, ref = _fps_book.offer((tuple(off_h), xyz.shape[0], flags), xyz.device)
         cert_out = torch.empty(b, dtype=torch.int32, device=xyz.device)
     check(lib().tgn_furthestsampling_prefix(b, n_max, ptr(xyz), ptr(offset), ptr(new_offset), ptr(ws), nbytes, ptr(idx),
                                             ptr(new_xyz), ptr(cert_in), ptr(ref), ptr(cert_out), flags, stream()),
           "tgn_furthestsampling")
     if use_prefix:
-        _fps_results.append((noff_h, xyz.device, new_xyz.clone(), cert_out))  # private copy: the caller may write to its own
-        del _fps_results[:-_FPS_RESULTS_CAP]
+        _fps_book.record((tuple(noff_h), m, flags), xyz.device, new_xyz, cert_out, shared=True)
     return idx, new_xyz
 
 
@@ -154,8 +148,11 @@ KNN_GRID_MIN_POINTS = int(os.environ.get("TGN_KNN_GRID_MIN", "3000"))   # averag
 
 # kNN memo.  The reference recomputes identical neighbour lists again and again: PointTransformerLayer calls
 # queryandgroup(idx=None) twice with the same arguments (blocks.py:34-35) and every block of a stage repeats it.
-# Results are keyed on the identity AND version counter of the argument tensors, which are kept alive by the
-# cache (so an address can not be recycled under a live key); an in-place write bumps the version and misses.
+# Results are keyed on the identity AND version counter of the argument tensors (kept alive by the cache, so an
+# address can not be recycled under a live key) and on the current stream (a result is only handed to launches that
+# are stream-ordered after the one that produced it); an in-place write bumps the version and misses.  Tensors
+# without a version counter (torch.inference_mode) bypass the memo.  Writes that torch cannot see -- through
+# `.data`, raw pointers, the pointops_cuda shim -- do not bump the version: call knn_cache_clear() after them.
 _KNN_CACHE = OrderedDict()
 _KNN_CACHE_SIZE = int(os.environ.get("TGN_KNN_CACHE", "16"))
 
@@ -164,7 +161,12 @@ def _knn_cached(nsample, xyz, new_xyz, offset, new_offset):
     if _KNN_CACHE_SIZE <= 0:
         return _knn_raw(nsample, xyz, new_xyz, offset, new_offset)
     tensors = (xyz, xyz if new_xyz is None else new_xyz, offset, new_offset)
-    key = (as_int(nsample),) + tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype) for t in tensors)
+    try:
+        # inference tensors (torch.inference_mode) carry no version counter: _version raises -> no memo for them
+        key = (as_int(nsample), torch.cuda.current_stream().cuda_stream) + tuple(
+            (t.data_ptr(), t._version, tuple(t.shape), t.dtype) for t in tensors)
+    except RuntimeError:
+        return _knn_raw(nsample, xyz, new_xyz, offset, new_offset)
     hit = _KNN_CACHE.get(key)
     if hit is not None:
         _KNN_CACHE.move_to_end(key)
@@ -298,10 +300,15 @@ def queryandgroup(nsample, xyz, new_xyz, feat, idx, offset, new_offset, use_xyz=
         new_xyz = xyz
     require_cuda(xyz, new_xyz, feat)
     assert xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()
-    if idx is None:
+    own_idx = idx is None
+    if own_idx:
         idx, _ = knnquery(nsample, xyz, new_xyz, offset, new_offset)  # (m, nsample)
     idx = _i32(idx).contiguous()
-    return _QueryGroup.apply(xyz, new_xyz, feat, idx, bool(use_xyz))
+    out = _QueryGroup.apply(xyz, new_xyz, feat, idx, bool(use_xyz))
+    if not own_idx and use_xyz:
+        # a caller's index tensor may hold anything; the reference's fancy indexing (pointops.py:89-95) raises
+        _lib.raise_on_index_error("queryandgroup")
+    return out
 
 
 class Subtraction(Function):
