@@ -88,6 +88,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
 }
+// The same for a base the caller KNOWS to be wave-uniform but hipcc may not (anything downstream of an integer
+// division): both halves go through v_readfirstlane, so the descriptor sits in SGPRs and the access is not wrapped in
+// a waterfall loop (cdna_hip_programming.md T20).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_uniform(const void *base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
 
 // POLICY = the cache-policy immediate of the output stores: bit 0 sc0, bit 1 nt, bit 4 sc1 (gfx940+).
 // WIDE = rows of at least 64 floats and K <= 64 (Shape-A levels 2 and 3): a 64-float sub-step then lies in one row or
@@ -136,10 +146,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(24))) void grou
             const unsigned ro = v * (unsigned)D;
             sfb[wv][k] = ro;
             r0 = ro;
-            const auto p = __builtin_amdgcn_raw_buffer_load_b96(rs_xyz, v * 12u, 0, 0);
-            srel[wv][k * 3 + 0] = __builtin_bit_cast(float, p[0]) - cq0;
-            srel[wv][k * 3 + 1] = __builtin_bit_cast(float, p[1]) - cq1;
-            srel[wv][k * 3 + 2] = __builtin_bit_cast(float, p[2]) - cq2;
+            // (three dword loads: hipcc 7.2 narrows a raw_buffer_load_b96 whose lanes are used separately to ONE dword)
+            const float px = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_xyz, v * 12u, 0, 0));
+            const float py = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_xyz, v * 12u + 4u, 0, 0));
+            const float pz = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_xyz, v * 12u + 8u, 0, 0));
+            srel[wv][k * 3 + 0] = px - cq0;
+            srel[wv][k * 3 + 1] = py - cq1;
+            srel[wv][k * 3 + 2] = pz - cq2;
         }
         if (err && __any(bad) && lane == 0) atomicOr(err, 1);
         // (the same wave wrote the tables: LDS operations of one wave complete in order, no barrier needed)
@@ -225,6 +238,354 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(24))) void grou
     }
 }
 
+// ---- v3 (wide rows): the same walk with the gathers landing DIRECTLY in LDS ----------------------------------
+// `buffer_load_dword ... lds` (LDS-DMA) writes lane l's dword to LDS[M0 + 4*l]: exactly the staging layout, so the
+// gathered data never occupies a VGPR and the number of gathers in flight is bounded by LDS, not by registers: a ring
+// of NBUF 1-KiB slots per wave keeps NBUF-1 steps (4 gathers each) in flight.  With that much in flight per wave a
+// handful of waves per CU saturates the store stream, which is what lets the launcher keep the number of queries an
+// XCD works on at a time -- and with it the set of feature rows that must stay in its L2 -- small.
+// hipcc does not order a ds_read behind a pending LDS-DMA (MI355X_MICROARCH.md): the waits are explicit.  On gfx9 the
+// vector-memory operations of a wave retire in issue order on ONE counter, loads and stores alike, so "step t has
+// landed" == "at most (operations issued after step t's gathers) outstanding" = 4 per later step in flight + 1 per
+// store issued since; EXACT = false leaves the stores out of the count (never less safe, waits for their
+// acknowledgements too).
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70);  // expcnt / lgkmcnt fields: no wait
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void wait_vmcnt_dyn(unsigned n) {  // wave-uniform n <= 15
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;
+        case 7: wait_vmcnt<7>(); break;
+        case 8: wait_vmcnt<8>(); break;
+        case 9: wait_vmcnt<9>(); break;
+        case 10: wait_vmcnt<10>(); break;
+        case 11: wait_vmcnt<11>(); break;
+        case 12: wait_vmcnt<12>(); break;
+        case 13: wait_vmcnt<13>(); break;
+        case 14: wait_vmcnt<14>(); break;
+        default: wait_vmcnt<15>(); break;
+    }
+}
+
+#define TGN_WAIT16(NAME, BASE)                                                                                     \
+    __device__ __forceinline__ void NAME(unsigned n) {                                                             \
+        switch (n - BASE) {                                                                                        \
+            case 0: wait_vmcnt<BASE + 0>(); break;   case 1: wait_vmcnt<BASE + 1>(); break;                        \
+            case 2: wait_vmcnt<BASE + 2>(); break;   case 3: wait_vmcnt<BASE + 3>(); break;                        \
+            case 4: wait_vmcnt<BASE + 4>(); break;   case 5: wait_vmcnt<BASE + 5>(); break;                        \
+            case 6: wait_vmcnt<BASE + 6>(); break;   case 7: wait_vmcnt<BASE + 7>(); break;                        \
+            case 8: wait_vmcnt<BASE + 8>(); break;   case 9: wait_vmcnt<BASE + 9>(); break;                        \
+            case 10: wait_vmcnt<BASE + 10>(); break; case 11: wait_vmcnt<BASE + 11>(); break;                      \
+            case 12: wait_vmcnt<BASE + 12>(); break; case 13: wait_vmcnt<BASE + 13>(); break;                      \
+            case 14: wait_vmcnt<BASE + 14>(); break; default: wait_vmcnt<BASE + 15>(); break;                      \
+        }                                                                                                          \
+    }
+TGN_WAIT16(wait_vmcnt_dyn2, 16)
+TGN_WAIT16(wait_vmcnt_dyn3, 32)
+TGN_WAIT16(wait_vmcnt_dyn4, 48)
+#undef TGN_WAIT16
+__device__ __forceinline__ void wait_vmcnt_any(unsigned n) {   // wave-uniform n; n > 63 cannot be outstanding
+    if (n >= 63u) return;
+    if (n >= 48u) wait_vmcnt_dyn4(n);
+    else if (n >= 32u) wait_vmcnt_dyn3(n);
+    else if (n >= 16u) wait_vmcnt_dyn2(n);
+    else wait_vmcnt_dyn(n);
+}
+
+// DBG (tools/group_bench.py only): 1 = no gathers, 2 = no stores -- which side bounds a wave?
+template <typename IdxT, int POLICY, int NBUF, bool EXACT, int DBG = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(24))) void group_points_ring_kernel(
+    long long queries, long long q_per_xcd, int N, int S, int K, int D, unsigned magicC,
+    const float *__restrict__ xyz, const float *__restrict__ new_xyz, const float *__restrict__ points,
+    const IdxT *__restrict__ idx, int xyz_first, float *__restrict__ out, int *__restrict__ err) {
+    static_assert(NBUF >= 2 && NBUF <= 4, "ring depth");
+    __shared__ float srel[4][64 * 3];                                        // per neighbour: centred coordinates
+    __shared__ __attribute__((aligned(16))) float ring[4][NBUF][256];        // NBUF 1-KiB steps of the output, per wave
+    const unsigned lane = threadIdx.x & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const unsigned C = 3u + (unsigned)D;
+    const unsigned xo = xyz_first ? 0u : (unsigned)D;
+    const unsigned fo = xyz_first ? 3u : 0u;
+    const unsigned total = (unsigned)K * C;
+    const unsigned units = total >> 2;
+    const unsigned nsteps = (units + 63u) >> 6;
+    const unsigned lane4 = lane * 4u;
+    const unsigned x = blockIdx.x & 7u, j = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+    long long q1 = (long long)(x + 1) * q_per_xcd;
+    if (q1 > queries) q1 = queries;
+    for (long long q = (long long)x * q_per_xcd + (long long)j * 4 + wv; q < q1; q += (long long)nbx * 4) {
+        const int b = (int)(q / S);
+        const float cq0 = new_xyz[q * 3 + 0], cq1 = new_xyz[q * 3 + 1], cq2 = new_xyz[q * 3 + 2];
+        const __amdgpu_buffer_rsrc_t rs_xyz = make_rsrc(xyz + (size_t)b * N * 3, (unsigned)N * 12u);
+        const __amdgpu_buffer_rsrc_t rs_idx = make_rsrc(idx + q * K, (unsigned)K * (unsigned)sizeof(IdxT));
+        bool bad = false;
+        unsigned r0 = 0;  // lane k: feature-row offset of neighbour k
+        if (lane < (unsigned)K) {
+            IdxT raw;
+            if constexpr (sizeof(IdxT) == 8) {
+                const auto t = __builtin_amdgcn_raw_buffer_load_b64(rs_idx, lane * 8u, 0, 0);
+                raw = (IdxT)(((unsigned long long)t[1] << 32) | t[0]);
+            } else {
+                raw = (IdxT)__builtin_amdgcn_raw_buffer_load_b32(rs_idx, lane * 4u, 0, 0);
+            }
+            const unsigned v = checked_index(raw, N, bad);
+            r0 = v * (unsigned)D;
+            const float px = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_xyz, v * 12u, 0, 0));
+            const float py = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_xyz, v * 12u + 4u, 0, 0));
+            const float pz = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_xyz, v * 12u + 8u, 0, 0));
+            srel[wv][lane * 3 + 0] = px - cq0;
+            srel[wv][lane * 3 + 1] = py - cq1;
+            srel[wv][lane * 3 + 2] = pz - cq2;
+        }
+        if (err && __any(bad) && lane == 0) atomicOr(err, 1);
+        const __amdgpu_buffer_rsrc_t rs_pts = make_rsrc(points + (size_t)b * N * D, (unsigned)N * (unsigned)D * 4u);
+        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(out + (size_t)q * total, total * 4u);
+        // everything above has been consumed (r0 and the tables depend on it): the counter is at zero from here on
+        unsigned ki = 0, ci = 0;  // SGPRs: row / first channel of the next sub-step to ISSUE
+        unsigned kc = 0, cc = 0;  // ... and of the next sub-step to CONSUME
+        auto issue = [&](unsigned step) {
+            float *slot = ring[wv][step % NBUF];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                // 64 consecutive output floats, first one in row ki at channel ci.  Past the end of the query the
+                // cursor runs on (garbage rows, still inside the scan's feature block; those lanes are never stored).
+                const unsigned rowA = (unsigned)__builtin_amdgcn_readlane((int)r0, (int)(ki & 63u));
+                const unsigned sA = (rowA + ci - fo) * 4u;
+                unsigned voff = lane4, soff = sA;
+                if (!(ci >= fo && ci + 64u <= fo + (unsigned)D)) {
+                    // lanes >= C - ci belong to row ki + 1, channel ci + lane - C.  The hardware range-checks voff
+                    // only; a coordinate lane's offset may come out "negative": it reads 0 and is patched on arrival.
+                    const unsigned rowB = (unsigned)__builtin_amdgcn_readlane((int)r0, (int)((ki + 1u) & 63u));
+                    const unsigned sB = (rowB + ci - C - fo) * 4u;
+                    voff = lane4 + (lane >= C - ci ? sB : sA);
+                    soff = 0;
+                }
+                if (!(DBG & 1))
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pts, (__attribute__((address_space(3))) void *)(slot + s * 64),
+                                                             4, voff, soff, 0, 0);
+                ci += 64u;
+                if (ci >= C) {
+                    ci -= C;
+                    ++ki;
+                }
+            }
+        };
+        const unsigned pre = nsteps < (unsigned)(NBUF - 1) ? nsteps : (unsigned)(NBUF - 1);
+        for (unsigned t = 0; t < pre; ++t) issue(t);
+#pragma unroll 1
+        for (unsigned t = 0; t < nsteps; ++t) {
+            if (t + (unsigned)(NBUF - 1) < nsteps) issue(t + (unsigned)(NBUF - 1));
+            // gathers of step t have landed <=> no more than (ops issued after them) are outstanding
+            const unsigned ahead = nsteps - 1u - t < (unsigned)(NBUF - 1) ? nsteps - 1u - t : (unsigned)(NBUF - 1);
+            const unsigned stores_since = t < (unsigned)(NBUF - 1) ? t : (unsigned)(NBUF - 1);
+            if (!DBG) wait_vmcnt_dyn(4u * ahead + (EXACT ? stores_since : 0u));
+            if (DBG == 2) wait_vmcnt_dyn(4u * ahead);
+            float *slot = ring[wv][t % NBUF];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (!(cc >= fo && cc + 64u <= fo + (unsigned)D)) {  // wave-uniform: the sub-step holds a coordinate triple
+                    const bool wrap = lane >= C - cc;
+                    const unsigned cx = cc + lane - (wrap ? C : 0u) - xo;
+                    const unsigned k = kc + (wrap ? 1u : 0u);
+                    if (cx < 3u && k < (unsigned)K) slot[s * 64 + lane] = srel[wv][k * 3u + cx];
+                }
+                cc += 64u;
+                if (cc >= C) {
+                    cc -= C;
+                    ++kc;
+                }
+            }
+            const f32x4 w = *(const f32x4 *)&slot[lane * 4];
+            const unsigned u = t * 64u + lane;
+            if (u < units && (!(DBG & 2) || w[0] == 123.456f))
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, w),
+                                                       rs_out, u * 16u, 0, POLICY);
+        }
+        // the next query's set-up loads are waited for by the compiler (vmcnt(0)): the ring is drained by then
+    }
+}
+
+// ---- v5 (wide rows): row pieces straight into an LDS image of the output, ONE wave per workgroup --------------------
+// Measured in round 2 (profiles/r02_group_*.txt, r02_gather_bench.txt): with its stores removed the ring kernel above
+// still needs 1.3-1.9 ms for 4.3 GB, while a bare LDS-DMA gather loop reaches 6-7 TB/s from HBM with only 4-8 waves
+// per CU -- the grouping kernels were bound by their own instruction streams (~170 mostly scalar, mostly dependent
+// instructions per KiB: the scalar unit of a CU saturates at full occupancy, a lone wave crawls at low occupancy), not
+// by memory.  This version spends ~35 instructions per KiB:
+//   * the output of R consecutive neighbours (R*C floats, R a multiple of 4) is assembled in LDS exactly as it will
+//     lie in memory;
+//   * a neighbour's feature row arrives as ceil(D/64) LDS-DMA pieces of 64 floats, each ONE instruction whose operands
+//     are an SGPR offset and M0 bumped by 256 B -- no per-lane address arithmetic, no row-boundary cases;
+//   * the 3 centred coordinates of each of the R rows are dropped in by one masked ds_write;
+//   * an image leaves as 16 B per lane and in WHOLE 128-B LINES: it is streamed from the line boundary at or before
+//     its first float to the last line boundary inside it, and the <= 31 floats beyond are carried over into the head
+//     of the next image (write-through stores of partial lines cost a fabric write each: the level-3 images start
+//     48 B into a line);
+//   * two images per wave, the next one loading while this one is stored; the next QUERY's index row and coordinates
+//     are fetched underneath the current query, so a wave never sits through their two dependent round trips.
+// The vector-memory operations of a wave retire in issue order on one counter (gfx9), loads and stores alike, so
+// "X has landed" is "at most (operations issued after X) outstanding" -- acknowledgements of stores are never waited
+// for.  DBG (tools/group_bench.py only): 1 = no gathers, 2 = no stores.
+template <typename IdxT, int POLICY, int DBG = 0>
+__global__ __launch_bounds__(64) void group_points_rows_kernel(
+    long long queries, long long q_per_xcd, int N, int S, int K, int D, int R, const float *__restrict__ xyz,
+    const float *__restrict__ new_xyz, const float *__restrict__ points, const IdxT *__restrict__ idx, int xyz_first,
+    float *__restrict__ out, int *__restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) float lds_img[];   // [2][32 + R*C] images, [64*3] centred coordinates, [5][64] set-up planes
+    const unsigned lane = threadIdx.x;
+    const unsigned C = 3u + (unsigned)D;
+    const unsigned xo = xyz_first ? 0u : (unsigned)D;
+    const unsigned fo = xyz_first ? 3u : 0u;
+    const unsigned IMG = 32u + (unsigned)R * C;          // floats per image buffer (multiple of 4)
+    float *const srel = lds_img + 2u * IMG;
+    const unsigned pieces = ((unsigned)D + 63u) >> 6;    // 64-float pieces per feature row
+    const unsigned last_len = (unsigned)D - 64u * (pieces - 1u);
+    const unsigned nb = ((unsigned)K + (unsigned)R - 1u) / (unsigned)R;
+    const unsigned total = (unsigned)K * C;
+    const unsigned max_stores = (IMG + 255u) / 256u;     // 1-KiB store instructions per image, at most
+    const bool overlap = (unsigned)R * pieces + max_stores + 4u <= 62u;   // everything in flight fits the 6-bit counter
+    const unsigned lane4 = lane * 4u;
+    const unsigned pr = lane / 3u, pi = lane - pr * 3u;  // coordinate patch: lane -> (row of the image, axis)
+    const unsigned x = blockIdx.x & 7u, j = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+    long long q1 = (long long)(x + 1) * q_per_xcd;
+    if (q1 > queries) q1 = queries;
+    long long q = (long long)x * q_per_xcd + j;
+    if (q >= q1) return;
+
+    // the scan a query belongs to, as an SGPR (a 64-bit division comes out of the vector ALU: hipcc would wrap every
+    // buffer access that depends on it in a waterfall loop)
+    auto scan_of = [&](long long qq) { return __builtin_amdgcn_readfirstlane((int)((unsigned)qq / (unsigned)S)); };
+    // Set-up data of a query -- its index row, then the coordinates of the K neighbours -- is fetched by LDS-DMA as
+    // well (planes of 64 dwords): nothing arrives in a VGPR, so hipcc has no reason to drain the counter (it answers a
+    // pending VGPR load with vmcnt(0), which would also wait for every store acknowledgement), and the two dependent
+    // round trips run underneath the previous query: the index row next to its first image, the coordinates next to
+    // the stores of its last one.
+    constexpr unsigned NIDX = sizeof(IdxT) / 4;              // dwords per index
+    float *const plane = srel + 64 * 3;                      // [NIDX] index planes, then x, y, z planes, 64 dwords each
+    float *const plane_xyz = plane + 64 * NIDX;
+    auto fetch_index = [&](long long qq) {
+        const __amdgpu_buffer_rsrc_t rs_idx = make_rsrc_uniform(idx + qq * K, (unsigned)K * (unsigned)sizeof(IdxT));
+#pragma unroll
+        for (unsigned w = 0; w < NIDX; ++w)   // lanes >= K: out of range, LDS gets 0
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_idx, (__attribute__((address_space(3))) void *)(plane + 64 * w), 4,
+                                                     lane * (unsigned)sizeof(IdxT) + 4u * w, 0, 0, 0);
+    };
+    auto read_index = [&](bool &bad_) -> unsigned {          // after the planes have landed
+        long long raw;
+        if constexpr (NIDX == 2)
+            raw = (long long)(((unsigned long long)__float_as_uint(plane[64 + lane]) << 32) | __float_as_uint(plane[lane]));
+        else
+            raw = (long long)(int)__float_as_uint(plane[lane]);
+        return lane < (unsigned)K ? checked_index(raw, N, bad_) : 0u;
+    };
+    auto fetch_xyz = [&](long long qq, unsigned vv) {
+        const __amdgpu_buffer_rsrc_t rs_xyz = make_rsrc_uniform(xyz + (size_t)scan_of(qq) * N * 3, (unsigned)N * 12u);
+#pragma unroll
+        for (unsigned a_ = 0; a_ < 3; ++a_)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xyz, (__attribute__((address_space(3))) void *)(plane_xyz + 64 * a_), 4,
+                                                     vv * 12u + 4u * a_, 0, 0, 0);
+    };
+    bool bad = false;
+    fetch_index(q);
+    wait_vmcnt<0>();
+    unsigned v = read_index(bad);
+    fetch_xyz(q, v);
+    unsigned tail_stores = 0;   // stores issued after a query's coordinate fetch: what may still be outstanding when it is needed
+    for (;;) {
+        const int b = scan_of(q);
+        const float cq0 = new_xyz[q * 3 + 0], cq1 = new_xyz[q * 3 + 1], cq2 = new_xyz[q * 3 + 2];
+        // the coordinates of THIS query have landed once at most the stores issued after their fetch are outstanding
+        wait_vmcnt_dyn(tail_stores);
+        const unsigned r0 = v * (unsigned)D * 4u;   // lane k: byte offset of neighbour k's feature row in the scan's block
+        if (lane < (unsigned)K) {
+            srel[lane * 3 + 0] = plane_xyz[lane] - cq0;
+            srel[lane * 3 + 1] = plane_xyz[64 + lane] - cq1;
+            srel[lane * 3 + 2] = plane_xyz[128 + lane] - cq2;
+        }
+        if (err && __any(bad) && lane == 0) atomicOr(err, 1);
+        bad = false;
+        const __amdgpu_buffer_rsrc_t rs_pts = make_rsrc_uniform(points + (size_t)b * N * D, (unsigned)N * (unsigned)D * 4u);
+        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc_uniform(out + (size_t)q * total, total * 4u);
+        const long long qn = q + nbx;
+        const bool has_next = qn < q1;
+        auto issue = [&](unsigned ib) {   // image ib: neighbours ib*R .. ib*R + rows - 1, at float offset (ib*R*C) % 32 of its buffer
+            const unsigned k0 = ib * (unsigned)R;
+            float *img = lds_img + (ib & 1u) * IMG + (k0 * C & 31u);
+            const unsigned rows = (unsigned)K - k0 < (unsigned)R ? (unsigned)K - k0 : (unsigned)R;
+            if (DBG & 1) return rows;
+            for (unsigned r = 0; r < rows; ++r) {
+                const unsigned soff = (unsigned)__builtin_amdgcn_readlane((int)r0, (int)(k0 + r));
+                float *dst = img + r * C + fo;
+                for (unsigned p = 0; p + 1u < pieces; ++p)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pts, (__attribute__((address_space(3))) void *)(dst + p * 64u), 4,
+                                                             lane4, soff + p * 256u, 0, 0);
+                if (lane < last_len)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pts, (__attribute__((address_space(3))) void *)(dst + (pieces - 1u) * 64u),
+                                                             4, lane4, soff + (pieces - 1u) * 256u, 0, 0);
+            }
+            return rows;
+        };
+        unsigned rows_next = issue(0);
+        if (has_next) fetch_index(qn);     // behind image 0, in front of image 1: lands underneath this query
+        unsigned prev_stores = 0;          // store instructions of the previous image of this query
+        for (unsigned ib = 0; ib < nb; ++ib) {
+            const unsigned rows = rows_next;
+            const bool last = ib + 1u == nb;
+            const unsigned idx_ops = (ib == 0 && has_next) ? NIDX : 0u;   // issued after image 0's pieces
+            if (DBG & 1) {
+                if (!last) rows_next = issue(ib + 1u);
+            } else if (overlap && !last) {
+                rows_next = issue(ib + 1u);
+                // image ib has landed <=> at most [what was issued after its pieces] is outstanding
+                wait_vmcnt_any(rows_next * pieces + idx_ops + ((DBG & 2) ? 0u : prev_stores));
+            } else if (last && has_next && ib == 0) {
+                wait_vmcnt<0>();           // single-image queries: the index row of the next query must be in as well
+            } else {
+                wait_vmcnt_any(overlap && !(DBG & 2) ? prev_stores : 0u);   // nothing was issued after image ib but those stores
+            }
+            if (last && has_next) {
+                // everything issued before this query's last image has landed, the next query's index row included:
+                // fetch its coordinates underneath the last image's stores
+                v = read_index(bad);
+                fetch_xyz(qn, v);
+            }
+            const unsigned k0 = ib * (unsigned)R;
+            const unsigned e0 = k0 * C;                       // first float of the image in the query's region
+            const unsigned a0 = e0 & ~31u;                    // ... rounded down to its 128-B line: the buffer's float 0
+            float *buf = lds_img + (ib & 1u) * IMG;
+            float *img = buf + (e0 - a0);
+            if (pr < rows) img[pr * C + xo + pi] = srel[(k0 + pr) * 3u + pi];
+            const unsigned e1 = e0 + rows * C;                // one past the image's last float
+            const unsigned f1 = last ? e1 : (e1 & ~31u);      // stream whole lines; the rest rides with the next image
+            if (!last && lane < e1 - f1)                      // carry: the floats beyond the last whole line -> head of the other buffer
+                lds_img[((ib + 1u) & 1u) * IMG + lane] = buf[(f1 - a0) + lane];
+            const unsigned units = (f1 - a0) >> 2;
+            unsigned nst = 0;
+            for (unsigned u = lane, u0 = 0; u0 < units; u += 64u, u0 += 64u, ++nst) {
+                if (u < units) {
+                    const f32x4 w = *(const f32x4 *)&buf[u * 4u];
+                    if (!(DBG & 2) || w[0] == 123.456f)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, w),
+                                                               rs_out, ((a0 >> 2) + u) * 16u, 0, POLICY);
+                }
+            }
+            prev_stores = (DBG & 2) ? 0u : nst;
+            if (!(DBG & 1) && !overlap && !last) rows_next = issue(ib + 1u);
+        }
+        if (!has_next) break;
+        tail_stores = prev_stores;
+        q = qn;
+    }
+}
+
 static int env_int(const char *name, int dflt) {
     const char *s = getenv(name);
     return (s && *s) ? atoi(s) : dflt;
@@ -234,7 +595,9 @@ static int env_int(const char *name, int dflt) {
 
 using namespace tgn;
 
-// impl: 0 = choose, 1 = v1 (4-B stores), 2 = v2 (16-B stores).  store_policy: cache-policy bits of the v2 output
+// impl: 0 = choose, 1 = v1 (4-B stores), 2 = v2 (16-B stores), 3 = v3 (16-B stores, gathers straight into an LDS ring),
+// 4 = v3 with conservative wait counts, 5/6 = v3 debug variants (no gathers / no stores: timing only),
+// 7 = v5 (row pieces into an LDS image, one wave per workgroup; max_blocks counts 4 waves as one block).  store_policy: cache-policy bits of the v2 output
 // stores (0 plain, 2 nt, 16 sc1, 17 sc0|sc1, 18 sc1|nt), -1 = default.  max_blocks: upper bound on the v2 grid
 // (0 = no bound): a caller that overlaps the grouping with a register-hungry kernel keeps CUs free this way.
 TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *xyz, const float *new_xyz,
@@ -255,6 +618,8 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
     static const int env_impl = env_int("TGN_GROUP_IMPL", 0);
     static const int env_policy = env_int("TGN_GROUP_POLICY", 16);
     static const int env_blocks = env_int("TGN_GROUP_MAX_BLOCKS", 0);
+    const bool exact = impl != 4;   // impl 4: the ring kernel with the conservative wait counts (stores not counted)
+    if (impl == 4) impl = 3;
     if (impl <= 0) impl = env_impl;
     if (store_policy < 0) store_policy = env_policy;
     if (max_blocks <= 0) max_blocks = env_blocks;
@@ -264,8 +629,13 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
     const float *pts = points ? points : xyz;
     hipStream_t st = (hipStream_t)stream;
     const bool v2_ok = ((long long)K * C) % 4 == 0 && ((uintptr_t)out & 15) == 0 && (long long)N * (D > 0 ? D : 1) < (1LL << 30);
+    const bool ring_ok = v2_ok && C >= 64 && K <= 64 && (long long)N * D * 4 >= 256;
+    if ((impl == 5 || impl == 6 || impl >= 8) && !(ring_ok && store_policy == 16)) impl = 3;   // debug variants: default policy only
+    if (impl >= 3 && !ring_ok) impl = 2;
     if (impl == 2 && !v2_ok) impl = 1;
-    if (impl == 0) impl = v2_ok ? 2 : 1;
+    // default: the row-piece kernel when the caller leaves the grid alone; a bounded grid means "runs beside something
+    // that owns most of every CU" (the FPS level-1 workgroups): there the LDS-light v2 kernel is the one that fits
+    if (impl == 0) impl = (ring_ok && K % 4 == 0 && queries < (1LL << 31) && max_blocks <= 0) ? 7 : v2_ok ? 2 : 1;
     if (impl == 1) {
         long long blocks = ((queries + 3) / 4 + 7) / 8 * 8;  // one query per wave, grid a multiple of the 8 XCDs
         if (blocks > (1LL << 30)) blocks = 1LL << 30;
@@ -277,6 +647,38 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
                                magicC, xyz, new_xyz, pts, (const int *)idx, xyz_first, out, err);
         return check_launch("group_points_kernel");
     }
+    if (impl >= 7 && !(ring_ok && K % 4 == 0 && queries < (1LL << 31))) impl = 3;
+    if (impl >= 7) {
+        // v5: one wave per workgroup; R rows per LDS image (multiple of 4, about 8 KiB, at most 20 rows)
+        int R = (int)(2176 / C) / 4 * 4;
+        if (R < 4) R = 4;
+        if (R > 20) R = 20;
+        if (R > K) R = K;
+        const size_t lds = (size_t)(2 * (32 + R * C) + 64 * 3 + 64 * 5) * sizeof(float);
+        long long qx = B >= 8 ? (long long)((B + 7) / 8) * S : (queries + 7) / 8;
+        long long nb = qx;                       // workgroups (= waves) per XCD
+        long long per_cu = (long long)(160 * 1024) / (long long)lds;   // resident workgroups per CU (LDS-bound)
+        if (per_cu > 16) per_cu = 16;
+        if (per_cu < 1) per_cu = 1;
+        long long capw = 32 * per_cu;            // ... per XCD: the grid is exactly what is resident
+        if (max_blocks > 0 && (long long)max_blocks * 4 / 8 < capw) capw = (long long)max_blocks * 4 / 8 > 0 ? (long long)max_blocks * 4 / 8 : 1;
+        if (nb > capw) nb = capw;
+#define TGN_GROUP_ROWS(IT, POL)                                                                                       \
+    do {                                                                                                              \
+        auto kfn = impl == 8 ? group_points_rows_kernel<IT, POL, 1> : impl == 9 ? group_points_rows_kernel<IT, POL, 2> \
+                                                                                 : group_points_rows_kernel<IT, POL, 0>; \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(nb * 8)), dim3(64), lds, st, queries, qx, N, S, K, D, R, xyz, new_xyz, pts, \
+                           (const IT *)idx, xyz_first, out, err);                                                     \
+    } while (0)
+        if (idx_is_int64) {
+            if (store_policy == 0) TGN_GROUP_ROWS(long long, 0); else if (store_policy == 2) TGN_GROUP_ROWS(long long, 2); else TGN_GROUP_ROWS(long long, 16);
+        } else {
+            if (store_policy == 0) TGN_GROUP_ROWS(int, 0); else if (store_policy == 2) TGN_GROUP_ROWS(int, 2); else TGN_GROUP_ROWS(int, 16);
+        }
+#undef TGN_GROUP_ROWS
+        return check_launch("group_points_rows_kernel");
+    }
     // v2: per-XCD query ranges (whole scans when B >= 8), at most 8 blocks per CU resident
     long long q_per_xcd = B >= 8 ? (long long)((B + 7) / 8) * S : ((queries + 7) / 8 + 3) / 4 * 4;
     long long nbx = (q_per_xcd + 3) / 4;
@@ -286,7 +688,19 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
     const dim3 grid((unsigned)(nbx * 8));
 #define TGN_GROUP_V2(IT, POL)                                                                                            \
     do {                                                                                                                 \
-        if (C >= 64 && K <= 64)                                                                                          \
+        if (impl == 5)                                                                                                   \
+            hipLaunchKernelGGL((group_points_ring_kernel<IT, POL, 4, true, 1>), grid, dim3(256), 0, st, queries,         \
+                               q_per_xcd, N, S, K, D, magicC, xyz, new_xyz, pts, (const IT *)idx, xyz_first, out, err);  \
+        else if (impl == 6)                                                                                              \
+            hipLaunchKernelGGL((group_points_ring_kernel<IT, POL, 4, true, 2>), grid, dim3(256), 0, st, queries,         \
+                               q_per_xcd, N, S, K, D, magicC, xyz, new_xyz, pts, (const IT *)idx, xyz_first, out, err);  \
+        else if (impl == 3 && exact)                                                                                     \
+            hipLaunchKernelGGL((group_points_ring_kernel<IT, POL, 4, true>), grid, dim3(256), 0, st, queries, q_per_xcd, \
+                               N, S, K, D, magicC, xyz, new_xyz, pts, (const IT *)idx, xyz_first, out, err);             \
+        else if (impl == 3)                                                                                              \
+            hipLaunchKernelGGL((group_points_ring_kernel<IT, POL, 4, false>), grid, dim3(256), 0, st, queries,           \
+                               q_per_xcd, N, S, K, D, magicC, xyz, new_xyz, pts, (const IT *)idx, xyz_first, out, err);  \
+        else if (C >= 64 && K <= 64)                                                                                     \
             hipLaunchKernelGGL((group_points_v2_kernel<IT, POL, true>), grid, dim3(256), 0, st, queries, q_per_xcd, N,   \
                                S, K, D, magicC, xyz, new_xyz, pts, (const IT *)idx, xyz_first, out, err);                \
         else                                                                                                             \
