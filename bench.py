@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--group-impl", type=int, default=0, help="grouping kernel: 0 choose, 1 = 4-B stores, 2 = 16-B stores through LDS")
     ap.add_argument("--group-policy", type=int, default=-1, help="cache policy of the 16-B grouping stores (0 plain, 2 nt, 16 sc1; -1 default)")
     ap.add_argument("--group-max-blocks", type=int, default=-1, help="grid bound of the grouping kernel (-1: 512 when pipelined, else none)")
+    ap.add_argument("--fused", type=int, default=0, help="1: every level is a fused set-abstraction level (single-layer shared MLP "
+                    "[128,512,1024], eval-mode BatchNorm folded): the grouped tensor is never written -- a second, non-headline line")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra with_fps_prefix_identity measurement (profiling runs)")
     args = ap.parse_args()
 
@@ -105,7 +107,9 @@ def main():
     shape = hotpath.SHAPE_A if args.shape == "A" else hotpath.SHAPE_B
     xyz, feats, scans = make_inputs(B, device, seed=100 + rank, shape=shape)
     gopts = dict(group_impl=args.group_impl, group_policy=args.group_policy,
-                 group_max_blocks=None if args.group_max_blocks < 0 else args.group_max_blocks)
+                 group_max_blocks=None if args.group_max_blocks < 0 else args.group_max_blocks, fused=bool(args.fused))
+    if args.fused and args.shape != "A":
+        raise SystemExit("--fused is defined for shape A (single-scale levels)")
     hp = hotpath.HotPath(B, device, shape=shape, pipeline=bool(args.pipeline), fps_prefix=bool(args.fps_prefix), **gopts)
     for _ in range(max(args.warmup, 0)):
         hp.run(xyz, feats, inputs_on_current_stream=False)   # the synthetic scans are resident before any step
@@ -125,7 +129,7 @@ def main():
 
     total_meshes = B * args.steps * world
     value = total_meshes / elapsed
-    bytes_per_mesh, per_level = hotpath.algorithmic_bytes(**shape)
+    bytes_per_mesh, per_level = hotpath.algorithmic_bytes(fused=bool(args.fused), **shape)
 
     out = {
         "metric": "meshes/sec (24k-pt FPS+ball_query+group fwd)",
@@ -140,7 +144,11 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": ("shape_A: 24000-pt scans, npoint=[4096,1024,256], nsample=32, radii=[0.05,0.1,0.2], "
+        "config": {"workload": ("shape_A FUSED (NOT the headline configuration): 24000-pt scans, npoint=[4096,1024,256], nsample=32, "
+                                "radii=[0.05,0.1,0.2]; FPS + ball query + fused set-abstraction level (gather, centre, 1x1 conv "
+                                "[9->128, 131->512, 515->1024] on the fp32 matrix cores, folded BatchNorm, ReLU, max over K); "
+                                "the grouped tensor is never written, level l feeds level l+1") if args.fused else
+                               ("shape_A: 24000-pt scans, npoint=[4096,1024,256], nsample=32, radii=[0.05,0.1,0.2], "
                                 "D=[6,128,512]; FPS+ball_query+group forward, grouped tensors materialised") if args.shape == "A" else
                                ("shape_B (NOT the headline configuration): 24000-pt scans, npoint=[1024,512,256], multi-scale "
                                 "radii [[.025,.05],[.05,.1],[.1,.2]], nsample [32,64], D=[6,256,1024]; FPS+ball_query+group forward"),
@@ -187,7 +195,20 @@ def main():
                                  "unit": "GB/s", "frac": galgo / (avg[gk] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "traffic": (pmc[gk]["fetch"] + pmc[gk]["write"]) if gk in pmc and B == 256 and args.shape == "A" else None,
                                  "algorithmic_bytes_per_launch": galgo, "avg_launch_ms": avg[gk]}
-    if world == 1 and not args.fps_prefix and not args.no_alt:
+    if args.fused and rank == 0 and not args.no_kernel_timing:
+        # matrix-core side of the fused levels: flops of the per-point transforms / direct contractions per step
+        fl = 0
+        Nl = shape["n"]
+        for S, K, D, C1 in zip(shape["npoint"], shape["nsample"], shape["d"], shape["c_out"]):
+            direct = (3 + D) <= 16
+            fl += 2 * (S * K if direct else Nl) * (3 + D) * C1
+            Nl = S
+        sa_ms = sum(v for k, v in avg.items() if k.startswith("group"))
+        out["fused_levels"] = {"flops_per_mesh": fl, "sa_kernels_ms_per_step": sa_ms,
+                               "achieved_TFLOPs_fp32": fl * B / (sa_ms * 1e-3) / 1e12, "peak_TFLOPs_fp32_mfma": 157.3,
+                               "note": "set-abstraction kernels (per-point transform + gather-max, or the direct kernel) are timed under the "
+                                       "group_l* keys; fp32 MFMA = exact fp32, 1/16 of the bf16 rate"}
+    if world == 1 and not args.fps_prefix and not args.no_alt and not args.fused:
         # the same steps with levels 2 and 3 answered by the FPS-of-an-FPS-result identity (exact):
         # reported next to the headline, never as the headline
         del hp

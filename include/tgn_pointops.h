@@ -221,6 +221,32 @@ int tgn_sa_first_layer(int B, int N, int S, int K, int C, const float *A, const 
                        int idx_is_int64, int relu, float *out, tgn_stream_t stream);
 int tgn_sa_first_layer_max(int B, int N, int S, int K, int C, const float *A, const float *Cst, const void *idx,
                            int idx_is_int64, int relu, float *out, tgn_stream_t stream);
+/*
+ * The three kernels of the fused set-abstraction level (eval mode, BatchNorm folded; pointnet2_utils.py:229-236,
+ * 281-294).  With scale = gamma/sqrt(var+eps), shift = beta - mean*scale and W = the first 1x1 convolution:
+ *
+ * tgn_sa_point_transform: A[m,:] = [points[m,:], xyz[m,:]] * Wt for the M = B*N points of a batch -- the per-POINT half
+ *   of the layer (the convolution commutes with the gather).  Wt: (D+3, C1) row-major, rows ordered
+ *   [feature channels..., x, y, z], columns already multiplied by scale.  Hand-written fp32-MFMA GEMM
+ *   (v_mfma_f32_32x32x2_f32: exact fp32 fma chain).
+ * tgn_sa_gather_max: out[b,s,c] = act( max_k A[b, idx[b,s,k], c] - (Wxs[0,c]*cx + Wxs[1,c]*cy + Wxs[2,c]*cz) + b2[c] )
+ *   with (cx,cy,cz) = new_xyz[b,s], Wxs = the x,y,z rows of Wt, b2 = shift + scale*bias: the whole single-layer
+ *   set-abstraction level, (B,S,C1) out, nothing of size S*K written.  nsample <= 64, C1 % 4 == 0.
+ * tgn_sa_direct_max: the same result without the per-point tensor for narrow inputs (3+D <= 16, C1 % 32 == 0,
+ *   C1 <= 256, nsample <= 64; tgn_sa_direct_supported): a wave owns a query and contracts its K gathered rows
+ *   [x-c, f] (D+3) with Wd on the matrix cores.  Wd: (16, C1), rows [x, y, z, f0.., zero padding], scale folded.
+ */
+int tgn_sa_point_transform(long long M, int D, int C1, const float *xyz, const float *points, const float *Wt, float *A,
+                           tgn_stream_t stream);
+int tgn_sa_gather_max(int B, int N, int S, int K, int C1, const float *A, const float *new_xyz, const float *Wxs,
+                      const float *b2, const void *idx, int idx_is_int64, int relu, float *out, tgn_stream_t stream);
+/* First layer of a MULTI-layer shared MLP: out[b,s,k,c] = act(A[b,idx[b,s,k],c] - Wxs[:,c].centre + b2[c]), (B,S,K,C1). */
+int tgn_sa_gather_act(int B, int N, int S, int K, int C1, const float *A, const float *new_xyz, const float *Wxs,
+                      const float *b2, const void *idx, int idx_is_int64, int relu, float *out, tgn_stream_t stream);
+int tgn_sa_direct_supported(int K, int D, int C1);
+int tgn_sa_direct_max(int B, int N, int S, int K, int D, int C1, const float *xyz, const float *new_xyz,
+                      const float *points, const float *Wd, const float *b2, const void *idx, int idx_is_int64, int relu,
+                      float *out, tgn_stream_t stream);
 /* index_points (pointnet2_utils.py:44-61): out[b,j,:] = points[b, idx[b,j], :], idx flattened to (B,M). */
 int tgn_gather_points(int B, int N, int M, int C, const float *points, const void *idx, int idx_is_int64, float *out,
                       tgn_stream_t stream);

@@ -290,3 +290,18 @@ def queryandgroup(nsample, xyz, new_xyz, feat, idx, offset, new_offset, use_xyz=
     if use_xyz:
         return np.concatenate([grouped_xyz, grouped_feat], axis=-1)
     return grouped_feat
+
+
+def set_abstraction_first_layer(xyz, new_xyz, points, idx, W, bias, gamma, beta, mean, var, eps=1e-5, xyz_first=True,
+                                reduce_max=False):
+    """First shared-MLP layer of a set-abstraction level in eval mode, restated from the reference modules:
+    grouping (pointnet2_utils.py:162-169 [xyz first] / 281-285 [features first]) -> Conv2d 1x1 (W (C1, 3+D), bias) ->
+    BatchNorm2d with running statistics -> ReLU (:229-233 / :289-293) -> optionally max over the K neighbours
+    (:236 / :294).  The grouping is the exact fp32 one; the contraction is accumulated in float64 (the value every fp32
+    summation order approximates)."""
+    grouped = group_points(xyz, new_xyz, points, idx, xyz_first).astype(np.float64)      # (B,S,K,3+D)
+    y = grouped @ np.asarray(W, dtype=np.float64).T + np.asarray(bias, dtype=np.float64)
+    y = (y - np.asarray(mean, np.float64)) / np.sqrt(np.asarray(var, np.float64) + eps) * np.asarray(gamma, np.float64) \
+        + np.asarray(beta, np.float64)
+    y = np.maximum(y, 0.0)
+    return y.max(axis=2) if reduce_max else y

@@ -1,0 +1,156 @@
+"""GPU: the fused set-abstraction kernels (tgn_sa_point_transform on the fp32 matrix cores, tgn_sa_gather_max,
+tgn_sa_gather_act, tgn_sa_direct_max) against the CPU oracle's float64 restatement of the reference layer
+(oracle/cpu.py::set_abstraction_first_layer, pointnet2_utils.py:162-169/229-236/281-294) and against outputs of the
+reference's own modules (tests/golden/make_golden_r2_sa.py) -- at shapes where the fused path is taken on its own.
+Tolerance: 1e-5 of the output's magnitude (the kernels and the reference's BLAS differ in summation order only)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def close(got, want, what=""):
+    want = np.asarray(want, dtype=np.float64)
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(np.asarray(got, dtype=np.float64) - want).max())
+    assert err <= 1e-5 * scale, f"{what}: max abs error {err:.3e} > 1e-5 * {scale:.3f}"
+
+
+@pytest.mark.parametrize("M,D,C1", [(1000, 128, 512), (4096, 512, 1024), (777, 61, 24), (300, 125, 784), (129, 0, 32),
+                                     (5000, 6, 128), (2048, 64, 96), (257, 1024, 100)])
+def test_point_transform_is_an_exact_fp32_contraction(dev, M, D, C1):
+    """A = [points, xyz] @ Wt on v_mfma_f32_32x32x2_f32: every tile shape class (partial row / column / K tiles,
+    widths that are no multiple of 4), asymmetric operands (a transposed fragment would not pass)."""
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    g = torch.Generator().manual_seed(M + D + C1)
+    xyz = torch.randn(1, M, 3, generator=g).to(dev)
+    pts = torch.randn(1, M, D, generator=g).to(dev) if D else None
+    Wt = (torch.randn(D + 3, C1, generator=g) * torch.linspace(0.5, 2.0, C1)).to(dev)
+    A = U.sa_point_transform(xyz, pts, Wt)
+    full = torch.cat([pts, xyz], -1) if D else xyz
+    ref = (full.double() @ Wt.double())[0]
+    mag = (full.double().abs() @ Wt.double().abs())[0]                     # sum |a||w|: what fp32 rounding scales with
+    err = (A[0].double() - ref).abs()
+    assert float((err / (mag + 1e-30)).max()) < 4e-7 * max(1.0, (D + 3) ** 0.5 / 4), float((err / mag).max())
+    # bitwise: an fp32 fma chain in k order (the MFMA's definition) gives the same bits on a small case
+    if M <= 1000 and D + 3 <= 64:
+        a = full[0].cpu().numpy().astype(np.float32)
+        w = Wt.cpu().numpy().astype(np.float32)
+        acc = np.zeros((M, C1), np.float32)
+        for k in range(D + 3):
+            acc = np.float32(np.float64(a[:, k:k + 1]) * np.float64(w[k:k + 1, :]) + np.float64(acc)).astype(np.float32)
+        assert np.array_equal(A[0].cpu().numpy(), acc)
+
+
+def _layer(dev, D, C1, seed, xyz_first):
+    torch.manual_seed(seed)
+    conv = torch.nn.Conv2d(3 + D, C1, 1).to(dev)
+    bn = torch.nn.BatchNorm2d(C1).to(dev).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.4, 2.0)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.2)
+    return conv, bn
+
+
+@pytest.mark.parametrize("N,S,K,D,C1", [(4096, 1024, 32, 128, 512), (1024, 256, 32, 512, 1024), (6000, 1024, 32, 6, 128),
+                                         (900, 100, 16, 6, 64), (700, 50, 64, 13, 256), (500, 60, 7, 61, 100),
+                                         (800, 90, 48, 0, 32), (640, 33, 36, 200, 784)])
+@pytest.mark.parametrize("xyz_first", [True, False])
+def test_fused_level_and_first_layer_vs_oracle(dev, oracle, N, S, K, D, C1, xyz_first):
+    """sa_level_max (direct or transform + gather-max) and sa_first_layer (transform + gather-act) against the float64
+    restatement of grouping -> conv -> BN -> ReLU (-> max) on real ball-query neighbourhoods."""
+    from toothgroupnetwork_amd import pointnet2_utils as U, synth
+    B = 2
+    rng = np.random.default_rng(N + K + D)
+    pts6 = synth.scan_batch(B, N, "arch", seed=N % 97)
+    xyz = np.ascontiguousarray(pts6[:, :, :3])
+    feat = rng.normal(size=(B, N, D)).astype(np.float32) if D else None
+    tx, tf = T(xyz, dev), (T(feat, dev) if D else None)
+    fidx = U.farthest_point_sample(tx, S)
+    new_xyz = U.index_points(tx, fidx)
+    idx = U.query_ball_point(0.3, K, tx, new_xyz)
+    conv, bn = _layer(dev, D, C1, 7, xyz_first)
+    args = (xyz, new_xyz.cpu().numpy(), feat, idx.cpu().numpy(), conv.weight.detach().reshape(C1, -1).cpu().numpy(),
+            conv.bias.detach().cpu().numpy(), bn.weight.detach().cpu().numpy(), bn.bias.detach().cpu().numpy(),
+            bn.running_mean.cpu().numpy(), bn.running_var.cpu().numpy(), bn.eps, xyz_first)
+    with torch.no_grad():
+        got = U.sa_level_max(tx, new_xyz, tf, idx, conv, bn, xyz_first)
+        close(got.cpu().numpy(), oracle.set_abstraction_first_layer(*args, reduce_max=True), "level (max)")
+        if K <= 64 and C1 % 4 == 0:
+            got = U.sa_first_layer(tx, new_xyz, tf, idx.to(torch.int32), conv, bn, xyz_first)
+            close(got.cpu().numpy(), oracle.set_abstraction_first_layer(*args, reduce_max=False), "first layer")
+
+
+def test_fused_modules_match_the_reference_modules(dev, golden_r2, monkeypatch):
+    """The drop-in modules in eval mode take the fused path BY THEMSELVES at these shapes (nothing is patched; a spy only
+    counts) and reproduce the reference modules' outputs (same weights) within 1e-5 of the output magnitude."""
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    g = golden_r2
+    state = torch.load(os.path.join(GOLDEN, "module_weights_r2.pt"))
+    calls = {"level": 0, "first": 0, "group": 0}
+    real_level, real_first, real_group = U.sa_level_max, U.sa_first_layer, U.group_points
+
+    def spy(name, fn):
+        def wrapped(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return wrapped
+    monkeypatch.setattr(U, "sa_level_max", spy("level", real_level))
+    monkeypatch.setattr(U, "sa_first_layer", spy("first", real_first))
+    monkeypatch.setattr(U, "group_points", spy("group", real_group))
+    xyz, feat, pts6 = T(g["sa_in_xyz_cf"], dev), T(g["sa_in_feat_cf"], dev), T(g["sa_in_pts6_cf"], dev)
+    mods = {
+        "ssg_wide": (U.PointNetSetAbstraction(128, 0.25, 32, 3 + 64, [96], False), feat),
+        "ssg_narrow": (U.PointNetSetAbstraction(96, 0.3, 16, 3 + 6, [64], False), pts6),
+        "msg": (U.PointNetSetAbstractionMsg(128, [0.2, 0.3], [16, 32], 64, [[128], [64, 96]]), feat),
+    }
+    for name, (mod, f) in mods.items():
+        mod = mod.to(dev).eval()
+        mod.load_state_dict(state[name])
+        with torch.no_grad():
+            nx, nf = mod(xyz, f)
+        assert np.array_equal(nx.cpu().numpy(), g[f"sa_{name}_xyz"]), name      # same FPS indices -> identical centres
+        close(nf.cpu().numpy(), g[f"sa_{name}_feat"], name)
+    # ssg_wide, ssg_narrow and the single-layer Msg branch: whole level fused; the two-layer Msg branch: fused first layer
+    assert calls == {"level": 3, "first": 1, "group": 0}, calls
+
+
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_hotpath_fused_levels_vs_oracle(dev, oracle, pipeline):
+    """bench.py --fused: three chained fused levels (level l's output is level l+1's feature input) against the oracle
+    chain FPS -> ball query -> float64 layer, level by level, on every scan of a small batch."""
+    from toothgroupnetwork_amd import hotpath, synth
+    shape = dict(n=3000, npoint=[512, 128, 32], radius=[0.15, 0.3, 0.6], nsample=[32, 32, 16], d=[6, 64, 96], c_out=[64, 96, 160])
+    B = 3
+    scans = synth.scan_batch(B, 3000, "arch", 41)
+    pts = T(scans, dev)
+    xyz = pts[:, :, :3].contiguous()
+    hp = hotpath.HotPath(B, dev, shape=shape, pipeline=pipeline, fused=True)
+    for _ in range(3):
+        levels = hp.run(xyz, [pts])
+    torch.cuda.synchronize()
+    cur, feat = scans[:, :, :3].copy(), scans
+    for li, lv in enumerate(levels):
+        S, K, D, C1 = lv["S"], lv["K"], lv["D"], lv["C1"]
+        fidx = oracle.farthest_point_sample(cur, S)
+        assert np.array_equal(lv["fps_idx"].cpu().numpy(), fidx)
+        new_xyz = oracle.index_points(cur, fidx)
+        gidx = oracle.query_ball_point(shape["radius"][li], K, cur, new_xyz)
+        assert np.array_equal(lv["group_idx"].cpu().numpy(), gidx)
+        Wt = lv["Wt"].cpu().numpy()                                   # rows [features..., x, y, z]
+        W = np.concatenate([Wt[D:], Wt[:D]], 0).T                     # (C1, 3+D) in [xyz, features] order
+        want = oracle.set_abstraction_first_layer(cur, new_xyz, feat, gidx, W, lv["b2"].cpu().numpy(), np.ones(C1), np.zeros(C1),
+                                                  np.zeros(C1), np.full(C1, 1.0 - 1e-5), 1e-5, True, reduce_max=True)
+        close(lv["out"].cpu().numpy(), want, f"level {li + 1}")
+        cur, feat = new_xyz, lv["out"].cpu().numpy()                  # the GPU's own fp32 output feeds the next level in both chains

@@ -67,6 +67,11 @@ SIGNATURES = {
     "tgn_group_points_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, c_int, c_int, c_int, _P]),
     "tgn_sa_first_layer": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P]),
     "tgn_sa_first_layer_max": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P]),
+    "tgn_sa_point_transform": (c_int, [ctypes.c_longlong, c_int, c_int, _P, _P, _P, _P, _P]),
+    "tgn_sa_gather_max": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "tgn_sa_gather_act": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "tgn_sa_direct_supported": (c_int, [c_int, c_int, c_int]),
+    "tgn_sa_direct_max": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "tgn_gather_points": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P]),
     "tgn_scatter_add_points": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P]),
     "tgn_three_nn": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),

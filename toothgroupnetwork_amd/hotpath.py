@@ -14,7 +14,8 @@ import torch
 from . import _lib
 from ._lib import check, lib, ptr
 
-SHAPE_A = dict(n=24000, npoint=[4096, 1024, 256], radius=[0.05, 0.1, 0.2], nsample=[32, 32, 32], d=[6, 128, 512])
+SHAPE_A = dict(n=24000, npoint=[4096, 1024, 256], radius=[0.05, 0.1, 0.2], nsample=[32, 32, 32], d=[6, 128, 512],
+               c_out=[128, 512, 1024])   # c_out: width of the (single-layer) shared MLP of each level, fused mode only
 # Shape B of SURVEY.md section 8: what the reference instantiates (models/modules/pointnet_pp.py:13-15, scale 4) --
 # multi-scale grouping, two radii per level, grouped layout [features, centred xyz] (pointnet2_utils.py:285)
 SHAPE_B = dict(n=24000, npoint=[1024, 512, 256], radius=[[0.025, 0.05], [0.05, 0.1], [0.1, 0.2]],
@@ -28,10 +29,11 @@ def _branches(radius, nsample):
     return list(zip(rs, ks))
 
 
-def algorithmic_bytes(n, npoint, nsample, d, fused=False, radius=None, **_):
+def algorithmic_bytes(n, npoint, nsample, d, fused=False, radius=None, c_out=None, **_):
     """Compulsory HBM bytes per scan (inputs read once, outputs written once; fp32 data, int32 indices),
     per level: FPS = 12N + 4S ; per (radius, K) branch: ball = 12N + 12S + 4SK ; group = 4SK + 4N(3+D) + 12S + 4SK(3+D)
-    (Shape A 46 109 952 B, Shape B 165 863 680 B).
+    (Shape A 46 109 952 B, Shape B 165 863 680 B); fused: the grouped
+    tensor is never written, the level's output is (S, C_out): group = 4SK + 4N(3+D) + 12S + 4*S*C_out (Shape A 12 588 288 B).
     Returns (total, per_level list of dicts)."""
     levels = []
     N = n
@@ -39,7 +41,7 @@ def algorithmic_bytes(n, npoint, nsample, d, fused=False, radius=None, **_):
         ks = [k for _, k in _branches(radius[i] if radius is not None else 0.0, nsample[i])]
         fps = 12 * N + 4 * S
         ball = sum(12 * N + 12 * S + 4 * S * K for K in ks)
-        group = sum(4 * S * K + 4 * N * (3 + D) + 12 * S + (0 if fused else 4 * S * K * (3 + D)) for K in ks)
+        group = sum(4 * S * K + 4 * N * (3 + D) + 12 * S + (4 * S * c_out[i] if fused else 4 * S * K * (3 + D)) for K in ks)
         levels.append(dict(fps=fps, ball=ball, group=group, total=fps + ball + group))
         N = S
     return sum(l["total"] for l in levels), levels
@@ -51,17 +53,21 @@ class HotPath:
     pipeline=True software-pipelines consecutive steps over two HIP streams: the FPS chain of step k+1 (latency
     bound: one workgroup per CU, nearly all registers, almost no issue slots or bandwidth) runs on a high-priority
     stream while the ball queries and groupings of step k (HBM / VALU bound, 26-56 VGPRs) run on a second stream and
-    fill the CUs around it.  Buffers are double-buffered by step parity; HIP events order FPS level l before the
+    fill the CUs around it (in fused mode the set-abstraction kernels take the groupings' place).  Buffers are double-buffered by step parity; HIP events order FPS level l before the
     ball query / grouping of level l of the same step, and step k-2's consumers before step k's producers."""
 
     def __init__(self, B, device, shape=SHAPE_A, xyz_first=True, index_dtype=torch.int32, pipeline=False,
-                 fps_prefix=False, group_impl=0, group_policy=-1, group_max_blocks=None):
+                 fps_prefix=False, group_impl=0, group_policy=-1, group_max_blocks=None, fused=False):
         self.B, self.device, self.shape = B, device, shape
         # launch knobs of the grouping kernel (include/tgn_pointops.h, tgn_group_points_ex).  In the two-stream schedule
         # its grid is bounded so that an FPS level-1 workgroup (which needs an almost empty CU) always finds room:
         # 512 blocks = 2 per CU = 2 waves per SIMD, what fits beside 2 x 232 VGPRs of FPS.
         self.group_impl, self.group_policy = int(group_impl), int(group_policy)
         self.group_max_blocks = int(group_max_blocks) if group_max_blocks is not None else (512 if pipeline else 0)
+        # fused: every level is a whole set-abstraction level with a single-layer shared MLP (eval-mode BatchNorm folded):
+        # FPS -> ball query -> [per-point transform on the fp32 matrix cores + gather-max | direct kernel]; the grouped
+        # tensor is never written and level l's (B,S,C_out) output is level l+1's feature input.
+        self.fused = bool(fused)
         # fps_prefix: hand every FPS level the certificate of the level that produced its input (FPS of an FPS result
         # is the identity, include/tgn_pointops.h): levels > 0 then return 0..S-1 without iterating, decided per cloud
         # on the device.  Off by default: the headline benchmark runs every level's sampling for real.
@@ -95,8 +101,21 @@ class HotPath:
                 lv["branches"].append(dict(
                     K=kb, r2=float(torch.tensor(float(rb) ** 2, dtype=torch.float32).item()),
                     group_idx=torch.empty(B, S, kb, dtype=index_dtype, device=device),
-                    grouped=torch.empty(B, S, kb, 3 + D, **f32), ws_bytes=nbytes,
+                    grouped=None if self.fused else torch.empty(B, S, kb, 3 + D, **f32), ws_bytes=nbytes,
                     ws=torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None))
+            if self.fused:
+                li = len(levels)
+                C1 = shape["c_out"][li]
+                g = torch.Generator(device="cpu").manual_seed(1000 + li)
+                # folded weights of the level's Conv2d(3+D -> C1) + BatchNorm (synthetic, seeded): Wt rows [features.., x,y,z]
+                Wt = (torch.randn(D + 3, C1, generator=g) / float(D + 3) ** 0.5).to(device)
+                Wd = torch.zeros(16, C1, device=device)
+                if D + 3 <= 16:
+                    Wd[:3], Wd[3:3 + D] = Wt[D:], Wt[:D]
+                lv.update(C1=C1, Wt=Wt.contiguous(), Wxs=Wt[D:].contiguous(), Wd=Wd, b2=(0.1 * torch.randn(C1, generator=g)).to(device),
+                          out=torch.empty(B, S, C1, **f32),
+                          direct=bool(self.L.tgn_sa_direct_supported(lv["branches"][0]["K"], D, C1)))
+                lv["A"] = None if lv["direct"] else torch.empty(B, N, C1, **f32)
             lv.update({k: lv["branches"][0][k] for k in ("K", "r2", "group_idx", "grouped", "ws", "ws_bytes")})
             levels.append(lv)
             N = S
@@ -111,6 +130,25 @@ class HotPath:
                                                 ptr(pts), ptr(br["group_idx"]), self.idx64, int(self.xyz_first),
                                                 ptr(br["grouped"]), self.group_impl, self.group_policy,
                                                 self.group_max_blocks, st), "group_points")
+
+    def _sa(self, lv, br, cur_xyz, pts, st):
+        """one fused set-abstraction level on stream st (tgn_sa_direct_max, or tgn_sa_point_transform + tgn_sa_gather_max)"""
+        L, B = self.L, self.B
+        if lv["direct"]:
+            return check(L.tgn_sa_direct_max(B, lv["N"], lv["S"], br["K"], lv["D"], lv["C1"], ptr(cur_xyz), ptr(lv["new_xyz"]),
+                                             ptr(pts), ptr(lv["Wd"]), ptr(lv["b2"]), ptr(br["group_idx"]), self.idx64, 1,
+                                             ptr(lv["out"]), st), "sa_direct_max")
+        check(L.tgn_sa_point_transform(B * lv["N"], lv["D"], lv["C1"], ptr(cur_xyz), ptr(pts), ptr(lv["Wt"]), ptr(lv["A"]), st),
+              "sa_point_transform")
+        return check(L.tgn_sa_gather_max(B, lv["N"], lv["S"], br["K"], lv["C1"], ptr(lv["A"]), ptr(lv["new_xyz"]), ptr(lv["Wxs"]),
+                                         ptr(lv["b2"]), ptr(br["group_idx"]), self.idx64, 1, ptr(lv["out"]), st), "sa_gather_max")
+
+    def _consume(self, i, lv, cur_xyz, feats, levels, st):
+        """what follows the ball query of level i: the grouping (materialised) or the fused level"""
+        if self.fused:
+            pts = feats[0] if i == 0 else levels[i - 1]["out"]     # level l consumes level l-1's output features
+            return [self._sa(lv, br, cur_xyz, pts, st) for br in lv["branches"]]
+        return [self._group(lv, br, cur_xyz, feats[i], st) for br in lv["branches"]]
 
     def enable_kernel_timing(self, steps):
         """HIP events on the launch stream around each kernel class (start/stop per step)."""
@@ -145,10 +183,9 @@ class HotPath:
         cur_xyz = xyz
         for i, lv in enumerate(self.levels):
             B, N, S, K, D = self.B, lv["N"], lv["S"], lv["K"], lv["D"]
-            pts = feats[i]
             self._timed(f"fps_l{i + 1}", lambda: self._fps(i, lv, cur_xyz, self.levels, st))
             self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, cur_xyz, st) for br in lv["branches"]])
-            self._timed(f"group_l{i + 1}", lambda: [self._group(lv, br, cur_xyz, pts, st) for br in lv["branches"]])
+            self._timed(f"group_l{i + 1}", lambda: self._consume(i, lv, cur_xyz, feats, self.levels, st))
             cur_xyz = lv["new_xyz"]
         if self.events is not None:
             self._step += 1
@@ -192,7 +229,7 @@ class HotPath:
         for i, lv in enumerate(levels):
             N, S, K, D = lv["N"], lv["S"], lv["K"], lv["D"]
             sg.wait_event(self.ev_fps[p][i])
-            self._timed(f"group_l{i + 1}", lambda: [self._group(lv, br, cur_xyz, feats[i], pg) for br in lv["branches"]], sg)
+            self._timed(f"group_l{i + 1}", lambda: self._consume(i, lv, cur_xyz, feats, levels, pg), sg)
             cur_xyz = lv["new_xyz"]
         self.ev_done[p].record(sg)
         cur.wait_event(self.ev_done[p])     # the caller's stream sees this step's results

@@ -388,7 +388,7 @@ def three_interpolate(points2, dist, idx):
 
 
 # ---------------------------------------------------------------------------------------------
-# fused first layer of a set-abstraction MLP (eval mode)
+# fused set abstraction (eval mode): the first shared-MLP layer without the grouped (B,S,K,3+D) tensor
 # ---------------------------------------------------------------------------------------------
 FUSED_SA = os.environ.get("TGN_FUSED_SA", "1") != "0"
 
@@ -405,42 +405,94 @@ def _can_fuse(module, *tensors):
 
 
 def _fuse_pays(N, S, K, c_in, c1):
-    """The fused first layer trades the grouped tensor (S*K rows of c_in) for a per-point one (N rows of c1): worth it
-    once the former is the larger (sa1 of the reference net, c_in = 9 -> 128 channels: it is not; measured 0.89x)."""
+    """A MULTI-layer MLP still needs its (B,S,K,C1) first-layer output; the commuted first layer trades the grouped
+    tensor (S*K rows of c_in) for a per-point one (N rows of c1): worth it once the former is the larger (sa1 of the
+    reference net, c_in = 9 -> 128 channels: it is not; measured 0.89x)."""
     return S * K * c_in > N * c1
+
+
+def fold_first_layer(conv, bn, D, xyz_first):
+    """The first Conv2d(1x1) + eval-mode BatchNorm2d of a shared MLP as the operands of the fused kernels
+    (include/tgn_pointops.h): scale = gamma/sqrt(var+eps) goes into the weight columns, shift + scale*bias into b2.
+      Wt  (D+3, C1) rows [features..., x, y, z]   -- tgn_sa_point_transform
+      Wxs (3, C1)   the x, y, z rows of Wt        -- centre term of tgn_sa_gather_max / tgn_sa_gather_act
+      Wd  (16, C1)  rows [x, y, z, features..., 0] -- tgn_sa_direct_max
+      b2  (C1,)"""
+    C1 = conv.out_channels
+    W = conv.weight.detach().reshape(C1, -1).float()                       # (C1, 3+D) in the module's channel order
+    bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(C1, device=W.device)
+    scale = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).float()
+    shift = (bn.bias.detach() - bn.running_mean * scale).float()
+    Wx, Wp = (W[:, :3], W[:, 3:]) if xyz_first else (W[:, D:], W[:, :D])   # sample_and_group: [xyz, feat]; Msg: [feat, xyz]
+    Ws = W.new_empty(C1, 3 + D)
+    Ws[:, :D], Ws[:, D:] = Wp * scale[:, None], Wx * scale[:, None]
+    Wt = Ws.t().contiguous()                                               # (D+3, C1): [features..., x, y, z]
+    Wd = W.new_zeros(16, C1)
+    if 3 + D <= 16:
+        Wd[:3], Wd[3:3 + D] = Wt[D:], Wt[:D]
+    return dict(Wt=Wt, Wxs=Wt[D:].contiguous(), Wd=Wd, b2=(shift + scale * bias).contiguous(), C1=C1)
+
+
+def sa_point_transform(xyz, points, Wt):
+    """A[b,n,:] = [points[b,n,:], xyz[b,n,:]] @ Wt -- the per-POINT half of a fused first layer, on the fp32 matrix
+    cores (tgn_sa_point_transform).  xyz (B,N,3), points (B,N,D) or None, Wt (D+3, C1) -> (B,N,C1)."""
+    B, N, _ = xyz.shape
+    D = 0 if points is None else points.shape[2]
+    C1 = Wt.shape[1]
+    A = torch.empty(B, N, C1, dtype=torch.float32, device=xyz.device)
+    check(lib().tgn_sa_point_transform(B * N, D, C1, ptr(xyz), ptr(points), ptr(Wt), ptr(A), stream()), "sa_point_transform")
+    return A
+
+
+def sa_level_max(xyz, new_xyz, points, idx, conv, bn, xyz_first):
+    """A whole single-layer set-abstraction level after sampling and ball query:
+        max_k relu(bn(conv([xyz[idx]-new_xyz, points[idx]])))  ->  (B,S,C1)
+    (pointnet2_utils.py:162-169 + 229-236, or 281-294 for Msg) with nothing of size S*K ever written: narrow inputs go
+    through the direct kernel (gather -> matrix cores -> max), wide ones through the per-point transform + gather-max."""
+    B, N, _ = xyz.shape
+    _, S, K = idx.shape
+    D = 0 if points is None else points.shape[2]
+    f = fold_first_layer(conv, bn, D, xyz_first)
+    C1 = f["C1"]
+    idx = idx.contiguous()
+    out = torch.empty(B, S, C1, dtype=torch.float32, device=xyz.device)
+    L = lib()
+    if L.tgn_sa_direct_supported(K, D, C1):
+        check(L.tgn_sa_direct_max(B, N, S, K, D, C1, ptr(xyz), ptr(new_xyz), ptr(points), ptr(f["Wd"]), ptr(f["b2"]), ptr(idx),
+                                  int(idx.dtype == torch.int64), 1, ptr(out), stream()), "sa_direct_max")
+    else:
+        A = sa_point_transform(xyz, points, f["Wt"])
+        check(L.tgn_sa_gather_max(B, N, S, K, C1, ptr(A), ptr(new_xyz), ptr(f["Wxs"]), ptr(f["b2"]), ptr(idx),
+                                  int(idx.dtype == torch.int64), 1, ptr(out), stream()), "sa_gather_max")
+    _lib.raise_on_index_error("set abstraction (grouping)")
+    return out
 
 
 def sa_first_layer(xyz, new_xyz, points, idx, conv, bn, xyz_first, reduce_max=False):
     """relu(bn(conv(grouped))) of the FIRST shared-MLP layer without ever building `grouped`
     (pointnet2_utils.py:162-169 + 229-233, or 281-292 for Msg).  The 1x1 convolution commutes with the gather:
         W*[points[idx], xyz[idx]-c] + b = (W_p*points + W_x*xyz)[idx] + (b - W_x*c)
-    so the dense part runs over the N points (one GEMM) instead of the S*K grouped rows, and the HIP kernel only
-    gathers, adds the per-query constant and applies ReLU (optionally also the max over the K neighbours).
-    Returns (B,S,K,C1), or (B,S,C1) with reduce_max.  Eval-mode BatchNorm statistics are folded in."""
+    so the contraction runs over the N points (tgn_sa_point_transform, fp32 MFMA) instead of the S*K grouped rows and
+    the per-query kernel only gathers, adds the centre term and applies ReLU.  Returns (B,S,K,C1), or (B,S,C1) with
+    reduce_max (= sa_level_max).  Eval-mode BatchNorm statistics are folded in."""
+    if reduce_max:
+        return sa_level_max(xyz, new_xyz, points, idx, conv, bn, xyz_first)
     B, N, _ = xyz.shape
     _, S, K = idx.shape
-    C1 = conv.out_channels
-    W = conv.weight.detach().reshape(C1, -1).float()
-    bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(C1, device=W.device)
-    scale = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).float()
-    shift = (bn.bias.detach() - bn.running_mean * scale).float()
     D = 0 if points is None else points.shape[2]
-    Wx, Wp = (W[:, :3], W[:, 3:]) if xyz_first else (W[:, D:], W[:, :D])
-    G = torch.matmul(xyz, Wx.t())
-    if points is not None:
-        G = G + torch.matmul(points, Wp.t())
-    A = (G * scale).contiguous()                                                   # (B,N,C1)
-    Cst = (shift + scale * (bias - torch.matmul(new_xyz, Wx.t()))).contiguous()    # (B,S,C1)
+    f = fold_first_layer(conv, bn, D, xyz_first)
+    C1 = f["C1"]
     idx = idx.contiguous()
-    if reduce_max:
-        out = torch.empty(B, S, C1, dtype=torch.float32, device=xyz.device)
-        check(lib().tgn_sa_first_layer_max(B, N, S, K, C1, ptr(A), ptr(Cst), ptr(idx), int(idx.dtype == torch.int64), 1,
-                                           ptr(out), stream()), "sa_first_layer_max")
-    else:
-        out = torch.empty(B, S, K, C1, dtype=torch.float32, device=xyz.device)
-        check(lib().tgn_sa_first_layer(B, N, S, K, C1, ptr(A), ptr(Cst), ptr(idx), int(idx.dtype == torch.int64), 1,
-                                       ptr(out), stream()), "sa_first_layer")
+    A = sa_point_transform(xyz, points, f["Wt"])
+    out = torch.empty(B, S, K, C1, dtype=torch.float32, device=xyz.device)
+    check(lib().tgn_sa_gather_act(B, N, S, K, C1, ptr(A), ptr(new_xyz), ptr(f["Wxs"]), ptr(f["b2"]), ptr(idx),
+                                  int(idx.dtype == torch.int64), 1, ptr(out), stream()), "sa_gather_act")
+    _lib.raise_on_index_error("set abstraction (grouping)")
     return out
+
+
+def _fused_shape_ok(K, C1):
+    return K <= 64 and C1 % 4 == 0
 
 
 def _mlp_tail_and_max(x_bskc, convs, bns, first):
@@ -476,17 +528,20 @@ class PointNetSetAbstraction(nn.Module):
         if points is not None:
             points = points.permute(0, 2, 1)
         if (not self.group_all and len(self.mlp_convs) > 0 and _can_fuse(self, xyz, points)
-                and _fuse_pays(xyz.shape[1], self.npoint, self.nsample, 3 + (0 if points is None else points.shape[2]),
-                               self.mlp_convs[0].out_channels)):
+                and _fused_shape_ok(self.nsample, self.mlp_convs[0].out_channels)
+                and (len(self.mlp_convs) == 1 or
+                     _fuse_pays(xyz.shape[1], self.npoint, self.nsample, 3 + (0 if points is None else points.shape[2]),
+                                self.mlp_convs[0].out_channels))):
             # eval fast path: FPS (+coordinates) -> ball query -> fused first layer; `grouped` is never built
             xyz_c = _f32c(xyz)
             points_c = None if points is None else _f32c(points)
             _, new_xyz = _fps_dense(xyz_c, self.npoint, want_coords=True)
             idx = query_ball_point(self.radius, self.nsample, xyz_c, new_xyz)
-            single = len(self.mlp_convs) == 1
-            y = sa_first_layer(xyz_c, new_xyz, points_c, idx, self.mlp_convs[0], self.mlp_bns[0], xyz_first=True,
-                               reduce_max=single)
-            new_points = y.permute(0, 2, 1) if single else _mlp_tail_and_max(y, self.mlp_convs, self.mlp_bns, 1)
+            if len(self.mlp_convs) == 1:     # the whole level in the fused kernels
+                new_points = sa_level_max(xyz_c, new_xyz, points_c, idx, self.mlp_convs[0], self.mlp_bns[0], True).permute(0, 2, 1)
+            else:
+                y = sa_first_layer(xyz_c, new_xyz, points_c, idx, self.mlp_convs[0], self.mlp_bns[0], xyz_first=True)
+                new_points = _mlp_tail_and_max(y, self.mlp_convs, self.mlp_bns, 1)
             return new_xyz.permute(0, 2, 1), new_points
         if self.group_all:
             new_xyz, new_points = sample_and_group_all(xyz, points)
@@ -539,13 +594,16 @@ class PointNetSetAbstractionMsg(nn.Module):
         for i, radius in enumerate(self.radius_list):
             K = self.nsample_list[i]
             group_idx = query_ball_point(radius, K, xyz_c, new_xyz)
-            if fuse and _fuse_pays(xyz_c.shape[1], S, K, 3 + (0 if points_c is None else points_c.shape[2]),
-                                   self.conv_blocks[i][0].out_channels):
+            if (fuse and _fused_shape_ok(K, self.conv_blocks[i][0].out_channels)
+                    and (len(self.conv_blocks[i]) == 1 or
+                         _fuse_pays(xyz_c.shape[1], S, K, 3 + (0 if points_c is None else points_c.shape[2]),
+                                    self.conv_blocks[i][0].out_channels))):
                 convs, bns = self.conv_blocks[i], self.bn_blocks[i]
-                single = len(convs) == 1
-                y = sa_first_layer(xyz_c, new_xyz, points_c, group_idx, convs[0], bns[0], xyz_first=False,
-                                   reduce_max=single)
-                new_points_list.append(y.permute(0, 2, 1) if single else _mlp_tail_and_max(y, convs, bns, 1))
+                if len(convs) == 1:
+                    new_points_list.append(sa_level_max(xyz_c, new_xyz, points_c, group_idx, convs[0], bns[0], False).permute(0, 2, 1))
+                else:
+                    y = sa_first_layer(xyz_c, new_xyz, points_c, group_idx, convs[0], bns[0], xyz_first=False)
+                    new_points_list.append(_mlp_tail_and_max(y, convs, bns, 1))
                 continue
             grouped_points = group_points(xyz_c, new_xyz, points_c, group_idx, xyz_first=False)  # [feat, rel_xyz] (:285)
             grouped_points = grouped_points.permute(0, 3, 2, 1)  # [B, D, K, S]
