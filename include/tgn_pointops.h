@@ -180,6 +180,32 @@ int tgn_aggregation_backward(int n, int nsample, int c, int w_c, const float *in
                              const float *weight, const int *idx, const float *grad_output, float *grad_input,
                              float *grad_position, float *grad_weight, tgn_stream_t stream);
 
+/*
+ * Point-Transformer vector attention (models/modules/cbl_point_transformer/blocks.py:31-44), packed layout.
+ *
+ * tgn_pt_attention_forward: the whole PointTransformerLayer after its three input projections, eval mode:
+ *     p_r = linear_p(p[idx] - p)                      Linear(3,3) + BatchNorm1d(3) folded into (Wp1, bp1), ReLU, Linear(3,c) = (Wp2, bp2)
+ *     w   = linear_w(x_k[idx] - x_q + p_r)            BatchNorm1d(c) as (a1, t1), ReLU, Linear(c,g) + BatchNorm1d(g) folded into
+ *                                                     (Ww1, bw1), ReLU, Linear(g,g) = (Ww2, bw2);  g = c / share_planes
+ *     out = sum_j (x_v[idx_j] + p_r_j) * softmax_j(w)[.., ch % g]
+ *   p (n,3), x_q / x_k / x_v (n,c), idx (n,nsample) int32 neighbour rows (the kNN of p among p), out (n,c).
+ *   One kernel, nothing of size n*nsample*c is written.  nsample <= 64, c % 4 == 0, g in {4,8,16,32,64}.
+ * tgn_pt_softmax_aggregate_{forward,backward}: the trainable tail alone (blocks.py:41-43): softmax over the
+ *   neighbours of logit (n,nsample,g) -> sm (kept for backward), out[n,ch] = sum_j (x_v[idx[n,j],ch] + p_r[n,j,ch]) *
+ *   sm[n,j,ch % g]; the backward writes grad_pr (n,nsample,c), grad_logit (n,nsample,g) and ACCUMULATES into grad_xv
+ *   (n_v,c; pre-zeroed).  This is the reference's `aggregation` (aggregation_cuda_kernel.cu:5-39) with the softmax
+ *   fused in front.
+ */
+int tgn_pt_attention_forward(int n, int nsample, int c, int g, const float *p, const float *xq, const float *xk,
+                             const float *xv, const int *idx, const float *Wp1, const float *bp1, const float *Wp2,
+                             const float *bp2, const float *a1, const float *t1, const float *Ww1, const float *bw1,
+                             const float *Ww2, const float *bw2, float *out, tgn_stream_t stream);
+int tgn_pt_softmax_aggregate_forward(int n, int nsample, int c, int g, const float *xv, const float *pr, const float *logit,
+                                     const int *idx, float *sm, float *out, tgn_stream_t stream);
+int tgn_pt_softmax_aggregate_backward(int n, int nsample, int c, int g, const float *xv, const float *pr, const float *sm,
+                                      const int *idx, const float *grad_out, float *grad_xv, float *grad_pr,
+                                      float *grad_logit, tgn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * 3. pointnet2_utils operators as single kernels (dense (B,N,*) layout).
  * ---------------------------------------------------------------------------------------- */

@@ -305,3 +305,29 @@ def set_abstraction_first_layer(xyz, new_xyz, points, idx, W, bias, gamma, beta,
         + np.asarray(beta, np.float64)
     y = np.maximum(y, 0.0)
     return y.max(axis=2) if reduce_max else y
+
+
+def pt_attention_layer(p, x_q, x_k, x_v, idx, sd, share_planes=8, eps=1e-5):
+    """PointTransformerLayer.forward after the three input projections, eval mode, restated from
+    models/modules/cbl_point_transformer/blocks.py:34-43 in float64.  p (n,3), x_q/x_k/x_v (n,c), idx (n,nsample) neighbour
+    rows, sd: the layer's state_dict as numpy arrays (reference names: linear_p.0/1/3, linear_w.0/2/3/5)."""
+    f8 = lambda a: np.asarray(a, dtype=np.float64)
+    p, x_q, x_k, x_v = f8(p), f8(x_q), f8(x_k), f8(x_v)
+    li = np.asarray(idx).astype(np.int64)
+
+    def bn(x, name):          # BatchNorm1d over the channel (last) axis, running statistics
+        return (x - f8(sd[name + ".running_mean"])) / np.sqrt(f8(sd[name + ".running_var"]) + eps) * f8(sd[name + ".weight"]) \
+            + f8(sd[name + ".bias"])
+
+    def lin(x, name):
+        return x @ f8(sd[name + ".weight"]).T + f8(sd[name + ".bias"])
+    p_r = p[li] - p[:, None, :]                                              # queryandgroup: xyz[idx] - new_xyz (pointops.py:89-91)
+    p_r = lin(np.maximum(bn(lin(p_r, "linear_p.0"), "linear_p.1"), 0.0), "linear_p.3")      # (n, nsample, c)
+    w = x_k[li] - x_q[:, None, :] + p_r                                      # blocks.py:39 (mid_planes == out_planes)
+    w = lin(np.maximum(bn(w, "linear_w.0"), 0.0), "linear_w.2")
+    w = lin(np.maximum(bn(w, "linear_w.3"), 0.0), "linear_w.5")              # (n, nsample, c / share_planes)
+    w = np.exp(w - w.max(axis=1, keepdims=True))
+    w = w / w.sum(axis=1, keepdims=True)                                     # softmax over the neighbours (:41)
+    n, ns, c = p_r.shape
+    s = share_planes
+    return ((x_v[li] + p_r).reshape(n, ns, s, c // s) * w[:, :, None, :]).sum(1).reshape(n, c)

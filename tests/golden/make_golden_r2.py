@@ -71,6 +71,11 @@ def main():
     except ImportError:
         pass
     try:
+        from make_golden_r2_pt import pt_fixtures
+        pt_fixtures(out)
+    except ImportError:
+        pass
+    try:
         from make_golden_r2_io import io_fixtures
         io_fixtures(out)
     except ImportError:

@@ -1,0 +1,139 @@
+"""GPU: fused Point-Transformer attention (tgn_pt_attention_forward), its trainable tail (tgn_pt_softmax_aggregate_*),
+the fused transition-down step and the U-Net forward built from the mirror modules, against the reference layer's
+golden output (tests/golden/make_golden_r2_pt.py), the CPU oracle's float64 restatement of blocks.py:34-43 and torch
+autograd."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def close(got, want, what="", tol=1e-5):
+    want = np.asarray(want, dtype=np.float64)
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(np.asarray(got, dtype=np.float64) - want).max())
+    assert err <= tol * scale, f"{what}: max abs error {err:.3e} > {tol} * {scale:.3f}"
+
+
+def _randomise_bn(mod, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m_ in mod.modules():
+        if isinstance(m_, torch.nn.BatchNorm1d):
+            m_.running_mean.copy_(torch.randn(m_.num_features, generator=g) * 0.2)
+            m_.running_var.copy_(torch.rand(m_.num_features, generator=g) * 1.5 + 0.5)
+            m_.weight.data.copy_(torch.rand(m_.num_features, generator=g) + 0.5)
+            m_.bias.data.copy_(torch.randn(m_.num_features, generator=g) * 0.1)
+
+
+def test_fused_layer_reproduces_the_reference_layer(dev, golden_r2):
+    """our PointTransformerLayer with the reference layer's weights, eval mode: the single fused kernel against the
+    reference's own forward (its torch code over CPU gathers)."""
+    from toothgroupnetwork_amd import point_transformer as PT
+    g = golden_r2
+    layer = PT.PointTransformerLayer(32, 32, 8, 16).to(dev).eval()
+    layer.load_state_dict(torch.load(os.path.join(GOLDEN, "pt_layer_weights_r2.pt")))
+    with torch.no_grad():
+        y = layer([T(g["pt_xyz"], dev), T(g["pt_x"], dev), T(g["pt_off"], dev)])
+    close(y.cpu().numpy(), g["pt_y"], "fused layer vs reference layer", tol=2e-5)
+
+
+@pytest.mark.parametrize("n,c,ns", [(24000, 32, 36), (6000, 64, 24), (1500, 128, 24), (375, 256, 24), (93, 512, 24), (500, 32, 5),
+                                     (333, 64, 64)])
+def test_fused_attention_vs_oracle(dev, oracle, n, c, ns):
+    """every stage width of the tgnet_fps U-Net (enc1 ... enc5: c = 32 ... 512, share_planes 8), enc1 at full size
+    (24 000 points, 36 neighbours): the fused kernel against the float64 restatement, eval mode; and the training-path
+    composition (fused softmax + aggregation tail) against the same."""
+    from toothgroupnetwork_amd import point_transformer as PT, pointops as P, synth
+    xyz = synth.arch_cloud(n, seed=n % 89, with_normals=False)
+    off = np.array([n], np.int32)
+    x = np.random.default_rng(c).normal(size=(n, c)).astype(np.float32)
+    torch.manual_seed(c + ns)
+    layer = PT.PointTransformerLayer(c, c, 8, ns).to(dev).eval()
+    _randomise_bn(layer, c)
+    tx, tp, to = T(x, dev), T(xyz, dev), T(off, dev)
+    with torch.no_grad():
+        y = layer([tp, tx, to])
+        xq, xk, xv = layer.linear_q(tx), layer.linear_k(tx), layer.linear_v(tx)
+        idx, _ = P.knnquery(ns, tp, tp, to, to)
+    sd = {k: v.cpu().numpy() for k, v in layer.state_dict().items()}
+    want = oracle.pt_attention_layer(xyz, xq.cpu().numpy(), xk.cpu().numpy(), xv.cpu().numpy(), idx.cpu().numpy(), sd, 8)
+    close(y.cpu().numpy(), want, "fused")
+    if n <= 6000:
+        y2 = layer([tp, tx.clone().requires_grad_(True), to])          # autograd on: the composition with the fused tail
+        assert y2.requires_grad
+        close(y2.detach().cpu().numpy(), want, "training-path composition")
+
+
+def test_softmax_aggregate_forward_backward_vs_torch(dev):
+    from toothgroupnetwork_amd import point_transformer as PT
+    torch.manual_seed(3)
+    n, nv, ns, c, s = 300, 340, 11, 48, 8
+    g = c // s
+    xv = torch.randn(nv, c, device=dev, requires_grad=True)
+    pr = torch.randn(n, ns, c, device=dev, requires_grad=True)
+    lg = torch.randn(n, ns, g, device=dev, requires_grad=True)
+    idx = torch.randint(0, nv, (n, ns), device=dev, dtype=torch.int32)
+    go = torch.randn(n, c, device=dev)
+    out = PT.pt_softmax_aggregate(xv, pr, lg, idx)
+    out.backward(go)
+    x2, p2, l2 = (t.detach().clone().requires_grad_(True) for t in (xv, pr, lg))
+    w = torch.softmax(l2, dim=1)
+    ref = ((x2[idx.long()] + p2).view(n, ns, s, g) * w.unsqueeze(2)).sum(1).view(n, c)      # blocks.py:41-43
+    ref.backward(go)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(pr.grad, p2.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(lg.grad, l2.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(xv.grad, x2.grad, rtol=1e-4, atol=1e-4)      # atomically accumulated
+
+
+def test_transition_down_fused_equals_the_reference_composition(dev, oracle):
+    """stride-4 TransitionDown (blocks.py:62-74), eval: FPS + kNN + fused set-abstraction kernels against the same
+    module's torch composition (queryandgroup -> Linear -> BN -> ReLU -> MaxPool) and against the oracle chain."""
+    from toothgroupnetwork_amd import point_transformer as PT, synth
+    sizes = [3000, 1700]
+    xyz = np.concatenate([synth.arch_cloud(m, seed=60 + i, with_normals=False) for i, m in enumerate(sizes)])
+    off = np.cumsum(sizes).astype(np.int32)
+    x = np.random.default_rng(1).normal(size=(sum(sizes), 32)).astype(np.float32)
+    torch.manual_seed(5)
+    td = PT.TransitionDown(32, 64, 4, 24).to(dev).eval()
+    _randomise_bn(td, 9)
+    tp, tx, to = T(xyz, dev), T(x, dev), T(off, dev)
+    with torch.no_grad():
+        p1, y1, o1 = td([tp, tx, to])
+    p2, y2, o2 = td([tp, tx.clone().requires_grad_(True), to])            # autograd on: the torch composition
+    assert torch.equal(p1, p2) and torch.equal(o1, o2) and o1.tolist() == [750, 1175]
+    close(y1.cpu().numpy(), y2.detach().cpu().numpy(), "fused vs composition")
+    n_o = np.array([750, 1175], np.int32)
+    fidx = oracle.furthestsampling(xyz, off, n_o)
+    assert np.array_equal(p1.cpu().numpy(), xyz[fidx.astype(np.int64)])
+    kidx, _ = oracle.knnquery(24, xyz, xyz[fidx.astype(np.int64)], off, n_o)
+    W = td.linear.weight.detach().cpu().numpy()
+    bn = td.bn
+    want = oracle.set_abstraction_first_layer(xyz[None], xyz[fidx.astype(np.int64)][None], x[None], kidx[None].astype(np.int64), W,
+                                              np.zeros(64), bn.weight.detach().cpu().numpy(), bn.bias.detach().cpu().numpy(),
+                                              bn.running_mean.cpu().numpy(), bn.running_var.cpu().numpy(), bn.eps, True, reduce_max=True)
+    close(y1.cpu().numpy(), want[0], "fused vs oracle")
+
+
+def test_unet_forward_at_24000_points(dev):
+    """BASELINE.json config 4: the Point-Transformer encoder / decoder forward on one 24 000-point scan, built from the
+    mirror modules; the fused eval path and the unfused composition agree."""
+    from toothgroupnetwork_amd import point_transformer as PT, synth
+    torch.manual_seed(0)
+    net = PT.PointTransformerUNet().to(dev).eval()
+    _randomise_bn(net, 1)
+    inp = T(synth.scan_batch(1, 24000, "arch", 3).transpose(0, 2, 1).copy(), dev)
+    with torch.no_grad():
+        y = net(inp)
+    assert y.shape == (24000, 32) and torch.isfinite(y).all()
+    y2 = net(inp.clone().requires_grad_(True))
+    close(y.cpu().numpy(), y2.detach().cpu().numpy(), "fused vs composition through 23 blocks", tol=1e-3)

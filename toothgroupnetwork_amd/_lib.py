@@ -60,6 +60,9 @@ SIGNATURES = {
     "tgn_subtraction_backward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "tgn_aggregation_forward": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "tgn_aggregation_backward": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "tgn_pt_attention_forward": (c_int, [c_int, c_int, c_int, c_int] + [_P] * 16 + [_P]),
+    "tgn_pt_softmax_aggregate_forward": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "tgn_pt_softmax_aggregate_backward": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     # section 3
     "tgn_ball_query_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "tgn_ball_query": (c_int, [c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_int, _P, c_size_t, _P]),

@@ -1,0 +1,270 @@
+"""Host-side mirror of the Point-Transformer building blocks of the reference
+(``models/modules/cbl_point_transformer/blocks.py:14-135``) on top of this package's operators.
+
+Same constructor signatures, sub-module and parameter names as the reference classes, so state_dicts interchange
+(tests/test_host_logic.py checks the key sets against the reference's own classes).  What differs is the forward:
+
+* ``PointTransformerLayer`` (blocks.py:31-44), eval mode without autograd: ONE kernel for everything after the three
+  input projections (``tgn_pt_attention_forward``) -- gather of keys / values / relative coordinates, both small MLPs
+  with their BatchNorms folded, softmax over the neighbours, share_planes-weighted sum.  Training mode keeps the
+  learned layers as torch modules (BatchNorm needs batch statistics) and runs the tail -- softmax + weighted sum -- as
+  the fused, differentiable ``pt_softmax_aggregate`` (forward + backward kernels).  The neighbour search is shared
+  between the two ``queryandgroup`` calls of the reference (pointops' kNN memo).
+* ``TransitionDown`` with stride > 1 (blocks.py:62-74), eval mode: FPS (+coordinates from the kernel) -> kNN -> the fused
+  set-abstraction kernels (per-point transform on the fp32 matrix cores + gather-max): the (m, nsample, 3+c) tensor of
+  the reference is never built.
+* ``TransitionUp`` / ``PointTransformerBlock``: the reference's torch composition over ``pointops.interpolation``.
+
+``PointTransformerUNet`` strings them together the way ``PointTransformerSeg.forward`` does
+(cbl_point_transformer_module.py:93-160) for the forward benchmark of BASELINE.json config 4 (tools/pt_forward_bench.py).
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _lib, pointops
+from ._lib import check, lib, ptr, stream
+
+_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd = torch.amp.custom_bwd(device_type="cuda")
+
+
+class _SoftmaxAggregate(Function):
+    """out[n,ch] = sum_j (x_v[idx[n,j],ch] + p_r[n,j,ch]) * softmax_j(logit)[n,j,ch % g]   (blocks.py:41-43)"""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, x_v, p_r, logit, idx):
+        n, nsample, c = p_r.shape
+        g = logit.shape[2]
+        x_v, p_r, logit = x_v.contiguous(), p_r.contiguous(), logit.contiguous()
+        sm = torch.empty(n, nsample, g, dtype=torch.float32, device=x_v.device)
+        out = torch.empty(n, c, dtype=torch.float32, device=x_v.device)
+        check(lib().tgn_pt_softmax_aggregate_forward(n, nsample, c, g, ptr(x_v), ptr(p_r), ptr(logit), ptr(idx), ptr(sm), ptr(out),
+                                                     stream()), "pt_softmax_aggregate fwd")
+        ctx.save_for_backward(x_v, p_r, sm, idx)
+        return out
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad_out):
+        x_v, p_r, sm, idx = ctx.saved_tensors
+        n, nsample, c = p_r.shape
+        g = sm.shape[2]
+        grad_out = grad_out.contiguous().float()
+        g_xv = torch.zeros_like(x_v)
+        g_pr = torch.empty_like(p_r)
+        g_lg = torch.empty_like(sm)
+        check(lib().tgn_pt_softmax_aggregate_backward(n, nsample, c, g, ptr(x_v), ptr(p_r), ptr(sm), ptr(idx), ptr(grad_out),
+                                                      ptr(g_xv), ptr(g_pr), ptr(g_lg), stream()), "pt_softmax_aggregate bwd")
+        return g_xv, g_pr, g_lg, None
+
+
+def pt_softmax_aggregate(x_v, p_r, logit, idx):
+    """x_v (n_v, c) value rows, p_r (n, nsample, c) position encodings, logit (n, nsample, c // share_planes) attention
+    logits, idx (n, nsample) int32 neighbour rows -> (n, c).  Differentiable w.r.t. x_v, p_r and logit."""
+    _lib.require_cuda(x_v, p_r, logit, idx)
+    return _SoftmaxAggregate.apply(x_v, p_r, logit, idx.to(torch.int32).contiguous())
+
+
+def _bn_scale_shift(bn):
+    s = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).float()
+    return s, (bn.bias.detach() - bn.running_mean * s).float()
+
+
+def fold_pt_layer(layer):
+    """Operands of tgn_pt_attention_forward from a PointTransformerLayer in eval mode (include/tgn_pointops.h)."""
+    lp0, bnp, lp3 = layer.linear_p[0], layer.linear_p[1], layer.linear_p[3]
+    bnw0, lw2, bnw3, lw5 = layer.linear_w[0], layer.linear_w[2], layer.linear_w[3], layer.linear_w[5]
+    sp, tp = _bn_scale_shift(bnp)
+    a1, t1 = _bn_scale_shift(bnw0)
+    s3, t3 = _bn_scale_shift(bnw3)
+    f = lambda t: t.detach().float().contiguous()
+    return dict(Wp1=f(lp0.weight * sp[:, None]), bp1=f(lp0.bias * sp + tp), Wp2=f(lp3.weight), bp2=f(lp3.bias),
+                a1=f(a1), t1=f(t1), Ww1=f(lw2.weight * s3[:, None]), bw1=f(lw2.bias * s3 + t3), Ww2=f(lw5.weight), bw2=f(lw5.bias))
+
+
+def pt_attention(p, x_q, x_k, x_v, idx, params):
+    """The fused eval-mode layer: p (n,3), x_q/x_k/x_v (n,c), idx (n,nsample) int32 -> (n,c)."""
+    n, c = x_q.shape
+    nsample = idx.shape[1]
+    g = params["Ww2"].shape[0]
+    out = torch.empty(n, c, dtype=torch.float32, device=x_q.device)
+    P = params
+    check(lib().tgn_pt_attention_forward(n, nsample, c, g, ptr(p), ptr(x_q), ptr(x_k), ptr(x_v), ptr(idx), ptr(P["Wp1"]),
+                                         ptr(P["bp1"]), ptr(P["Wp2"]), ptr(P["bp2"]), ptr(P["a1"]), ptr(P["t1"]), ptr(P["Ww1"]),
+                                         ptr(P["bw1"]), ptr(P["Ww2"]), ptr(P["bw2"]), ptr(out), stream()), "pt_attention")
+    return out
+
+
+def _frozen(module, *tensors):
+    return (not module.training) and not (torch.is_grad_enabled() and (
+        any(t is not None and t.requires_grad for t in tensors) or any(q.requires_grad for q in module.parameters())))
+
+
+class PointTransformerLayer(nn.Module):
+    def __init__(self, in_planes, out_planes, share_planes=8, nsample=16):
+        super().__init__()
+        self.mid_planes = mid_planes = out_planes // 1
+        self.out_planes = out_planes
+        self.share_planes = share_planes
+        self.nsample = nsample
+        self.linear_q = nn.Linear(in_planes, mid_planes)
+        self.linear_k = nn.Linear(in_planes, mid_planes)
+        self.linear_v = nn.Linear(in_planes, out_planes)
+        self.linear_p = nn.Sequential(nn.Linear(3, 3), nn.BatchNorm1d(3), nn.ReLU(inplace=True), nn.Linear(3, out_planes))
+        self.linear_w = nn.Sequential(nn.BatchNorm1d(mid_planes), nn.ReLU(inplace=True),
+                                      nn.Linear(mid_planes, mid_planes // share_planes),
+                                      nn.BatchNorm1d(mid_planes // share_planes), nn.ReLU(inplace=True),
+                                      nn.Linear(out_planes // share_planes, out_planes // share_planes))
+        self.softmax = nn.Softmax(dim=1)
+
+    def forward(self, pxo):
+        p, x, o = pxo  # (n, 3), (n, c), (b)
+        x_q, x_k, x_v = self.linear_q(x), self.linear_k(x), self.linear_v(x)
+        idx, _ = pointops.knnquery(self.nsample, p, p, o, o)           # one search for both groupings of blocks.py:34-35
+        g = self.out_planes // self.share_planes
+        if (_frozen(self, p, x) and self.nsample <= 64 and self.out_planes % 4 == 0 and g in (4, 8, 16, 32, 64)
+                and x_q.dtype == torch.float32):
+            return pt_attention(p.contiguous(), x_q.contiguous(), x_k.contiguous(), x_v.contiguous(), idx, fold_pt_layer(self))
+        # training: the reference's composition with the softmax + weighted sum as one differentiable kernel pair
+        x_kg = pointops.queryandgroup(self.nsample, p, p, x_k.contiguous(), idx, o, o, use_xyz=True)   # (n, nsample, 3+c)
+        p_r, x_kg = x_kg[:, :, 0:3], x_kg[:, :, 3:]
+        for i, layer in enumerate(self.linear_p):
+            p_r = layer(p_r.transpose(1, 2).contiguous()).transpose(1, 2).contiguous() if i == 1 else layer(p_r)
+        w = x_kg - x_q.unsqueeze(1) + p_r
+        for i, layer in enumerate(self.linear_w):
+            w = layer(w.transpose(1, 2).contiguous()).transpose(1, 2).contiguous() if i % 3 == 0 else layer(w)
+        return pt_softmax_aggregate(x_v.contiguous(), p_r.contiguous(), w.contiguous(), idx)
+
+
+class TransitionDown(nn.Module):
+    def __init__(self, in_planes, out_planes, stride=1, nsample=16):
+        super().__init__()
+        self.stride, self.nsample = stride, nsample
+        if stride != 1:
+            self.linear = nn.Linear(3 + in_planes, out_planes, bias=False)
+            self.pool = nn.MaxPool1d(nsample)
+        else:
+            self.linear = nn.Linear(in_planes, out_planes, bias=False)
+        self.bn = nn.BatchNorm1d(out_planes)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, pxo):
+        p, x, o = pxo  # (n, 3), (n, c), (b)
+        if self.stride == 1:
+            return [p, self.relu(self.bn(self.linear(x))), o]
+        counts = torch.diff(o, prepend=o.new_zeros(1)) // self.stride     # per-cloud sample counts (blocks.py:64-68), no host loop
+        n_o = torch.cumsum(counts, 0).to(torch.int32)
+        idx, n_p = pointops.fps_with_coords(p, o, n_o)                     # blocks.py:69-70: indices and p[idx] from one kernel
+        C1 = self.linear.out_features
+        if _frozen(self, p, x) and self.nsample <= 64 and C1 % 4 == 0 and x.dtype == torch.float32:
+            # the whole down-sampling step fused: (m, nsample, 3+c) is never built (blocks.py:71-73)
+            kidx, _ = pointops.knnquery(self.nsample, p, n_p, o, n_o)
+            s, t = _bn_scale_shift(self.bn)
+            W = self.linear.weight.detach().float()                        # (C1, 3+c), columns [xyz, features] (use_xyz=True)
+            Wt = torch.cat([W[:, 3:], W[:, :3]], 1).mul(s[:, None]).t().contiguous()   # rows [features..., x, y, z]
+            n, c = x.shape
+            m = n_p.shape[0]
+            A = torch.empty(n, C1, dtype=torch.float32, device=x.device)
+            L = lib()
+            check(L.tgn_sa_point_transform(n, c, C1, ptr(p.contiguous()), ptr(x.contiguous()), ptr(Wt), ptr(A), stream()),
+                  "sa_point_transform")
+            out = torch.empty(m, C1, dtype=torch.float32, device=x.device)
+            check(L.tgn_sa_gather_max(1, n, m, self.nsample, C1, ptr(A), ptr(n_p), ptr(Wt[c:].contiguous()), ptr(t.contiguous()),
+                                      ptr(kidx), 0, 1, ptr(out), stream()), "sa_gather_max")
+            return [n_p, out, n_o]
+        x = pointops.queryandgroup(self.nsample, p, n_p, x, None, o, n_o, use_xyz=True)  # (m, nsample, 3+c)
+        x = self.relu(self.bn(self.linear(x).transpose(1, 2).contiguous()))              # (m, c, nsample)
+        x = self.pool(x).squeeze(-1)                                                     # (m, c)
+        return [n_p, x, n_o]
+
+
+class TransitionUp(nn.Module):
+    def __init__(self, in_planes, out_planes=None):
+        super().__init__()
+        if out_planes is None:
+            self.linear1 = nn.Sequential(nn.Linear(2 * in_planes, in_planes), nn.BatchNorm1d(in_planes), nn.ReLU(inplace=True))
+            self.linear2 = nn.Sequential(nn.Linear(in_planes, in_planes), nn.ReLU(inplace=True))
+        else:
+            self.linear1 = nn.Sequential(nn.Linear(out_planes, out_planes), nn.BatchNorm1d(out_planes), nn.ReLU(inplace=True))
+            self.linear2 = nn.Sequential(nn.Linear(in_planes, out_planes), nn.BatchNorm1d(out_planes), nn.ReLU(inplace=True))
+
+    def forward(self, pxo1, pxo2=None):
+        if pxo2 is None:
+            _, x, o = pxo1
+            # x = mlp[x, mlp[mean of the cloud]] (blocks.py:103-116) without the per-cloud host loop
+            seg = torch.repeat_interleave(torch.arange(o.shape[0], device=x.device), torch.diff(o, prepend=o.new_zeros(1)).long())
+            cnt = torch.diff(o, prepend=o.new_zeros(1)).to(x.dtype).unsqueeze(1)
+            mean = torch.zeros(o.shape[0], x.shape[1], dtype=x.dtype, device=x.device).index_add_(0, seg, x) / cnt
+            return self.linear1(torch.cat((x, self.linear2(mean)[seg]), 1))
+        p1, x1, o1 = pxo1
+        p2, x2, o2 = pxo2
+        return self.linear1(x1) + pointops.interpolation(p2, p1, self.linear2(x2).contiguous(), o2, o1)
+
+
+class PointTransformerBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, in_planes, planes, share_planes=8, nsample=16):
+        super().__init__()
+        self.linear1 = nn.Linear(in_planes, planes, bias=False)
+        self.bn1 = nn.BatchNorm1d(planes)
+        self.transformer2 = PointTransformerLayer(planes, planes, share_planes, nsample)
+        self.bn2 = nn.BatchNorm1d(planes)
+        self.linear3 = nn.Linear(planes, planes * self.expansion, bias=False)
+        self.bn3 = nn.BatchNorm1d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, pxo):
+        p, x, o = pxo
+        identity = x
+        x = self.relu(self.bn1(self.linear1(x)))
+        x = self.relu(self.bn2(self.transformer2([p, x, o])))
+        x = self.bn3(self.linear3(x))
+        x = x + identity
+        return [p, self.relu(x), o]
+
+
+class PointTransformerUNet(nn.Module):
+    """Encoder / decoder of PointTransformerSeg (cbl_point_transformer_module.py:44-60, 93-160) with the tgnet_fps stage
+    sizes by default (planes 32..512, blocks [2,3,4,6,3], stride [1,4,4,4,4], nsample [36,24,24,24,24]); input
+    (B, C, N) channel-first like the reference, output the per-point features of dec1, (B*N, planes[0])."""
+
+    def __init__(self, c=6, planes=(32, 64, 128, 256, 512), blocks=(2, 3, 4, 6, 3), stride=(1, 4, 4, 4, 4),
+                 nsample=(36, 24, 24, 24, 24), share_planes=8):
+        super().__init__()
+        self.in_planes = c
+        enc, dec = [], []
+        for i in range(5):
+            layers = [TransitionDown(self.in_planes, planes[i], stride[i], nsample[i])]
+            self.in_planes = planes[i]
+            layers += [PointTransformerBlock(planes[i], planes[i], share_planes, nsample[i]) for _ in range(1, blocks[i])]
+            enc.append(nn.Sequential(*layers))
+        for i in range(4, -1, -1):
+            layers = [TransitionUp(self.in_planes, None if i == 4 else planes[i])]
+            self.in_planes = planes[i]
+            layers += [PointTransformerBlock(planes[i], planes[i], share_planes, nsample[i])]
+            dec.append(nn.Sequential(*layers))
+        self.enc, self.dec = nn.ModuleList(enc), nn.ModuleList(dec)   # dec[0] = dec5 ... dec[4] = dec1
+
+    def forward(self, inputs):
+        B, C, N = inputs.shape
+        pxo = inputs.permute(0, 2, 1)
+        x = pxo.reshape(-1, C).contiguous()
+        p = pxo[:, :, :3].reshape(-1, 3).contiguous()
+        o = torch.arange(1, B + 1, dtype=torch.int32, device=inputs.device) * N
+        stages = []
+        cur = [p, x, o]
+        for e in self.enc:
+            cur = e(cur)
+            stages.append(cur)
+        p5, x5, o5 = stages[4]
+        x5 = self.dec[0][1:]([p5, self.dec[0][0]([p5, x5, o5]), o5])[1]
+        up = [p5, x5, o5]
+        for k, i in enumerate(range(3, -1, -1)):
+            pi, xi, oi = stages[i]
+            d = self.dec[k + 1]
+            xi = d[1:]([pi, d[0]([pi, xi, oi], up), oi])[1]
+            up = [pi, xi, oi]
+        return up[1]
