@@ -297,6 +297,23 @@ int tgn_three_interpolate(int B, int N, int S, int C, const float *points2, cons
  */
 int tgn_take_index_error(tgn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 4. Mesh input of the preprocess path (HOST pointers, CPU code): gen_utils.read_txt_obj_ls (gen_utils.py:207-233).
+ * ---------------------------------------------------------------------------------------- */
+/*
+ * Text-OBJ reader with the reference loop's semantics (gen_utils.py:211-226): only lines whose first token is exactly
+ * "v" or "f" count, reading stops at the first blank line, "a//b" face references are cut at "//", anything int() /
+ * float() would reject is an error.  vertices (cap_v,3) double, faces (cap_f,3) int64, 1-based as in the file.
+ */
+int tgn_obj_count(const char *path, long long *n_vertices, long long *n_faces);
+int tgn_obj_read(const char *path, double *vertices, long long *faces, long long cap_v, long long cap_f,
+                 long long *n_vertices, long long *n_faces);
+/*
+ * Vertex normals as open3d's compute_vertex_normals() (gen_utils.py:228-233): area-weighted sum of the triangle
+ * cross products, normalised, (0,0,1) where undefined.  triangles are ZERO-based.  Parity unpinned (no open3d here).
+ */
+int tgn_vertex_normals(const double *vertices, long long nv, const long long *triangles, long long nf, double *normals);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,120 @@
+"""Preprocess I/O either side of the FPS and the sharded runner (BASELINE.json config 5).
+
+CPU part: the native OBJ reader and vertex normals (libtgn_pointops.so section 4 runs on the host) against what the
+REFERENCE's gen_utils.read_txt_obj_ls parsed from the same synthetic files (tests/golden/make_golden_r2_io.py) and the
+oracle; the runner's control flow on 2 gloo ranks with the oracle's FPS plugged in.
+GPU part (-m gpu): the whole pipeline -- native reader, normals, label remap, scaling, batched GPU FPS, np.save -- must
+write byte-identical .npy files to the ones the reference's preprocess_data.py wrote (sha256 in the golden file)."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+from make_golden_r2_io import SCANS, SMALL, write_dataset  # noqa: E402  (pure python, no reference import at module level)
+
+
+def test_native_obj_reader_matches_the_reference_parser(tmp_path, golden_r2):
+    from oracle import meshio as OM
+    from toothgroupnetwork_amd import preprocess, synth
+    for style, nu, nv, seed in SMALL:
+        path = tmp_path / f"{style}.obj"
+        path.write_text(synth.obj_text(nu, nv, seed, style))
+        v, f = preprocess.read_obj(str(path))
+        assert v.dtype == np.float64 and f.dtype == np.int64
+        assert np.array_equal(v, golden_r2[f"obj_{style}_vertices"])            # what the reference handed to open3d
+        assert np.array_equal(f - 1, golden_r2[f"obj_{style}_triangles"])
+        ov, of = OM.read_obj(str(path))
+        assert np.array_equal(v, ov) and np.array_equal(f, of)
+        vn = preprocess.read_txt_obj_ls(str(path))[0]
+        assert np.array_equal(vn[:, :3], v)
+        assert np.array_equal(vn, golden_r2[f"obj_{style}_vn"])                 # normals: oracle restatement (parity unpinned)
+        assert np.array_equal(vn[:, 3:], OM.vertex_normals(v, f - 1))
+
+
+def test_obj_reader_quirks_and_errors(tmp_path):
+    from toothgroupnetwork_amd import preprocess
+    p = tmp_path / "q.obj"
+    p.write_text("# c\nv 1 2 3 0.5 0.5 0.5\nvn 0 0 1\n  v\t-1e-3  +2.5 .5\r\nf 1//7 2//8 1//9\nf 2 1 2 9\n   \nv 9 9 9\n")
+    v, f = preprocess.read_obj(str(p))
+    assert np.array_equal(v, [[1, 2, 3], [-1e-3, 2.5, 0.5]])                    # extra tokens ignored, blank line ends the file
+    assert np.array_equal(f, [[1, 2, 1], [2, 1, 2]])
+    for bad in ("v 1 2\n", "v 1 2 x\n", "f 1/2/3 4/5/6 7/8/9\n", "f 1 2\n"):     # what float() / int() / the array build reject
+        p.write_text(bad)
+        with pytest.raises(ValueError):
+            preprocess.read_obj(str(p))
+    with pytest.raises(ValueError):
+        preprocess.read_obj(str(tmp_path / "missing.obj"))
+    # a vertex no triangle touches gets open3d's (0,0,1); a triangle index out of range is an error
+    n = preprocess.vertex_normals(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [5, 5, 5]], float), np.array([[0, 1, 2]]))
+    assert np.array_equal(n, [[0, 0, 1]] * 4)
+    with pytest.raises(ValueError):
+        preprocess.vertex_normals(np.zeros((3, 3)), np.array([[0, 1, 3]]))
+    lab = preprocess.remap_fdi_labels([0, 11, 18, 21, 28, 31, 38, 41, 48], "upper").reshape(-1)
+    assert lab.tolist()[:5] == [0, 1, 8, 9, 16]
+    assert preprocess.remap_fdi_labels([0, 31, 38, 41, 48], "lower").reshape(-1).tolist() == [0, 1, 8, 9, 16]
+
+
+def _oracle_fps_batch(xyz_list, npoint):
+    from oracle import cpu as O
+    return [O.furthestsampling(np.ascontiguousarray(x, dtype=np.float32), [x.shape[0]], [npoint]).reshape(-1) for x in xyz_list]
+
+
+def _check_outputs(save, golden_r2):
+    for name, jaw, nu, nv, seed, style in SCANS:
+        raw = open(os.path.join(save, f"{name}_{jaw}_sampled_points.npy"), "rb").read()
+        assert np.array_equal(np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8), golden_r2[f"pre_{name}_sha256"]), name
+
+
+def test_pipeline_with_oracle_fps_writes_the_reference_files(tmp_path, golden_r2):
+    """host logic only (CPU): reader + normals + remap + scaling + save with the ORACLE's FPS plugged in reproduce the
+    files the reference's preprocess_data.py wrote, byte for byte."""
+    from toothgroupnetwork_amd import preprocess
+    write_dataset(str(tmp_path))
+    pairs = preprocess.list_scans(str(tmp_path / "obj"), str(tmp_path / "json"))
+    assert len(pairs) == 2
+    st = preprocess.preprocess_scans(pairs, str(tmp_path / "out"), batch=2, fps_batch=_oracle_fps_batch)
+    assert st["scans"] == 2 and st["sampled"] == 1 and st["points_in"] == 27000 + 9000
+    _check_outputs(str(tmp_path / "out"), golden_r2)
+
+
+def test_sharded_runner_two_ranks_gloo(tmp_path, golden_r2):
+    """tools/preprocess_sharded.py under torch.distributed.run with 2 gloo ranks (oracle FPS: no GPU here): each rank
+    writes its shard, one all_gather combines the counters, the files are the reference's."""
+    write_dataset(str(tmp_path))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", os.path.join(REPO, "tools", "preprocess_sharded.py"), "--source_obj_data_path",
+           str(tmp_path / "obj"), "--source_json_data_path", str(tmp_path / "json"), "--save_data_path", str(tmp_path / "out"),
+           "--fps", "oracle", "--backend", "gloo"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["scans"] == 2 and res["per_rank_scans"] == [1, 1] and res["sampled"] == 1
+    _check_outputs(str(tmp_path / "out"), golden_r2)
+
+
+@pytest.mark.gpu
+def test_gpu_pipeline_writes_the_reference_files(dev, tmp_path, golden_r2, oracle):
+    """the product path end to end on the GPU (batched FPS kernel): byte-identical .npy files; and the label transfer
+    (inference_pipeline_sem.py:37-39) against a brute-force nearest neighbour."""
+    from toothgroupnetwork_amd import preprocess, sharding
+    write_dataset(str(tmp_path))
+    pairs = preprocess.list_scans(str(tmp_path / "obj"), str(tmp_path / "json"))
+    res = preprocess.preprocess_sharded(pairs, str(tmp_path / "out"), 0, 1, batch=4)
+    assert res["scans"] == 2 and res["sampled"] == 1 and res["per_rank_scans"] == [2]
+    _check_outputs(str(tmp_path / "out"), golden_r2)
+    arr = np.load(os.path.join(str(tmp_path / "out"), "SYNTHA_upper_upper_sampled_points.npy"))
+    assert arr.shape == (24000, 7) and np.array_equal(arr[:8], golden_r2["pre_SYNTHA_upper_head"])
+    full, _, _ = preprocess.load_scan(*pairs[0])
+    got = preprocess.transfer_labels(arr[:, :3], arr[:, 6], full[:, :3])
+    sub = np.arange(0, full.shape[0], 37)
+    d = ((full[sub, None, :3].astype(np.float32) - arr[None, :, :3].astype(np.float32)) ** 2).sum(-1)
+    assert np.array_equal(got[sub], arr[d.argmin(1), 6])
+    assert (got == full[:, 6]).mean() > 0.9          # most vertices sit next to a sample of their own tooth

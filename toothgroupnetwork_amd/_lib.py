@@ -81,6 +81,10 @@ SIGNATURES = {
     "tgn_three_interpolate": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P]),
     "tgn_take_index_error": (c_int, [_P]),
     "tgn_square_distance": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P]),
+    # section 4 (host pointers)
+    "tgn_obj_count": (c_int, [ctypes.c_char_p, _P, _P]),
+    "tgn_obj_read": (c_int, [ctypes.c_char_p, _P, _P, ctypes.c_longlong, ctypes.c_longlong, _P, _P]),
+    "tgn_vertex_normals": (c_int, [_P, ctypes.c_longlong, _P, ctypes.c_longlong, _P]),
 }
 
 FPS_FMA = 1

@@ -1,0 +1,182 @@
+"""The data either side of preprocess_data.py's FPS and the sharded preprocess runner of BASELINE.json
+config 5 ("preprocess_data.py over the full set sharded across 8 x MI355X, RCCL gather only").
+
+Reference path per scan (preprocess_data.py:35-58): load the ground-truth json, remap FDI labels (:38-44), parse the
+text OBJ and take open3d's vertex normals (gen_utils.read_txt_obj_ls, gen_utils.py:201-240), centre, scale by the
+fixed Y range (:48-50), append the labels, farthest-point-sample to 24 000 points if the scan has more (:55-56) and
+np.save the (24000, 7) float64 array (:58).  After the model, the inference pipeline transfers the 24 000 predicted
+labels back to every vertex with a 1-nearest-neighbour query (inference_pipeline_sem.py:37-39).
+
+Here: the OBJ reader and the normals are native (libtgn_pointops.so, include/tgn_pointops.h section 4: the reference's
+Python loop is its own "#TODO slow processing speed"), the FPS of a whole shard of scans is ONE launch (one workgroup /
+cooperative group per scan, resample.fps_batch) and the label transfer is the GPU kNN with k = 1.  ``preprocess_sharded``
+splits the scan list over the ranks of a torch.distributed job: nothing is exchanged while working, one all_gather of
+a small fp64 vector at the end.
+"""
+import ctypes
+import json
+import os
+import time
+
+import numpy as np
+
+from . import _lib, sharding
+
+Y_AXIS_MAX = 33.15232091532151       # preprocess_data.py:16-17
+Y_AXIS_MIN = -36.9843781139949
+N_SAMPLED = 24000                    # preprocess_data.py:55
+
+
+def read_obj(path):
+    """(vertices (n,3) float64, faces (m,3) int64, 1-based) of a text OBJ, with the reference loop's semantics
+    (gen_utils.py:211-226): see tgn_obj_read in include/tgn_pointops.h.  Raises ValueError where float() / int() would."""
+    L = _lib.lib()
+    nv, nf = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    bpath = os.fsencode(path)
+    if L.tgn_obj_count(bpath, ctypes.byref(nv), ctypes.byref(nf)):
+        raise ValueError(L.tgn_last_error().decode("utf-8", "replace"))
+    v = np.empty((max(nv.value, 0), 3), dtype=np.float64)
+    f = np.empty((max(nf.value, 0), 3), dtype=np.int64)
+    if L.tgn_obj_read(bpath, v.ctypes.data_as(ctypes.c_void_p), f.ctypes.data_as(ctypes.c_void_p), v.shape[0], f.shape[0],
+                      ctypes.byref(nv), ctypes.byref(nf)):
+        raise ValueError(L.tgn_last_error().decode("utf-8", "replace"))
+    return v, f
+
+
+def vertex_normals(vertices, triangles):
+    """open3d-style vertex normals (gen_utils.py:228-233): vertices (n,3) float64, triangles (m,3) ZERO-based -> (n,3)."""
+    L = _lib.lib()
+    v = np.ascontiguousarray(vertices, dtype=np.float64)
+    t = np.ascontiguousarray(triangles, dtype=np.int64)
+    out = np.empty_like(v)
+    if L.tgn_vertex_normals(v.ctypes.data_as(ctypes.c_void_p), v.shape[0], t.ctypes.data_as(ctypes.c_void_p), t.shape[0],
+                            out.ctypes.data_as(ctypes.c_void_p)):
+        raise ValueError(L.tgn_last_error().decode("utf-8", "replace"))
+    return out
+
+
+def read_txt_obj_ls(path, ret_mesh=False, use_tri_mesh=False):
+    """gen_utils.read_txt_obj_ls (gen_utils.py:201-240): [ (n,6) float64 = vertices + vertex normals ]; with ret_mesh also
+    a dict {"vertices", "triangles" (zero-based), "vertex_normals"} standing in for the open3d mesh object."""
+    if use_tri_mesh:
+        raise NotImplementedError("the trimesh loader of the reference (gen_utils.py:203-206) is not part of this path")
+    v, f = read_obj(path)
+    tri = f - 1
+    norms = vertex_normals(v, tri)
+    out = [np.concatenate([v, norms], axis=1)]
+    if ret_mesh:
+        out.append({"vertices": v, "triangles": tri, "vertex_normals": norms})
+    return out
+
+
+def remap_fdi_labels(labels, jaw):
+    """FDI tooth numbers -> 0..16 (preprocess_data.py:39-44); labels: int array, reshaped to (n,1)."""
+    labels = np.array(labels).reshape(-1, 1)
+    if jaw == "lower":
+        labels -= 20
+    labels[labels // 10 == 1] %= 10
+    labels[labels // 10 == 2] = (labels[labels // 10 == 2] % 10) + 8
+    labels[labels < 0] = 0
+    return labels
+
+
+def normalise_vertices(vertices):
+    """centre, then map the fixed Y range to [-1, 1] on every axis (preprocess_data.py:48-50); in place on a copy."""
+    vertices = np.array(vertices, dtype=np.float64)
+    vertices[:, :3] -= np.mean(vertices[:, :3], axis=0)
+    vertices[:, :3] = ((vertices[:, :3] - Y_AXIS_MIN) / (Y_AXIS_MAX - Y_AXIS_MIN)) * 2 - 1
+    return vertices
+
+
+def sampled_points_name(base_name, jaw):
+    return f"{base_name}_{jaw}_sampled_points"       # np.save appends ".npy" (preprocess_data.py:58)
+
+
+def load_scan(obj_path, json_path):
+    """-> (labeled_vertices (n,7) float64 before sampling, base_name, jaw)   [preprocess_data.py:37-52]"""
+    base_name = os.path.basename(obj_path).split(".")[0]
+    with open(json_path, "r") as st:
+        loaded = json.load(st)
+    labels = remap_fdi_labels(loaded["labels"], loaded["jaw"])
+    vertices = normalise_vertices(read_txt_obj_ls(obj_path)[0])
+    return np.concatenate([vertices, labels], axis=1), str(base_name), loaded["jaw"]
+
+
+def _default_fps_batch(xyz_list, npoint):
+    from . import resample
+    return resample.fps_batch(xyz_list, npoint)
+
+
+def preprocess_scans(pairs, save_path, batch=16, fps_batch=None):
+    """pairs: [(obj_path, json_path)] -> one "<id>_<jaw>_sampled_points.npy" per scan under save_path, exactly the arrays
+    preprocess_data.py writes.  Scans with more than 24 000 vertices are farthest-point-sampled `batch` at a time in one
+    launch.  Returns {"scans", "sampled", "points_in", "checksum", "seconds_load", "seconds_fps"}."""
+    fps_batch = fps_batch or _default_fps_batch
+    os.makedirs(save_path, exist_ok=True)
+    stats = dict(scans=0, sampled=0, points_in=0, checksum=0.0, seconds_load=0.0, seconds_fps=0.0)
+    for s in range(0, len(pairs), max(int(batch), 1)):
+        t0 = time.perf_counter()
+        loaded = [load_scan(o, j) for o, j in pairs[s:s + batch]]
+        t1 = time.perf_counter()
+        stats["points_in"] += sum(int(lv.shape[0]) for lv, _, _ in loaded)
+        big = [i for i, (lv, _, _) in enumerate(loaded) if lv.shape[0] > N_SAMPLED]
+        if big:
+            idx = fps_batch([loaded[i][0][:, :3] for i in big], N_SAMPLED)
+            for i, ix in zip(big, idx):
+                lv, name, jaw = loaded[i]
+                loaded[i] = (lv[np.asarray(ix)[:N_SAMPLED]], name, jaw)        # gen_utils.resample_pcd: pcd[idx[:n]]
+                stats["checksum"] += float(np.asarray(ix, dtype=np.int64).sum())
+        t2 = time.perf_counter()
+        for lv, name, jaw in loaded:
+            np.save(os.path.join(save_path, sampled_points_name(name, jaw)), lv)
+        stats["scans"] += len(loaded)
+        stats["sampled"] += len(big)
+        stats["seconds_load"] += t1 - t0
+        stats["seconds_fps"] += t2 - t1
+    return stats
+
+
+def list_scans(source_obj_data_path, source_json_data_path):
+    """The (obj, json) pairs preprocess_data.py:21-33 walks, sorted so that every rank sees the same order."""
+    from glob import glob
+    objs = []
+    for dir_path in sorted(x[0] for x in os.walk(source_obj_data_path))[1:]:
+        objs += sorted(glob(os.path.join(dir_path, "*.obj")))
+    jmap = {}
+    for dir_path in sorted(x[0] for x in os.walk(source_json_data_path))[1:]:
+        for jp in glob(os.path.join(dir_path, "*.json")):
+            jmap[os.path.basename(jp).split(".")[0]] = jp
+    return [(o, jmap[os.path.basename(o).split(".")[0]]) for o in objs]
+
+
+def preprocess_sharded(pairs, save_path, rank, world, batch=16, fps_batch=None, device=None, mode="round_robin"):
+    """BASELINE.json config 5: rank `rank` of `world` preprocesses its shard of `pairs` (round robin: raw scans differ in
+    size); ONE collective at the end gathers the per-rank counters.  Returns the job totals (identical on every rank):
+    {"scans", "sampled", "points_in", "checksum", "seconds" (max over ranks), "per_rank_scans", "meshes_per_s"}."""
+    mine = [pairs[i] for i in sharding.shard_indices(len(pairs), rank, world, mode)]
+    sharding.barrier()
+    t0 = time.perf_counter()
+    st = preprocess_scans(mine, save_path, batch=batch, fps_batch=fps_batch)
+    dt = time.perf_counter() - t0
+    mat = sharding.gather_metrics([st["scans"], st["sampled"], st["points_in"], st["checksum"], dt, st["seconds_load"],
+                                   st["seconds_fps"]], device=device).cpu().numpy()
+    tot = mat.sum(0)
+    seconds = float(mat[:, 4].max())
+    return {"scans": int(round(tot[0])), "sampled": int(round(tot[1])), "points_in": int(round(tot[2])), "checksum": float(tot[3]),
+            "seconds": seconds, "seconds_load_max": float(mat[:, 5].max()), "seconds_fps_max": float(mat[:, 6].max()),
+            "per_rank_scans": [int(round(v)) for v in mat[:, 0]], "meshes_per_s": float(tot[0] / seconds) if seconds > 0 else 0.0}
+
+
+def transfer_labels(sampled_xyz, sampled_labels, vertices):
+    """Labels of the 24 000 sampled points back onto every vertex: the 1-nearest-neighbour query of
+    inference_pipeline_sem.py:37-39 (sklearn KDTree there) as the GPU kNN with k = 1 -- fp32 distances: the same
+    neighbour wherever the nearest one is unique at fp32 resolution."""
+    import torch
+    from . import pointops
+    dev = torch.device("cuda")
+    s = torch.from_numpy(np.ascontiguousarray(sampled_xyz[:, :3], dtype=np.float32)).to(dev)
+    v = torch.from_numpy(np.ascontiguousarray(vertices[:, :3], dtype=np.float32)).to(dev)
+    o = torch.tensor([s.shape[0]], dtype=torch.int32, device=dev)
+    n_o = torch.tensor([v.shape[0]], dtype=torch.int32, device=dev)
+    idx, _ = pointops.knnquery(1, s, v, o, n_o)
+    return np.asarray(sampled_labels).reshape(-1)[idx.reshape(-1).cpu().numpy()]

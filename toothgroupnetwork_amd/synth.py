@@ -76,3 +76,45 @@ def scan_batch(b, n, kind="arch", seed=0):
             nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
             out[i] = np.concatenate([xyz, nrm], axis=1)
     return out
+
+
+def obj_text(n_u, n_v, seed=0, style="plain", with_tail=True):
+    """Text of a synthetic arch-surface OBJ mesh: n_u * n_v vertices on a bumpy horseshoe in millimetre-like units
+    (what raw 3DTeethSeg scans look like before preprocess_data.py:48-50 scales them), 2*(n_u-1)*(n_v-1) triangles.
+    style "plain": `f a b c`; "slashes": `f a//a b//b c//c` with `vn` lines in between (gen_utils.py:221-223).
+    A comment, a `g` line and `vt`-like lines are interleaved (all skipped by the reference loop); with_tail appends a
+    BLANK line followed by more vertices, which the reference never reads (`if not line: break`, gen_utils.py:216)."""
+    rng = np.random.default_rng(seed)
+    u = np.linspace(0.0, np.pi, n_u)
+    v = np.linspace(-1.0, 1.0, n_v)
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    r = 22.0 + 3.0 * vv
+    x = r * np.cos(uu) + rng.normal(0, 0.02, uu.shape)
+    y = r * np.sin(uu) * 1.3 + rng.normal(0, 0.02, uu.shape)
+    z = 4.0 * np.sin(6 * uu) * np.cos(3 * vv) + 2.0 * vv + rng.normal(0, 0.02, uu.shape)
+    lines = ["# synthetic arch mesh", "g scan"]
+    for i in range(n_u * n_v):
+        lines.append("v %.6f %.6f %.6f" % (x.flat[i], y.flat[i], z.flat[i]))
+        if style == "slashes":
+            lines.append("vn 0.0 0.0 1.0")
+        if i % 97 == 0:
+            lines.append("vt 0.5 0.5")
+    for i in range(n_u - 1):
+        for j in range(n_v - 1):
+            a, b, c, d = i * n_v + j + 1, i * n_v + j + 2, (i + 1) * n_v + j + 1, (i + 1) * n_v + j + 2
+            for tri in ((a, b, c), (b, d, c)):
+                if style == "slashes":
+                    lines.append("f " + " ".join("%d//%d" % (t, t) for t in tri))
+                else:
+                    lines.append("f %d %d %d" % tri)
+    if with_tail:
+        lines += ["", "v 1000.0 1000.0 1000.0", "f 1 2 3"]
+    return "\n".join(lines) + "\n"
+
+
+def fdi_labels(n, jaw, seed=0):
+    """n FDI labels of one jaw (0 = gingiva, 11-18 / 21-28 upper, 31-38 / 41-48 lower) for synthetic ground truth."""
+    rng = np.random.default_rng(seed)
+    base = (10, 20) if jaw == "upper" else (30, 40)
+    teeth = np.array([0] + [b + t for b in base for t in range(1, 9)])
+    return teeth[rng.integers(0, teeth.size, n)].tolist()
