@@ -72,7 +72,10 @@ def cpu_baseline(scans, budget_meshes, shape):
     dt = time.perf_counter() - t0
     return {"value": sample.shape[0] / dt, "unit": "meshes/s", "cores": cores, "kind": "port",
             "sample": f"{sample.shape[0]} scans x {len(shape['npoint'])} levels through oracle/pointops_oracle.c, "
-                      f"{cores} OpenMP threads, {dt:.1f} s"}
+                      f"{cores} OpenMP threads, {dt:.1f} s",
+            "note": "C/OpenMP port of the reference algorithm (oracle/), stronger than the reference's own torch-CPU path "
+                    "(BASELINE.md section 2: ~5.8 s per mesh for level 1 alone on 8 threads); the reference checkout is not "
+                    "present on the bench host, so its code cannot be timed here"}
 
 
 def main():
@@ -89,11 +92,14 @@ def main():
                     "(exact, certificate checked on the device) instead of iterating; reported separately, never the headline")
     ap.add_argument("--shape", default="A", choices=["A", "B"], help="A: the headline configuration (BASELINE.json config 2); "
                     "B: what the reference net instantiates (multi-scale grouping, SURVEY.md 8) -- not the headline")
-    ap.add_argument("--group-impl", type=int, default=0, help="grouping kernel: 0 choose, 1 = 4-B stores, 2 = 16-B stores through LDS")
-    ap.add_argument("--group-policy", type=int, default=-1, help="cache policy of the 16-B grouping stores (0 plain, 2 nt, 16 sc1; -1 default)")
-    ap.add_argument("--group-max-blocks", type=int, default=-1, help="grid bound of the grouping kernel (-1: 512 when pipelined, else none)")
+    ilist = lambda s: [int(v) for v in str(s).split(",")]
+    ap.add_argument("--group-impl", type=ilist, default=[0], help="grouping kernel, one value or one per level: 0 choose, 1 = 4-B stores, "
+                    "2 = 16-B stores through LDS, 3 = LDS-DMA ring, 7 = row pieces into an LDS image")
+    ap.add_argument("--group-policy", type=ilist, default=[-1], help="cache policy of the 16-B grouping stores (0 plain, 2 nt, 16 sc1; -1 default)")
+    ap.add_argument("--group-max-blocks", type=ilist, default=[-1], help="grid bound of the grouping kernel (-1: 512 when pipelined, else none)")
     ap.add_argument("--fused", type=int, default=0, help="1: every level is a fused set-abstraction level (single-layer shared MLP "
                     "[128,512,1024], eval-mode BatchNorm folded): the grouped tensor is never written -- a second, non-headline line")
+    ap.add_argument("--ball-stream", type=int, default=0, help="1: ball queries on a third stream (experiment; slower, DESIGN.md 4.3)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra with_fps_prefix_identity measurement (profiling runs)")
     args = ap.parse_args()
 
@@ -106,8 +112,10 @@ def main():
     B = args.batch
     shape = hotpath.SHAPE_A if args.shape == "A" else hotpath.SHAPE_B
     xyz, feats, scans = make_inputs(B, device, seed=100 + rank, shape=shape)
-    gopts = dict(group_impl=args.group_impl, group_policy=args.group_policy,
-                 group_max_blocks=None if args.group_max_blocks < 0 else args.group_max_blocks, fused=bool(args.fused))
+    one = lambda v: v[0] if len(v) == 1 else v
+    mb = one(args.group_max_blocks)
+    gopts = dict(group_impl=one(args.group_impl), group_policy=one(args.group_policy),
+                 group_max_blocks=None if mb == -1 else mb, fused=bool(args.fused), ball_stream=bool(args.ball_stream))
     if args.fused and args.shape != "A":
         raise SystemExit("--fused is defined for shape A (single-scale levels)")
     hp = hotpath.HotPath(B, device, shape=shape, pipeline=bool(args.pipeline), fps_prefix=bool(args.fps_prefix), **gopts)
@@ -156,7 +164,9 @@ def main():
                    "index_dtype": "int32",
                    "fps_levels_2_3": "identity shortcut (FPS of an FPS result; certificate checked on device)"
                    if args.fps_prefix else "iterated like level 1",
-                   "schedule": "2 HIP streams, steps software-pipelined (FPS of step k+1 over ball query + group of step k)"
+                   "schedule": ("3 HIP streams, steps software-pipelined (FPS chain | ball queries | groupings; the FPS of step k+1 runs "
+                                "over the ball queries and groupings of step k)" if args.ball_stream else
+                                "2 HIP streams, steps software-pipelined (FPS of step k+1 over ball query + group of step k)")
                    if args.pipeline else "1 stream"},
         "path_hbm": {"algorithmic_bytes_per_mesh": bytes_per_mesh,
                      "achieved_GBs": bytes_per_mesh * value / world / 1e9,
@@ -181,11 +191,14 @@ def main():
             out["roofline"]["us_per_fps_iteration"] = 1e3 * avg[dom] / max(S - 1, 1)
         # HBM bytes per launch from the PMC passes committed under profiles/ (tools/gpu_pmc.sh; same workload)
         pmc = {}
-        try:
-            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
-        except Exception:
-            pass
-        if dom in pmc and B == 256 and args.shape == "A":
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(REPO, "profiles", name)))
+                break
+            except Exception:
+                pass
+        pmc_ok = B == 256 and args.shape == "A" and not args.fused
+        if dom in pmc and pmc_ok:
             out["roofline"]["traffic"] = pmc[dom]["fetch"] + pmc[dom]["write"]
         # the HBM-bound kernel of the path, for reference next to the (latency-bound) dominant one
         gk = max((k for k in avg if k.startswith("group")), key=lambda k: avg[k])
@@ -193,7 +206,7 @@ def main():
         galgo = per_level[gl]["group"] * B
         out["roofline_group"] = {"kernel": gk, "bound": "hbm", "achieved": galgo / (avg[gk] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": galgo / (avg[gk] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "traffic": (pmc[gk]["fetch"] + pmc[gk]["write"]) if gk in pmc and B == 256 and args.shape == "A" else None,
+                                 "traffic": (pmc[gk]["fetch"] + pmc[gk]["write"]) if gk in pmc and pmc_ok else None,
                                  "algorithmic_bytes_per_launch": galgo, "avg_launch_ms": avg[gk]}
     if args.fused and rank == 0 and not args.no_kernel_timing:
         # matrix-core side of the fused levels: flops of the per-point transforms / direct contractions per step

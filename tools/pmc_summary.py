@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise the two PMC passes of tools/gpu_pmc.sh into profiles/r01_pmc_traffic.json (read by bench.py for
+"""Summarise the two PMC passes of tools/gpu_pmc.sh into profiles/r02_pmc_traffic.json (read by bench.py for
 roofline.traffic) and copy the raw counter CSVs next to it.
 
     python tools/pmc_summary.py [gpurun_out] [profiles]
@@ -28,7 +28,7 @@ def read(counter):
             continue
         rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"].split("(")[0], float(row["Counter_Value"]) * 1024.0))
     rows.sort()
-    shutil.copy(path, os.path.join(dst, f"r01_pmc_{counter}_counter_collection.csv"))
+    shutil.copy(path, os.path.join(dst, f"r02_pmc_{counter}_counter_collection.csv"))
     return rows
 
 
@@ -37,7 +37,7 @@ def classify(name):
         return "fps"
     if "ball_grid_query" in name or "ball_query_scan" in name:
         return "ball"
-    if "group_points_kernel" in name:
+    if "group_points" in name:
         return "group"
     return None
 
@@ -62,6 +62,6 @@ for name, pk in out["per_kernel"].items():
     pk["dispatches"] = max(len(pk["fetch_bytes_per_dispatch"]), len(pk["write_bytes_per_dispatch"]))
 for k, v in sorted(acc.items()):
     out[k] = {"fetch": sum(v["fetch"]) / max(len(v["fetch"]), 1), "write": sum(v["write"]) / max(len(v["write"]), 1)}
-json.dump(out, open(os.path.join(dst, "r01_pmc_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, "r02_pmc_traffic.json"), "w"), indent=1)
 for k in sorted(acc):
     print(f"{k:10s} fetch {out[k]['fetch'] / 1e6:10.1f} MB  write {out[k]['write'] / 1e6:10.1f} MB per launch")

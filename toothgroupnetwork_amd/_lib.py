@@ -194,7 +194,9 @@ def take_index_error():
 
 
 def raise_on_index_error(what):
-    if INDEX_CHECK != "off" and take_index_error():
+    if INDEX_CHECK == "off" or torch.cuda.is_current_stream_capturing():   # (a host read cannot be captured into a HIP graph)
+        return
+    if take_index_error():
         raise IndexError(f"{what}: index out of range for the gathered dimension "
                          "(the reference's advanced indexing raises here too, pointnet2_utils.py:56-60)")
 

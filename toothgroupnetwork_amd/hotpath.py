@@ -57,13 +57,15 @@ class HotPath:
     ball query / grouping of level l of the same step, and step k-2's consumers before step k's producers."""
 
     def __init__(self, B, device, shape=SHAPE_A, xyz_first=True, index_dtype=torch.int32, pipeline=False,
-                 fps_prefix=False, group_impl=0, group_policy=-1, group_max_blocks=None, fused=False):
+                 fps_prefix=False, group_impl=0, group_policy=-1, group_max_blocks=None, fused=False, ball_stream=False):
         self.B, self.device, self.shape = B, device, shape
         # launch knobs of the grouping kernel (include/tgn_pointops.h, tgn_group_points_ex).  In the two-stream schedule
         # its grid is bounded so that an FPS level-1 workgroup (which needs an almost empty CU) always finds room:
         # 512 blocks = 2 per CU = 2 waves per SIMD, what fits beside 2 x 232 VGPRs of FPS.
-        self.group_impl, self.group_policy = int(group_impl), int(group_policy)
-        self.group_max_blocks = int(group_max_blocks) if group_max_blocks is not None else (512 if pipeline else 0)
+        nl = len(shape["npoint"])
+        per_level = lambda v, d: [int(x) for x in v] if isinstance(v, (list, tuple)) else [int(d if v is None else v)] * nl
+        self.group_impl, self.group_policy = per_level(group_impl, 0), per_level(group_policy, -1)   # scalar or one value per level
+        self.group_max_blocks = per_level(group_max_blocks, 512 if pipeline else 0)
         # fused: every level is a whole set-abstraction level with a single-layer shared MLP (eval-mode BatchNorm folded):
         # FPS -> ball query -> [per-point transform on the fp32 matrix cores + gather-max | direct kernel]; the grouped
         # tensor is never written and level l's (B,S,C_out) output is level l+1's feature input.
@@ -80,9 +82,15 @@ class HotPath:
         self.idx64 = int(index_dtype == torch.int64)
         self.events = None
         self.step_no = 0
+        # ball_stream (experiment, off by default): the ball queries on a stream of their own, so that stream F carries the FPS
+        # chain alone.  Measured in round 2 with the query kernel squeezed to 42 VGPRs (fits beside an FPS level-1 workgroup):
+        # 8.5 ms per step against 7.1-7.5 -- the queries slow down by more than the chain gains
+        self.ball_stream = bool(ball_stream) and pipeline
         if pipeline:
             self.s_fps = torch.cuda.Stream(device=device, priority=-1)
             self.s_rest = torch.cuda.Stream(device=device, priority=0)
+            self.s_ball = torch.cuda.Stream(device=device, priority=-1) if self.ball_stream else None
+            self.ev_ball = [[torch.cuda.Event() for _ in shape["npoint"]] for _ in range(2)]
             self.ev_fps = [[torch.cuda.Event() for _ in shape["npoint"]] for _ in range(2)]
             self.ev_done = [torch.cuda.Event() for _ in range(2)]
             self.ev_start = torch.cuda.Event()
@@ -125,11 +133,11 @@ class HotPath:
         return check(self.L.tgn_ball_query(self.B, lv["N"], lv["S"], br["K"], br["r2"], ptr(cur_xyz), ptr(lv["new_xyz"]),
                                            ptr(br["group_idx"]), self.idx64, ptr(br["ws"]), br["ws_bytes"], st), "ball_query")
 
-    def _group(self, lv, br, cur_xyz, pts, st):
+    def _group(self, lv, br, cur_xyz, pts, st, i=0):
         return check(self.L.tgn_group_points_ex(self.B, lv["N"], lv["S"], br["K"], lv["D"], ptr(cur_xyz), ptr(lv["new_xyz"]),
                                                 ptr(pts), ptr(br["group_idx"]), self.idx64, int(self.xyz_first),
-                                                ptr(br["grouped"]), self.group_impl, self.group_policy,
-                                                self.group_max_blocks, st), "group_points")
+                                                ptr(br["grouped"]), self.group_impl[i], self.group_policy[i],
+                                                self.group_max_blocks[i], st), "group_points")
 
     def _sa(self, lv, br, cur_xyz, pts, st):
         """one fused set-abstraction level on stream st (tgn_sa_direct_max, or tgn_sa_point_transform + tgn_sa_gather_max)"""
@@ -148,7 +156,7 @@ class HotPath:
         if self.fused:
             pts = feats[0] if i == 0 else levels[i - 1]["out"]     # level l consumes level l-1's output features
             return [self._sa(lv, br, cur_xyz, pts, st) for br in lv["branches"]]
-        return [self._group(lv, br, cur_xyz, feats[i], st) for br in lv["branches"]]
+        return [self._group(lv, br, cur_xyz, feats[i], st, i) for br in lv["branches"]]
 
     def enable_kernel_timing(self, steps):
         """HIP events on the launch stream around each kernel class (start/stop per step)."""
@@ -216,19 +224,28 @@ class HotPath:
             sf.wait_event(self.ev_done[p])  # buffer set p is free again once step k-2's consumers are through
         B = self.B
         cur_xyz = xyz
-        # stream F: the latency-bound chain FPS_l -> ball query_l (needs 56 VGPRs: it cannot squeeze in beside an FPS
-        # workgroup, so it stays in line with them); stream G: the groupings (26 VGPRs), which slot in beside the
-        # next step's FPS level 1
+        # stream F: the latency-bound FPS chain (with the ball queries in line when ball_stream is off); stream B: the ball
+        # queries (42 VGPRs); stream G: the groupings (<= 24 VGPRs per wave) -- both slot in beside the next step's
+        # FPS level 1, whose workgroups leave 48 VGPRs per SIMD lane
+        sb = self.s_ball
+        pb = _lib.c_void_p(sb.cuda_stream) if sb is not None else None
+        if sb is not None and (inputs_on_current_stream or self.step_no == 0):
+            sb.wait_event(self.ev_start)
         for i, lv in enumerate(levels):
             N, S, K = lv["N"], lv["S"], lv["K"]
             self._timed(f"fps_l{i + 1}", lambda: self._fps(i, lv, cur_xyz, levels, pf), sf)
-            self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, cur_xyz, pf) for br in lv["branches"]], sf)
+            if sb is None:
+                self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, cur_xyz, pf) for br in lv["branches"]], sf)
             self.ev_fps[p][i].record(sf)
+            if sb is not None:
+                sb.wait_event(self.ev_fps[p][i])
+                self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, cur_xyz, pb) for br in lv["branches"]], sb)
+                self.ev_ball[p][i].record(sb)
             cur_xyz = lv["new_xyz"]
         cur_xyz = xyz
         for i, lv in enumerate(levels):
             N, S, K, D = lv["N"], lv["S"], lv["K"], lv["D"]
-            sg.wait_event(self.ev_fps[p][i])
+            sg.wait_event(self.ev_ball[p][i] if sb is not None else self.ev_fps[p][i])
             self._timed(f"group_l{i + 1}", lambda: self._consume(i, lv, cur_xyz, feats, levels, pg), sg)
             cur_xyz = lv["new_xyz"]
         self.ev_done[p].record(sg)

@@ -107,16 +107,24 @@ def _default_fps_batch(xyz_list, npoint):
     return resample.fps_batch(xyz_list, npoint)
 
 
-def preprocess_scans(pairs, save_path, batch=16, fps_batch=None):
+def preprocess_scans(pairs, save_path, batch=16, fps_batch=None, workers=None):
     """pairs: [(obj_path, json_path)] -> one "<id>_<jaw>_sampled_points.npy" per scan under save_path, exactly the arrays
     preprocess_data.py writes.  Scans with more than 24 000 vertices are farthest-point-sampled `batch` at a time in one
-    launch.  Returns {"scans", "sampled", "points_in", "checksum", "seconds_load", "seconds_fps"}."""
+    launch; the host side of a batch (OBJ parse + normals in the native library, which releases the GIL, json, scaling) runs
+    on `workers` threads (default: min(batch, host cores / ranks on the node)).
+    Returns {"scans", "sampled", "points_in", "checksum", "seconds_load", "seconds_fps"}."""
+    from concurrent.futures import ThreadPoolExecutor
     fps_batch = fps_batch or _default_fps_batch
     os.makedirs(save_path, exist_ok=True)
+    if workers is None:
+        local = max(int(os.environ.get("LOCAL_WORLD_SIZE", "1")), 1)
+        workers = max(1, min(int(batch), (os.cpu_count() or 1) // local))
     stats = dict(scans=0, sampled=0, points_in=0, checksum=0.0, seconds_load=0.0, seconds_fps=0.0)
+    pool = ThreadPoolExecutor(max_workers=workers) if workers > 1 else None
     for s in range(0, len(pairs), max(int(batch), 1)):
         t0 = time.perf_counter()
-        loaded = [load_scan(o, j) for o, j in pairs[s:s + batch]]
+        chunk = pairs[s:s + batch]
+        loaded = list(pool.map(lambda oj: load_scan(*oj), chunk)) if pool else [load_scan(o, j) for o, j in chunk]
         t1 = time.perf_counter()
         stats["points_in"] += sum(int(lv.shape[0]) for lv, _, _ in loaded)
         big = [i for i, (lv, _, _) in enumerate(loaded) if lv.shape[0] > N_SAMPLED]
@@ -133,6 +141,8 @@ def preprocess_scans(pairs, save_path, batch=16, fps_batch=None):
         stats["sampled"] += len(big)
         stats["seconds_load"] += t1 - t0
         stats["seconds_fps"] += t2 - t1
+    if pool:
+        pool.shutdown()
     return stats
 
 
