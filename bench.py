@@ -96,10 +96,14 @@ def main():
     ap.add_argument("--group-impl", type=ilist, default=[0], help="grouping kernel, one value or one per level: 0 choose, 1 = 4-B stores, "
                     "2 = 16-B stores through LDS, 3 = LDS-DMA ring, 7 = row pieces into an LDS image")
     ap.add_argument("--group-policy", type=ilist, default=[-1], help="cache policy of the 16-B grouping stores (0 plain, 2 nt, 16 sc1; -1 default)")
-    ap.add_argument("--group-max-blocks", type=ilist, default=[-1], help="grid bound of the grouping kernel (-1: 512 when pipelined, else none)")
+    ap.add_argument("--group-max-blocks", type=ilist, default=[-1], help="grid bound of the grouping kernel (-1: 256 = one wave per SIMD when pipelined, else none)")
     ap.add_argument("--fused", type=int, default=0, help="1: every level is a fused set-abstraction level (single-layer shared MLP "
                     "[128,512,1024], eval-mode BatchNorm folded): the grouped tensor is never written -- a second, non-headline line")
-    ap.add_argument("--ball-stream", type=int, default=0, help="1: ball queries on a third stream (experiment; slower, DESIGN.md 4.3)")
+    ap.add_argument("--ball-stream", type=int, default=-1, help="-1: default (2 = phased: ball queries on a third stream beside FPS levels "
+                    "2-3, fenced off from the next step's FPS level 1); 0: in line on the FPS stream; 1: third stream, free-running")
+    ap.add_argument("--early-grid", type=int, default=-1, help="phased schedule: build the level-1 ball-query grid ahead of the fence (-1 default on)")
+    ap.add_argument("--group-gate", type=int, default=-1, help="1: groupings of a step wait for its last ball query, i.e. run beside the next "
+                    "step's FPS level 1 (-1: default on when pipelined)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra with_fps_prefix_identity measurement (profiling runs)")
     args = ap.parse_args()
 
@@ -115,7 +119,10 @@ def main():
     one = lambda v: v[0] if len(v) == 1 else v
     mb = one(args.group_max_blocks)
     gopts = dict(group_impl=one(args.group_impl), group_policy=one(args.group_policy),
-                 group_max_blocks=None if mb == -1 else mb, fused=bool(args.fused), ball_stream=bool(args.ball_stream))
+                 group_max_blocks=None if mb == -1 else mb, fused=bool(args.fused),
+                 ball_stream=None if args.ball_stream < 0 else args.ball_stream,
+                 group_gate=None if args.group_gate < 0 else bool(args.group_gate),
+                 early_grid=None if args.early_grid < 0 else bool(args.early_grid))
     if args.fused and args.shape != "A":
         raise SystemExit("--fused is defined for shape A (single-scale levels)")
     hp = hotpath.HotPath(B, device, shape=shape, pipeline=bool(args.pipeline), fps_prefix=bool(args.fps_prefix), **gopts)
@@ -164,10 +171,7 @@ def main():
                    "index_dtype": "int32",
                    "fps_levels_2_3": "identity shortcut (FPS of an FPS result; certificate checked on device)"
                    if args.fps_prefix else "iterated like level 1",
-                   "schedule": ("3 HIP streams, steps software-pipelined (FPS chain | ball queries | groupings; the FPS of step k+1 runs "
-                                "over the ball queries and groupings of step k)" if args.ball_stream else
-                                "2 HIP streams, steps software-pipelined (FPS of step k+1 over ball query + group of step k)")
-                   if args.pipeline else "1 stream"},
+                   "schedule": hp.describe_schedule()},
         "path_hbm": {"algorithmic_bytes_per_mesh": bytes_per_mesh,
                      "achieved_GBs": bytes_per_mesh * value / world / 1e9,
                      "frac_of_peak": bytes_per_mesh * value / world / 1e9 / HBM_PEAK_GBS},

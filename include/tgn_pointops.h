@@ -221,6 +221,15 @@ size_t tgn_ball_query_workspace_bytes(int B, int N, int S);
 int tgn_ball_query(int B, int N, int S, int nsample, float r2, const float *xyz, const float *new_xyz, void *idx,
                    int idx_is_int64, void *workspace, size_t workspace_bytes, tgn_stream_t stream);
 /*
+ * The same in two launches, for planners: _build fills the workspace (per-cloud uniform grid: depends on xyz and r2 only,
+ * not on the queries -- it can run while the sampling that produces new_xyz is still in flight), _prebuilt answers the
+ * queries from a workspace filled by _build with the same (B, N, S, nsample, r2, xyz).  Same results as tgn_ball_query.
+ */
+int tgn_ball_query_build(int B, int N, int S, int nsample, float r2, const float *xyz, void *workspace,
+                         size_t workspace_bytes, tgn_stream_t stream);
+int tgn_ball_query_prebuilt(int B, int N, int S, int nsample, float r2, const float *xyz, const float *new_xyz, void *idx,
+                            int idx_is_int64, void *workspace, size_t workspace_bytes, tgn_stream_t stream);
+/*
  * Grouping of sample_and_group (pointnet2_utils.py:162-169, xyz_first=1: [xyz[idx]-new_xyz, points[idx]])
  * and of PointNetSetAbstractionMsg (pointnet2_utils.py:281-285, xyz_first=0: [points[idx], xyz[idx]-new_xyz]).
  * points (B,N,D) may be NULL (D ignored).  out: (B,S,K,3+D).

@@ -1,8 +1,9 @@
 """CPU: register / scratch budgets the design relies on, read from hipcc's resource-usage remarks (no GPU needed).
 
-bench.py's two-stream schedule only pays off if a wave of the grouping kernel fits beside the FPS level-1 workgroup
-on every SIMD: FPS allocates 2 waves x 232 VGPRs (granule 8) of the 512 per SIMD lane, which leaves 48 = two
-grouping waves of 24 (wide rows) or one of up to 48 (short rows)."""
+bench.py's pipelined schedule only pays off if the grouping kernels fit beside the FPS level-1 workgroup on every CU:
+FPS allocates 2 waves x 232 VGPRs (granule 8) of the 512 per SIMD lane and 63 KiB of the 160 KiB of LDS, which leaves
+one wave of up to 48 VGPRs per SIMD (or two of 24) and ~95 KiB: four single-wave workgroups of the row-piece kernel
+(19 KiB each) or one 256-thread workgroup of the pairs kernel (18 KiB)."""
 import os
 import re
 import shutil
@@ -29,19 +30,27 @@ def _usage(src):
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
 def test_fps_and_group_kernels_can_share_a_cu():
     fps = _usage("fps_bucket.hip")
-    vgpr, scratch, lds = fps["tgn::fps_bucket_kernel<512, 48, 0, false>"]
+    vgpr, scratch, lds = fps["tgn::fps_bucket_kernel<512, 48, 0, false, 4>"]
     assert scratch == 0, "the 24 000-point FPS kernel must not spill"
-    assert vgpr <= 232, f"FPS level-1 kernel uses {vgpr} VGPRs: no room left for two grouping waves (needs <= 232)"
+    assert vgpr <= 232, f"FPS level-1 kernel uses {vgpr} VGPRs: no room left for a grouping wave per SIMD (needs <= 232)"
+    assert lds <= 66 * 1024, f"FPS level-1 kernel holds {lds} B of LDS: the row-piece grouping kernel no longer fits 4 waves beside it"
     g = _usage("group.hip")
-    # levels 2 and 3 (rows of >= 64 floats): TWO waves per SIMD beside the FPS workgroup
+    # levels 2 and 3 (rows of >= 64 floats): the row-piece kernel, ONE wave per SIMD beside the FPS workgroup, 4 per CU
+    # (dynamic LDS: 2 images of 32 + R*C floats + 512 floats of set-up planes, R*C <= 2176 -- group.hip launcher)
+    rows_lds = (2 * (32 + 2176) + 64 * 3 + 64 * 5) * 4
+    for name in ("tgn::group_points_rows_kernel<int, 16, 0>", "tgn::group_points_rows_kernel<long long, 16, 0>"):
+        gv, gs, _ = g[name]
+        assert gs == 0 and gv <= 48, f"{name} uses {gv} VGPRs (> 48: does not fit beside the FPS workgroup)"
+    assert lds + 4 * rows_lds <= 160 * 1024
+    # level 1 (9-float rows): the pairs kernel, one wave per SIMD = one 256-thread workgroup per CU
+    nv, ns, nlds = g["tgn::group_points_pairs_kernel<int, 6, 16>"]
+    assert ns == 0 and nv <= 48, f"pairs grouping kernel uses {nv} VGPRs (> 48: does not fit beside the FPS workgroup)"
+    assert lds + nlds <= 160 * 1024
+    # the LDS-light fallback (shapes the two above do not take): two waves per SIMD
     gv, gs, glds = g["tgn::group_points_v2_kernel<int, 16, true>"]
-    assert gs == 0 and gv <= 24, f"grouping kernel uses {gv} VGPRs (> 24: only one wave fits beside the FPS workgroup)"
-    assert lds + 2 * glds <= 160 * 1024
-    # level 1 (9-float rows): at least ONE wave per SIMD
-    nv, ns, nlds = g["tgn::group_points_v2_kernel<int, 16, false>"]
-    assert ns == 0 and nv <= 48, f"short-row grouping kernel uses {nv} VGPRs (> 48: does not fit beside the FPS workgroup)"
+    assert gs == 0 and gv <= 24, f"v2 grouping kernel uses {gv} VGPRs (> 24: only one wave fits beside the FPS workgroup)"
     for name, (v, s_, _) in g.items():
         assert s_ == 0, f"{name} spills"
     for name, (v, s, _) in fps.items():
-        if name.endswith(", 0, false>") and "56" not in name:
+        if ", 0, false, 4>" in name and "56" not in name:
             assert s == 0, f"{name} spills"

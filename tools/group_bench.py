@@ -25,6 +25,8 @@ variants = ([(1, -1, 0)] + [(2, p, mb) for p in (2, 16) for mb in (0, 1024, 512)
             + [(i, p, mb) for i in (3, 4) for p in (16, 0, 2) for mb in (0, 1024, 512, 256)])
 if len(sys.argv) > 1 and sys.argv[1] == "rows":
     variants = [(7, p, mb) for p in (0, 2) for mb in (0, 1024, 256)] + [(i, 16, mb) for i in (7, 8, 9) for mb in (0, 1024, 256)]
+if len(sys.argv) > 1 and sys.argv[1] == "pairs":   # level 1: the pairs kernel (impl 10) against v1 / v2, per grid bound
+    variants = [(1, -1, 0), (2, 16, 0)] + [(10, p, mb) for p in (16, 0, 2) for mb in (0, 2048, 1024, 512, 256)]
 if len(sys.argv) > 1 and sys.argv[1] == "dbg":
     variants = [(i, 16, mb) for i in (3, 5, 6) for mb in (0, 1024, 512, 256)]
 if len(sys.argv) > 1 and sys.argv[1] == "quick":

@@ -402,27 +402,28 @@ TGN_API size_t tgn_ball_query_workspace_bytes(int B, int N, int S) {
     return (size_t)B * grid_cloud_bytes(N);
 }
 
-TGN_API int tgn_ball_query(int B, int N, int S, int nsample, float r2, const float *xyz, const float *new_xyz,
-                           void *idx, int idx_is_int64, void *workspace, size_t workspace_bytes,
-                           tgn_stream_t stream) {
+static int ball_query_impl(int B, int N, int S, int nsample, float r2, const float *xyz, const float *new_xyz, void *idx,
+                           int idx_is_int64, void *workspace, size_t workspace_bytes, hipStream_t st, bool build, bool query) {
     if (B < 0 || N < 0 || S < 0 || nsample < 0) {
         set_error("tgn_ball_query: negative size");
         return TGN_ERR_INVALID_ARGUMENT;
     }
     const long long total = (long long)B * S;
     if (total == 0 || nsample == 0) return TGN_OK;
-    if (!xyz || !new_xyz || !idx) {
+    if (!xyz || (query && (!new_xyz || !idx))) {
         set_error("tgn_ball_query: null pointer");
         return TGN_ERR_INVALID_ARGUMENT;
     }
-    hipStream_t st = (hipStream_t)stream;
     long long blocks = ((total + 3) / 4 + 7) / 8 * 8;  // a multiple of the 8 XCDs (ball_grid_query_kernel)
     if (blocks > 256 * 64) blocks = 256 * 64;
     const bool grid = use_grid(N, S, nsample) && workspace && workspace_bytes >= (size_t)B * grid_cloud_bytes(N);
     if (grid) {
-        hipLaunchKernelGGL(ball_grid_build_kernel, dim3(B), dim3(kGridThreads), 0, st, N, r2, xyz,
-                           (unsigned char *)workspace);
-        if (int rc = check_launch("ball_grid_build_kernel")) return rc;
+        if (build) {
+            hipLaunchKernelGGL(ball_grid_build_kernel, dim3(B), dim3(kGridThreads), 0, st, N, r2, xyz,
+                               (unsigned char *)workspace);
+            if (int rc = check_launch("ball_grid_build_kernel")) return rc;
+        }
+        if (!query) return TGN_OK;
         if (idx_is_int64)
             hipLaunchKernelGGL((ball_grid_query_kernel<long long>), dim3((unsigned)blocks), dim3(256), 0, st, B, N, S,
                                nsample, r2, xyz, new_xyz, (const unsigned char *)workspace, (long long *)idx);
@@ -431,6 +432,7 @@ TGN_API int tgn_ball_query(int B, int N, int S, int nsample, float r2, const flo
                                r2, xyz, new_xyz, (const unsigned char *)workspace, (int *)idx);
         return check_launch("ball_grid_query_kernel");
     }
+    if (!query) return TGN_OK;
     if (idx_is_int64)
         hipLaunchKernelGGL((ball_query_scan_kernel<long long>), dim3((unsigned)blocks), dim3(256), 0, st, B, N, S,
                            nsample, r2, xyz, new_xyz, (long long *)idx);
@@ -438,4 +440,26 @@ TGN_API int tgn_ball_query(int B, int N, int S, int nsample, float r2, const flo
         hipLaunchKernelGGL((ball_query_scan_kernel<int>), dim3((unsigned)blocks), dim3(256), 0, st, B, N, S, nsample, r2,
                            xyz, new_xyz, (int *)idx);
     return check_launch("ball_query_scan_kernel");
+}
+
+TGN_API int tgn_ball_query(int B, int N, int S, int nsample, float r2, const float *xyz, const float *new_xyz,
+                           void *idx, int idx_is_int64, void *workspace, size_t workspace_bytes,
+                           tgn_stream_t stream) {
+    return ball_query_impl(B, N, S, nsample, r2, xyz, new_xyz, idx, idx_is_int64, workspace, workspace_bytes,
+                           (hipStream_t)stream, true, true);
+}
+
+// The two halves of tgn_ball_query for callers that schedule them apart: the grid depends on the cloud and the radius
+// only, not on the queries, so a planner can build it while the sampling that produces the queries is still running.
+TGN_API int tgn_ball_query_build(int B, int N, int S, int nsample, float r2, const float *xyz, void *workspace,
+                                 size_t workspace_bytes, tgn_stream_t stream) {
+    return ball_query_impl(B, N, S, nsample, r2, xyz, nullptr, nullptr, 0, workspace, workspace_bytes, (hipStream_t)stream,
+                           true, false);
+}
+
+TGN_API int tgn_ball_query_prebuilt(int B, int N, int S, int nsample, float r2, const float *xyz, const float *new_xyz,
+                                    void *idx, int idx_is_int64, void *workspace, size_t workspace_bytes,
+                                    tgn_stream_t stream) {
+    return ball_query_impl(B, N, S, nsample, r2, xyz, new_xyz, idx, idx_is_int64, workspace, workspace_bytes,
+                           (hipStream_t)stream, false, true);
 }

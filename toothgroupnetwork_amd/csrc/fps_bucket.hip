@@ -53,7 +53,7 @@ constexpr int next_pow2(int v) {
     return p;
 }
 
-template <int NT, int P, int MODE, bool DBG = false>
+template <int NT, int P, int MODE, bool DBG = false, int CB = 4>
 __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
     constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0, CERT = (MODE & kFpsModeCert) != 0;
     constexpr int NW = NT / kWave;
@@ -62,15 +62,21 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
     static_assert(CAP <= 32768, "15-bit local indices");
     // Set-up: 32 768 Z-order cells, two 16-bit counters per word (a cloud has < 65 536 points); once the points are
     // placed the same 64 KiB hold the result staging buffer and the bucket arg-max planes.
-    constexpr int kCellWords = 16384;
-    __shared__ unsigned cells[kCellWords];
+    // CB = bits per axis of the Z-order cell code.  4 (default): 4096 cells, 8 KiB of counters; 5: 32 768 cells, 64 KiB.
+    // The order only decides which bucket a point lands in, never a result, and 12 bits are as good as 15 for buckets of
+    // 64 points (24 000 -> 4096: 3.76 vs 3.75 ms per 256 scans) -- but the workgroup then holds 63 KiB of LDS instead of
+    // 116, which is what lets four waves of the row-piece grouping kernel (19 KiB each) run beside it.
+    constexpr int kCellWords = (1 << (3 * CB)) / 2;
+    constexpr int kAliasWords = NT * 4 + 4 * NW * P;
+    constexpr int kLdsWords = kCellWords > kAliasWords ? kCellWords : kAliasWords;
+    __shared__ unsigned cells[kLdsWords];
     __shared__ unsigned short tab[CAP];  // sorted position -> local point index (0xFFFF = padding)
     __shared__ float red[6][NW];
     __shared__ int wave_tot[NW];
     __shared__ float4 rec[2][NW][2];  // per wave: {value, tie key} and {x, y, z} of its candidate
     float4 *outbuf = (float4 *)cells;                                  // [NT]: results of the current chunk of NT iterations
     float (*bmeta)[NW][P] = (float (*)[NW][P])(cells + NT * 4);        // [4][NW][P]: per bucket x, y, z, tie key of its arg-max
-    static_assert((NT * 4 + 4 * NW * P) <= kCellWords, "aliased buffers fit");
+    static_assert(kCellWords % NT == 0, "prefix scan: whole words per thread");
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
         }
         const float ext = h - l;
         glo[c] = l;
-        gscale[c] = (ext > 0.0f && ext < 3.0e38f) ? 32.0f / ext : 0.0f;
+        gscale[c] = (ext > 0.0f && ext < 3.0e38f) ? (float)(1 << CB) / ext : 0.0f;
     }
 
     // ---- 2. counting sort by 15-bit Z-order cell (LDS atomics; the order inside a cell is arbitrary -- it only decides
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float t = (base[(size_t)i * 3 + c] - glo[c]) * gscale[c];
-            t = fminf(fmaxf(t, 0.0f), 31.0f);  // NaN -> 0
+            t = fminf(fmaxf(t, 0.0f), (float)((1 << CB) - 1));  // NaN -> 0
             cc[c] = (unsigned)(int)t;
         }
         return spread5(cc[0]) | (spread5(cc[1]) << 1) | (spread5(cc[2]) << 2);
@@ -736,6 +742,16 @@ static int bucket_launch_mode(int b, int n_max, const FpsArgs &a, hipStream_t st
         best = NT_ * P_;                                       \
         nt = NT_;                                              \
         p = P_;                                                \
+    }
+        TGN_FPS_BUCKET_CONFIGS(X)
+#undef X
+    }
+    if constexpr (MODE == 0) {   // experiments: TGN_FPS_CELL_BITS=5 selects the 15-bit cell codes of round 1 (116 KiB of LDS)
+        static const int cell_bits = getenv("TGN_FPS_CELL_BITS") ? atoi(getenv("TGN_FPS_CELL_BITS")) : 4;
+#define X(NT_, P_)                                                                                              \
+    if (cell_bits == 5 && nt == NT_ && p == P_ && !(a.flags & 0x100)) {                                          \
+        hipLaunchKernelGGL((fps_bucket_kernel<NT_, P_, MODE, false, 5>), dim3(b), dim3(NT_), 0, stream, a);     \
+        return check_launch("fps_bucket_kernel<cb5>");                                                           \
     }
         TGN_FPS_BUCKET_CONFIGS(X)
 #undef X

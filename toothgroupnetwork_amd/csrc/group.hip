@@ -586,6 +586,123 @@ __global__ __launch_bounds__(64) void group_points_rows_kernel(
     }
 }
 
+
+// ---- pairs kernel (narrow rows: level 1, C = 3 + D <= 15) -------------------------------------------------------------
+// The grouped tensor of a batch is ONE flat array of (query, neighbour) pairs, C floats each, in the order of the index
+// tensor.  A lane owns a pair: it loads its index, gathers the point's coordinates and its D features (6 floats = three
+// 8-byte loads), centres the coordinates and drops its finished row into an LDS image of the wave's 64 rows exactly as
+// they lie in memory (row stride C floats, odd for the usual C = 9: conflict-free); the image -- 64*C*4 bytes, whole
+// 128-B lines, line-aligned -- then leaves as 16 B per lane.  ~45 instructions per 2.3 KiB instead of the per-element
+// walk of v2<WIDE = false> (5 four-byte gathers and a multiply-high per lane and KiB).  Two chunks per loop trip, all
+// loads of both issued before either is consumed; chunk = 64 consecutive pairs of one scan (S*K % 64 == 0, K a power of
+// two, so a query never straddles lanes of different chunks in a way that matters: q = pair >> log2(K)).
+// XCD x walks the contiguous chunk range [x*cpx, (x+1)*cpx): whole scans when B is a multiple of 8.
+template <typename IdxT, int D, int POLICY>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void group_points_pairs_kernel(
+    unsigned chunks, unsigned cpx, unsigned cps, int N, int log2K, const float *__restrict__ xyz,
+    const float *__restrict__ new_xyz, const float *__restrict__ points, const IdxT *__restrict__ idx, int xyz_first,
+    float *__restrict__ out, int *__restrict__ err) {
+    constexpr unsigned C = 3u + (unsigned)D;
+    constexpr unsigned IMG = 64u * C;                    // floats per image
+    constexpr unsigned UNITS = IMG / 4u;                 // 16-B units per image
+    constexpr unsigned NST = (UNITS + 63u) / 64u;        // store instructions per image
+    __shared__ __attribute__((aligned(16))) float img[4][2][IMG];
+    const unsigned lane = threadIdx.x & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const unsigned xo = xyz_first ? 0u : (unsigned)D;
+    const unsigned fo = xyz_first ? 3u : 0u;
+    const unsigned x = blockIdx.x & 7u, nwx = (gridDim.x >> 3) * 4u;
+    unsigned c = x * cpx + (blockIdx.x >> 3) * 4u + (unsigned)wv;
+    unsigned c_end = (x + 1u) * cpx;
+    if (c_end > chunks) c_end = chunks;
+    if (c >= c_end) return;
+    struct Chunk {
+        unsigned v;
+        float p[3], q[3], f[D > 0 ? D : 1];
+    };
+    bool bad = false;
+    auto load_index = [&](unsigned cc) -> long long {
+        const __amdgpu_buffer_rsrc_t rs_idx = make_rsrc_uniform(idx + (size_t)cc * 64u, 64u * (unsigned)sizeof(IdxT));
+        if constexpr (sizeof(IdxT) == 8) {
+            const unsigned lo = __builtin_amdgcn_raw_buffer_load_b32(rs_idx, lane * 8u, 0, 0);
+            const unsigned hi = __builtin_amdgcn_raw_buffer_load_b32(rs_idx, lane * 8u + 4u, 0, 0);
+            return (long long)(((unsigned long long)hi << 32) | lo);
+        } else {
+            return (long long)(int)__builtin_amdgcn_raw_buffer_load_b32(rs_idx, lane * 4u, 0, 0);
+        }
+    };
+    auto gather = [&](unsigned cc, unsigned b, Chunk &k) {
+        const __amdgpu_buffer_rsrc_t rs_xyz = make_rsrc_uniform(xyz + (size_t)b * N * 3, (unsigned)N * 12u);
+        // (three dword loads: hipcc 7.2 narrows a raw_buffer_load_b96 whose lanes are used separately to ONE dword)
+#pragma unroll
+        for (unsigned a_ = 0; a_ < 3; ++a_)
+            k.p[a_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_xyz, k.v * 12u + 4u * a_, 0, 0));
+        const unsigned q0 = (unsigned)(((unsigned long long)cc * 64u) >> log2K);   // first query of the chunk
+        const unsigned nq = (64u >> log2K) ? (64u >> log2K) : 1u;
+        const __amdgpu_buffer_rsrc_t rs_q = make_rsrc_uniform(new_xyz + (size_t)q0 * 3, nq * 12u);
+        const unsigned ql = (lane >> log2K) * 12u;
+#pragma unroll
+        for (unsigned a_ = 0; a_ < 3; ++a_)
+            k.q[a_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_q, ql + 4u * a_, 0, 0));
+        if constexpr (D > 0) {
+            const __amdgpu_buffer_rsrc_t rs_pts = make_rsrc_uniform(points + (size_t)b * N * D, (unsigned)N * (unsigned)D * 4u);
+            // (dword loads, merged by the compiler where it is safe: hipcc 7.2 narrows raw_buffer_load_b64 / _b96 whose
+            //  lanes are used separately to ONE dword -- seen in the ISA)
+#pragma unroll
+            for (unsigned i = 0; i < (unsigned)D; ++i)
+                k.f[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_pts, k.v * (unsigned)(D * 4) + 4u * i, 0, 0));
+        }
+    };
+    auto emit = [&](unsigned cc, const Chunk &k, float *im, bool on) {
+        float *row = im + lane * C;
+#pragma unroll
+        for (unsigned a_ = 0; a_ < 3; ++a_) row[xo + a_] = k.p[a_] - k.q[a_];
+#pragma unroll
+        for (unsigned i = 0; i < (unsigned)D; ++i) row[fo + i] = k.f[i];
+        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc_uniform(out + (size_t)cc * IMG, on ? IMG * 4u : 0u);   // off: every store out of range
+#pragma unroll
+        for (unsigned t = 0; t < NST; ++t) {
+            const unsigned u = t * 64u + lane;
+            if (UNITS % 64u == 0u || u < UNITS) {
+                const f32x4 w = *(const f32x4 *)&im[u * 4u];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, w), rs_out,
+                                                       u * 16u, 0, POLICY);
+            }
+        }
+    };
+    // scan of a chunk, tracked incrementally in SGPRs (b = c / cps, r = c % cps): no division in the loop
+    unsigned b1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(c / cps));
+    unsigned r1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(c - b1 * cps));
+#pragma unroll 1
+    for (; c < c_end; c += 2u * nwx) {
+        const bool has2 = c + nwx < c_end;                       // wave-uniform
+        const unsigned c2 = has2 ? c + nwx : c;                   // no second chunk: the first again, its stores disabled
+        unsigned b2 = b1, r2 = r1;
+        if (has2) {
+            r2 += nwx;
+            while (r2 >= cps) {
+                r2 -= cps;
+                ++b2;
+            }
+        }
+        Chunk k1, k2;
+        const long long raw1 = load_index(c), raw2 = load_index(c2);   // both in flight before either is looked at
+        k1.v = checked_index(raw1, N, bad);
+        k2.v = checked_index(raw2, N, bad);
+        gather(c, b1, k1);
+        gather(c2, b2, k2);
+        emit(c, k1, img[wv][0], true);
+        emit(c2, k2, img[wv][1], has2);
+        b1 = b2;
+        r1 = r2 + nwx;
+        while (r1 >= cps) {
+            r1 -= cps;
+            ++b1;
+        }
+    }
+    if (err && __any(bad) && lane == 0) atomicOr(err, 1);
+}
+
 static int env_int(const char *name, int dflt) {
     const char *s = getenv(name);
     return (s && *s) ? atoi(s) : dflt;
@@ -630,12 +747,50 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
     hipStream_t st = (hipStream_t)stream;
     const bool v2_ok = ((long long)K * C) % 4 == 0 && ((uintptr_t)out & 15) == 0 && (long long)N * (D > 0 ? D : 1) < (1LL << 30);
     const bool ring_ok = v2_ok && C >= 64 && K <= 64 && (long long)N * D * 4 >= 256;
-    if ((impl == 5 || impl == 6 || impl >= 8) && !(ring_ok && store_policy == 16)) impl = 3;   // debug variants: default policy only
+    // narrow rows (level 1): one lane per (query, neighbour) pair, rows assembled in an LDS image (impl 10)
+    {
+        const long long pairs_per_scan = (long long)S * K;
+        const bool pairs_ok = (D == 0 || D == 3 || D == 6) && (K & (K - 1)) == 0 && pairs_per_scan % 64 == 0 &&
+                              ((uintptr_t)out & 15) == 0 && (long long)B * pairs_per_scan / 64 < (1LL << 31) &&
+                              (long long)N * (D > 3 ? D : 3) * 4 < (1LL << 31);
+        if (impl == 10 && !pairs_ok) impl = 0;
+        if (impl == 0 && pairs_ok && C < 64) impl = 10;
+        if (impl == 10) {
+            const unsigned cps = (unsigned)(pairs_per_scan / 64), chunks = (unsigned)B * cps;
+            const unsigned cpx = B % 8 == 0 ? (unsigned)(B / 8) * cps : (chunks + 7u) / 8u;
+            int log2K = 0;
+            while ((1 << log2K) < K) ++log2K;
+            long long blocks = ((long long)cpx + 7) / 8;          // a wave walks at least two chunks
+            if (blocks > 256) blocks = 256;                        // per XCD: 32 CUs x 8 blocks
+            if (max_blocks > 0 && max_blocks / 8 < blocks) blocks = max_blocks / 8 > 0 ? max_blocks / 8 : 1;
+            const dim3 grid((unsigned)blocks * 8u);
+#define TGN_GROUP_PAIRS(IT, DD)                                                                                        \
+    do {                                                                                                               \
+        if (store_policy == 0)                                                                                         \
+            hipLaunchKernelGGL((group_points_pairs_kernel<IT, DD, 0>), grid, dim3(256), 0, st, chunks, cpx, cps, N, log2K, xyz, \
+                               new_xyz, pts, (const IT *)idx, xyz_first, out, err);                                    \
+        else if (store_policy == 2)                                                                                    \
+            hipLaunchKernelGGL((group_points_pairs_kernel<IT, DD, 2>), grid, dim3(256), 0, st, chunks, cpx, cps, N, log2K, xyz, \
+                               new_xyz, pts, (const IT *)idx, xyz_first, out, err);                                    \
+        else                                                                                                           \
+            hipLaunchKernelGGL((group_points_pairs_kernel<IT, DD, 16>), grid, dim3(256), 0, st, chunks, cpx, cps, N, log2K, xyz, \
+                               new_xyz, pts, (const IT *)idx, xyz_first, out, err);                                    \
+    } while (0)
+            if (idx_is_int64) {
+                if (D == 0) TGN_GROUP_PAIRS(long long, 0); else if (D == 3) TGN_GROUP_PAIRS(long long, 3); else TGN_GROUP_PAIRS(long long, 6);
+            } else {
+                if (D == 0) TGN_GROUP_PAIRS(int, 0); else if (D == 3) TGN_GROUP_PAIRS(int, 3); else TGN_GROUP_PAIRS(int, 6);
+            }
+#undef TGN_GROUP_PAIRS
+            return check_launch("group_points_pairs_kernel");
+        }
+    }
+    if ((impl == 5 || impl == 6 || impl == 8 || impl == 9) && !(ring_ok && store_policy == 16)) impl = 3;   // debug variants: default policy only
     if (impl >= 3 && !ring_ok) impl = 2;
     if (impl == 2 && !v2_ok) impl = 1;
-    // default: the row-piece kernel when the caller leaves the grid alone; a bounded grid means "runs beside something
-    // that owns most of every CU" (the FPS level-1 workgroups): there the LDS-light v2 kernel is the one that fits
-    if (impl == 0) impl = (ring_ok && K % 4 == 0 && queries < (1LL << 31) && max_blocks <= 0) ? 7 : v2_ok ? 2 : 1;
+    // default: the row-piece kernel for wide rows (a bounded grid means "runs beside something that owns most of every
+    // CU" -- the FPS level-1 workgroups, which leave one <= 48-VGPR wave per SIMD and ~95 KiB of LDS: 4 of its waves fit)
+    if (impl == 0) impl = (ring_ok && K % 4 == 0 && queries < (1LL << 31)) ? 7 : v2_ok ? 2 : 1;
     if (impl == 1) {
         long long blocks = ((queries + 3) / 4 + 7) / 8 * 8;  // one query per wave, grid a multiple of the 8 XCDs
         if (blocks > (1LL << 30)) blocks = 1LL << 30;

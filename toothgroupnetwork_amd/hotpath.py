@@ -50,22 +50,32 @@ def algorithmic_bytes(n, npoint, nsample, d, fused=False, radius=None, c_out=Non
 class HotPath:
     """Pre-planned FPS -> ball query -> group over `levels` for a fixed batch of B scans.
 
-    pipeline=True software-pipelines consecutive steps over two HIP streams: the FPS chain of step k+1 (latency
-    bound: one workgroup per CU, nearly all registers, almost no issue slots or bandwidth) runs on a high-priority
-    stream while the ball queries and groupings of step k (HBM / VALU bound, 26-56 VGPRs) run on a second stream and
-    fill the CUs around it (in fused mode the set-abstraction kernels take the groupings' place).  Buffers are double-buffered by step parity; HIP events order FPS level l before the
-    ball query / grouping of level l of the same step, and step k-2's consumers before step k's producers."""
+    pipeline=True software-pipelines consecutive steps over three HIP streams in two phases per step:
+
+      phase 1   stream F: FPS level 1 of step k (latency bound: one workgroup per CU, 2 x 232 of a SIMD's 512 VGPRs, 63 KiB
+                of LDS, almost no issue slots or bandwidth)  ||  stream G: the groupings of step k-1 (HBM bound) in what the
+                FPS workgroups leave free -- one wave of <= 48 VGPRs per SIMD and ~95 KiB of LDS per CU, which is what the
+                row-piece / pairs grouping kernels are built for (4 waves per CU each);
+      phase 2   stream F: FPS levels 2, 3 (small workgroups, VALU bound)  ||  stream H: the three ball queries (VALU bound,
+                57 VGPRs: they cannot run beside an FPS level-1 workgroup, so stream F does not start the next step's level 1
+                before the last query is through) -- and, on F behind FPS level 3, the level-1 ball-query grid of step k+1.
+
+    Buffers are double-buffered by step parity; HIP events order FPS level l before the ball query of level l, the last ball
+    query of a step before its groupings (group_gate) and before the next step's FPS level 1 (ball_stream = 2), and step
+    k-2's groupings before step k's producers.  ball_stream = 0 / group_gate = False give the round-1 two-stream schedule
+    (ball queries in line on stream F, groupings released level by level)."""
 
     def __init__(self, B, device, shape=SHAPE_A, xyz_first=True, index_dtype=torch.int32, pipeline=False,
-                 fps_prefix=False, group_impl=0, group_policy=-1, group_max_blocks=None, fused=False, ball_stream=False):
+                 fps_prefix=False, group_impl=0, group_policy=-1, group_max_blocks=None, fused=False, ball_stream=None,
+                 group_gate=None, early_grid=None):
         self.B, self.device, self.shape = B, device, shape
-        # launch knobs of the grouping kernel (include/tgn_pointops.h, tgn_group_points_ex).  In the two-stream schedule
-        # its grid is bounded so that an FPS level-1 workgroup (which needs an almost empty CU) always finds room:
-        # 512 blocks = 2 per CU = 2 waves per SIMD, what fits beside 2 x 232 VGPRs of FPS.
+        # launch knobs of the grouping kernel (include/tgn_pointops.h, tgn_group_points_ex).  In the pipelined schedule its
+        # grid is bounded to what fits beside the FPS level-1 workgroups, so that those never wait for a CU to drain:
+        # 256 "blocks" = one wave per SIMD (4 single-wave workgroups of the row-piece kernel per CU).
         nl = len(shape["npoint"])
         per_level = lambda v, d: [int(x) for x in v] if isinstance(v, (list, tuple)) else [int(d if v is None else v)] * nl
         self.group_impl, self.group_policy = per_level(group_impl, 0), per_level(group_policy, -1)   # scalar or one value per level
-        self.group_max_blocks = per_level(group_max_blocks, 512 if pipeline else 0)
+        self.group_max_blocks = per_level(group_max_blocks, 256 if pipeline else 0)
         # fused: every level is a whole set-abstraction level with a single-layer shared MLP (eval-mode BatchNorm folded):
         # FPS -> ball query -> [per-point transform on the fp32 matrix cores + gather-max | direct kernel]; the grouped
         # tensor is never written and level l's (B,S,C_out) output is level l+1's feature input.
@@ -82,18 +92,33 @@ class HotPath:
         self.idx64 = int(index_dtype == torch.int64)
         self.events = None
         self.step_no = 0
-        # ball_stream (experiment, off by default): the ball queries on a stream of their own, so that stream F carries the FPS
-        # chain alone.  Measured in round 2 with the query kernel squeezed to 42 VGPRs (fits beside an FPS level-1 workgroup):
-        # 8.5 ms per step against 7.1-7.5 -- the queries slow down by more than the chain gains
-        self.ball_stream = bool(ball_stream) and pipeline
+        # schedule knobs (defaults = the phased schedule above; the fused mode keeps the two-stream one: its
+        # set-abstraction kernels are matrix-core bound and do not fit the leftovers of an FPS workgroup)
+        dflt = pipeline and not self.fused
+        self.ball_stream = (2 if dflt else 0) if ball_stream is None else (int(ball_stream) if pipeline else 0)
+        self.group_gate = dflt if group_gate is None else (bool(group_gate) and pipeline)
+        self.early_grid = (self.ball_stream == 2) if early_grid is None else (bool(early_grid) and self.ball_stream == 2)
         if pipeline:
             self.s_fps = torch.cuda.Stream(device=device, priority=-1)
             self.s_rest = torch.cuda.Stream(device=device, priority=0)
             self.s_ball = torch.cuda.Stream(device=device, priority=-1) if self.ball_stream else None
             self.ev_ball = [[torch.cuda.Event() for _ in shape["npoint"]] for _ in range(2)]
             self.ev_fps = [[torch.cuda.Event() for _ in shape["npoint"]] for _ in range(2)]
+            self.ev_grid = [torch.cuda.Event() for _ in range(2)]
             self.ev_done = [torch.cuda.Event() for _ in range(2)]
             self.ev_start = torch.cuda.Event()
+
+    def describe_schedule(self):
+        if not self.pipeline:
+            return "1 stream"
+        if self.ball_stream == 2:
+            return ("3 HIP streams, 2 phases per step: FPS level 1 of step k beside the groupings of step k-1" +
+                    ("" if self.group_gate else " (released level by level)") +
+                    ", then FPS levels 2-3 beside the three ball queries" +
+                    (" and the next step's level-1 ball-query grid" if self.early_grid else ""))
+        if self.ball_stream == 1:
+            return "3 HIP streams, free-running (FPS chain | ball queries | groupings)"
+        return "2 HIP streams, steps software-pipelined (FPS of step k+1 over ball query + group of step k)"
 
     def _alloc(self, B, device, shape, index_dtype):
         levels = []
@@ -129,9 +154,14 @@ class HotPath:
             N = S
         return levels
 
-    def _ball(self, lv, br, cur_xyz, st):
-        return check(self.L.tgn_ball_query(self.B, lv["N"], lv["S"], br["K"], br["r2"], ptr(cur_xyz), ptr(lv["new_xyz"]),
-                                           ptr(br["group_idx"]), self.idx64, ptr(br["ws"]), br["ws_bytes"], st), "ball_query")
+    def _ball(self, lv, br, cur_xyz, st, prebuilt=False):
+        fn = self.L.tgn_ball_query_prebuilt if prebuilt else self.L.tgn_ball_query
+        return check(fn(self.B, lv["N"], lv["S"], br["K"], br["r2"], ptr(cur_xyz), ptr(lv["new_xyz"]),
+                        ptr(br["group_idx"]), self.idx64, ptr(br["ws"]), br["ws_bytes"], st), "ball_query")
+
+    def _ball_build(self, lv, br, cur_xyz, st):
+        return check(self.L.tgn_ball_query_build(self.B, lv["N"], lv["S"], br["K"], br["r2"], ptr(cur_xyz), ptr(br["ws"]),
+                                                 br["ws_bytes"], st), "ball_query_build")
 
     def _group(self, lv, br, cur_xyz, pts, st, i=0):
         return check(self.L.tgn_group_points_ex(self.B, lv["N"], lv["S"], br["K"], lv["D"], ptr(cur_xyz), ptr(lv["new_xyz"]),
@@ -210,42 +240,49 @@ class HotPath:
                                                          _lib.FPS_LOCAL_INDEX, st), "fps")
 
     def _run_pipelined(self, xyz, feats, inputs_on_current_stream=True):
-        L = self.L
         p = self.step_no & 1
         levels = self.sets[p]
-        sf, sg = self.s_fps, self.s_rest
+        sf, sg, sb = self.s_fps, self.s_rest, self.s_ball
         pf, pg = _lib.c_void_p(sf.cuda_stream), _lib.c_void_p(sg.cuda_stream)
+        pb = _lib.c_void_p(sb.cuda_stream) if sb is not None else None
         cur = torch.cuda.current_stream()
         if inputs_on_current_stream or self.step_no == 0:
             self.ev_start.record(cur)      # inputs produced on the caller's stream
-            sf.wait_event(self.ev_start)
-            sg.wait_event(self.ev_start)
+            for s_ in (sf, sg, sb):
+                if s_ is not None:
+                    s_.wait_event(self.ev_start)
         if self.step_no >= 2:
             sf.wait_event(self.ev_done[p])  # buffer set p is free again once step k-2's consumers are through
-        B = self.B
+        if self.early_grid:
+            # the level-1 grid depends on the input cloud only: it goes onto stream F BEFORE the fence below, i.e. behind
+            # the previous step's FPS level 3, where stream F would otherwise idle until that step's ball queries are done
+            for br in levels[0]["branches"]:
+                self._ball_build(levels[0], br, xyz, pf)
+            self.ev_grid[p].record(sf)
+        if self.ball_stream == 2 and self.step_no >= 1:
+            sf.wait_event(self.ev_ball[1 - p][-1])   # phased: the previous step's ball queries are through
         cur_xyz = xyz
-        # stream F: the latency-bound FPS chain (with the ball queries in line when ball_stream is off); stream B: the ball
-        # queries (42 VGPRs); stream G: the groupings (<= 24 VGPRs per wave) -- both slot in beside the next step's
-        # FPS level 1, whose workgroups leave 48 VGPRs per SIMD lane
-        sb = self.s_ball
-        pb = _lib.c_void_p(sb.cuda_stream) if sb is not None else None
-        if sb is not None and (inputs_on_current_stream or self.step_no == 0):
-            sb.wait_event(self.ev_start)
         for i, lv in enumerate(levels):
-            N, S, K = lv["N"], lv["S"], lv["K"]
             self._timed(f"fps_l{i + 1}", lambda: self._fps(i, lv, cur_xyz, levels, pf), sf)
             if sb is None:
                 self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, cur_xyz, pf) for br in lv["branches"]], sf)
             self.ev_fps[p][i].record(sf)
             if sb is not None:
                 sb.wait_event(self.ev_fps[p][i])
-                self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, cur_xyz, pb) for br in lv["branches"]], sb)
+                pre = self.early_grid and i == 0
+                if pre:
+                    sb.wait_event(self.ev_grid[p])
+                self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, cur_xyz, pb, prebuilt=pre) for br in lv["branches"]], sb)
                 self.ev_ball[p][i].record(sb)
             cur_xyz = lv["new_xyz"]
         cur_xyz = xyz
+        ev_q = self.ev_ball if sb is not None else self.ev_fps    # "the queries of level i are done"
         for i, lv in enumerate(levels):
-            N, S, K, D = lv["N"], lv["S"], lv["K"], lv["D"]
-            sg.wait_event(self.ev_ball[p][i] if sb is not None else self.ev_fps[p][i])
+            if self.group_gate:
+                if i == 0:
+                    sg.wait_event(ev_q[p][-1])   # all of this step's groupings run beside the NEXT step's FPS level 1
+            else:
+                sg.wait_event(ev_q[p][i])
             self._timed(f"group_l{i + 1}", lambda: self._consume(i, lv, cur_xyz, feats, levels, pg), sg)
             cur_xyz = lv["new_xyz"]
         self.ev_done[p].record(sg)
