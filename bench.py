@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="scans per step per GPU (one FPS workgroup per scan)")
     ap.add_argument("--cpu-meshes", type=int, default=-1, help="CPU-baseline sample size (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--timing-stride", type=int, default=4, help="per-kernel HIP events on every n-th timed step (each event is a barrier "
+                    "packet in its queue: on every step they cost the pipelined schedule ~5 %%)")
     ap.add_argument("--pipeline", type=int, default=1, help="1: overlap the FPS chain of step k+1 with ball query / "
                     "grouping of step k on two HIP streams (double-buffered); 0: one stream")
     ap.add_argument("--fps-prefix", type=int, default=0, help="1: levels 2 and 3 use the FPS-of-an-FPS-result identity "
@@ -101,6 +103,7 @@ def main():
                     "[128,512,1024], eval-mode BatchNorm folded): the grouped tensor is never written -- a second, non-headline line")
     ap.add_argument("--ball-stream", type=int, default=-1, help="-1: default (2 = phased: ball queries on a third stream beside FPS levels "
                     "2-3, fenced off from the next step's FPS level 1); 0: in line on the FPS stream; 1: third stream, free-running")
+    ap.add_argument("--ball-split", type=int, default=1, help="phased schedule: ball queries of levels 2-3 on a stream of their own")
     ap.add_argument("--early-grid", type=int, default=-1, help="phased schedule: build the level-1 ball-query grid ahead of the fence (-1 default on)")
     ap.add_argument("--group-gate", type=int, default=-1, help="1: groupings of a step wait for its last ball query, i.e. run beside the next "
                     "step's FPS level 1 (-1: default on when pipelined)")
@@ -122,7 +125,7 @@ def main():
                  group_max_blocks=None if mb == -1 else mb, fused=bool(args.fused),
                  ball_stream=None if args.ball_stream < 0 else args.ball_stream,
                  group_gate=None if args.group_gate < 0 else bool(args.group_gate),
-                 early_grid=None if args.early_grid < 0 else bool(args.early_grid))
+                 early_grid=None if args.early_grid < 0 else bool(args.early_grid), ball_split=bool(args.ball_split))
     if args.fused and args.shape != "A":
         raise SystemExit("--fused is defined for shape A (single-scale levels)")
     hp = hotpath.HotPath(B, device, shape=shape, pipeline=bool(args.pipeline), fps_prefix=bool(args.fps_prefix), **gopts)
@@ -130,7 +133,7 @@ def main():
         hp.run(xyz, feats, inputs_on_current_stream=False)   # the synthetic scans are resident before any step
     torch.cuda.synchronize()
     if not args.no_kernel_timing:
-        hp.enable_kernel_timing(args.steps)
+        hp.enable_kernel_timing(args.steps, stride=max(args.timing_stride, 1))
 
     sharding.barrier()
     torch.cuda.synchronize()

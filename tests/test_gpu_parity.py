@@ -266,6 +266,18 @@ def test_ball_query_edge_cases(dev, oracle):
     assert np.array_equal(U.query_ball_point(0.1, 3, T(one, dev), T(one, dev)).cpu().numpy(), np.zeros((1, 1, 3), np.int64))
 
 
+def test_ball_query_dense_balls_and_large_clouds(dev, oracle):
+    """The bitmap-selection kernel: more hits than its hit list holds (256: the two-pass path), more than 64 hits (two
+    rounds of ranking), the largest cloud it takes (32 768 points) and the first one it does not (rank-select kernel)."""
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    for n, radius, ns in [(16384, 0.2, 32), (16384, 0.2, 64), (16384, 0.12, 128), (32768, 0.06, 32), (32769, 0.06, 32)]:
+        xyz = synth.uniform_cloud(n, 7)[None] * 0.5 + 0.5    # unit cube: ~n * 4.19 r^3 hits per query (550 at r = 0.2)
+        q = xyz[:, ::97][:, :160]
+        got = U.query_ball_point(radius, ns, T(xyz, dev), T(q, dev)).cpu().numpy()
+        want = oracle.query_ball_point(radius, ns, xyz, q)
+        assert np.array_equal(got, want), (n, radius, ns)
+
+
 # ------------------------------------------------------------------- grouping / index_points / SA
 def test_sample_and_group_matches_golden(dev, golden):
     from toothgroupnetwork_amd import pointnet2_utils as U

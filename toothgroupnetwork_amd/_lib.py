@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libtgn_pointops.so")
+LIB_PATH = os.environ.get("TGN_LIB_PATH") or os.path.join(_HERE, "csrc", "libtgn_pointops.so")   # TGN_LIB_PATH: A/B builds (tools/)
 
 _lib = None
 

@@ -26,6 +26,8 @@
 // coordinates (NaN compares as "inside" in the reference) take the scan path.
 #include "tgn_common.h"
 
+#include <stdlib.h>
+
 namespace tgn {
 
 // ------------------------------------------------------------------------------------------------
@@ -388,6 +390,246 @@ __global__ __launch_bounds__(256) void ball_grid_query_kernel(int B, int N, int 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// grid path, bitmap selection (clouds of up to 32 768 points: every Shape-A / Shape-B level)
+// ------------------------------------------------------------------------------------------------
+// The answer of a query is "the nsample smallest indices among its hits, ascending".  ball_grid_query_kernel gets there by
+// rank-selecting the hit list (every lane compares its hit with every other one: ~3 instructions per hit and lane-slot,
+// a third of the kernel).  Here the hits are ALSO dropped into a bitmap over the cloud's index range (one LDS `or` per
+// candidate step); the rank of a hit is then the number of set bits below it:
+//   * lane l owns the words of indices [l*W*32, (l+1)*W*32), W = 4*nquad: it counts its bits (one v_bcnt per word), a wave
+//     scan over the lane totals gives every 128-index group its base rank (gbase);
+//   * the lane that holds hit v reads gbase[v >> 7] and the group's four words and counts the bits below v: ~20
+//     instructions whatever the number of hits; ranks < nsample are stored, rank 0 is the pad value (pointnet2_utils.py:138-141);
+//   * the owners wipe their words (three 16-byte LDS stores per lane at N = 24 000).
+// Candidates are walked one x-run per 16-lane row (a run holds ~15 records on a scan surface) instead of as one flattened
+// list: the run a lane serves is a constant of the step, so there is no per-lane search for "which run does candidate g
+// belong to" (16 of the ~60 instructions of a step before).  More hits than the list holds (kBmHitCap) are handled by
+// walking the candidates a second time and ranking each hit straight from the bitmap.
+// Same cells, same test, same arithmetic as above: the results are identical.
+constexpr int kBmMaxN = 32768;
+constexpr int kBmHitCap = 256;
+
+// Latency: a query is a chain of dependent round trips (query -> cell table -> records -> LDS -> stores) and the kernel
+// is bound by them, not by its instruction count.  So the first 32 records of every run are requested at once (six 16-byte
+// loads per lane in flight; runs longer than that take a tail loop), and the cell-table look-ups of the wave's NEXT
+// query are issued before the current one is processed, so that they have landed when its turn comes.
+struct BallRuns {      // what a query needs to start: lanes 0..8 hold the record range of one x-run each
+    float cx, cy, cz;  // wave-uniform
+    int rs, re;
+    int b;             // scan (cloud) of the query
+    bool scan;         // wave-uniform: the cloud has no grid / the query is not finite -> index-order scan
+};
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int N, int S, int K, float r2,
+                                                                      const float *__restrict__ xyz,
+                                                                      const float *__restrict__ new_xyz,
+                                                                      const unsigned char *__restrict__ ws,
+                                                                      IdxT *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned bm_dyn[];   // per wave: bitmap [nquad*256], gbase [nquad*64], hits [kBmHitCap]
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int nquad = (N + 8191) >> 13;   // 16-byte quads (128 indices) per lane: lane l owns quads [l*nquad, (l+1)*nquad)
+    const int per_wave = nquad * 256 + nquad * 64 + kBmHitCap;
+    unsigned *bm = bm_dyn + wv * per_wave;
+    unsigned *gbase = bm + nquad * 256;
+    int *hits = (int *)(gbase + nquad * 64);
+    for (int t = 0; t < nquad; ++t) *(u32x4 *)&bm[(lane * nquad + t) * 4] = u32x4{0u, 0u, 0u, 0u};
+    const long long total = (long long)B * S;
+    const size_t cloud_bytes = grid_cloud_bytes(N);
+    const size_t rec_off = sizeof(GridHeader) + (size_t)((kGridCells + 1 + 3) / 4 * 4) * sizeof(int);
+    const int row = lane >> 4, col = lane & 15;
+    const int dy = lane % 3 - 1, dz = lane / 3 - 1;   // lanes 0..8: the (dy, dz) x-run this lane looks up
+    const unsigned nb = gridDim.x;   // XCD-aware block order, see ball_grid_query_kernel
+    const unsigned lb = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
+    const long long stride = (long long)nb * 4;
+
+    auto lookup = [&](long long q) -> BallRuns {   // issues the two cell-table loads of query q (lanes 0..8)
+        BallRuns r;
+        r.b = (int)(q / S);
+        const unsigned char *base = ws + (size_t)r.b * cloud_bytes;
+        const GridHeader *hdr = (const GridHeader *)base;
+        r.cx = new_xyz[q * 3 + 0];
+        r.cy = new_xyz[q * 3 + 1];
+        r.cz = new_xyz[q * 3 + 2];
+        const bool q_finite = fabsf(r.cx) <= 3.0e38f && fabsf(r.cy) <= 3.0e38f && fabsf(r.cz) <= 3.0e38f;
+        r.scan = hdr->use_scan || !q_finite;
+        r.rs = r.re = 0;
+        if (r.scan) return r;
+        const int *__restrict__ cell_start = (const int *)(base + sizeof(GridHeader));
+        const int gx = hdr->g[0], gy = hdr->g[1], gz = hdr->g[2];
+        const float inv_h = hdr->inv_h;
+        const int qx = cell_coord(r.cx, hdr->lo[0], inv_h, gx);
+        const int qy = cell_coord(r.cy, hdr->lo[1], inv_h, gy);
+        const int qz = cell_coord(r.cz, hdr->lo[2], inv_h, gz);
+        const int x0 = max(qx - 1, 0), x1 = min(qx + 1, gx - 1);
+        if (lane < 9 && x0 <= x1) {
+            const int yy = qy + dy, zz = qz + dz;
+            if (yy >= 0 && yy < gy && zz >= 0 && zz < gz) {
+                const int c0 = (zz * gy + yy) * gx;
+                r.rs = cell_start[c0 + x0];
+                r.re = cell_start[c0 + x1 + 1];
+            }
+        }
+        return r;
+    };
+
+    long long q = (long long)lb * 4 + wv;
+    if (q >= total) return;
+    BallRuns cur = lookup(q);
+    for (; q < total; q += stride) {
+        const long long qn = q + stride;
+        IdxT *__restrict__ orow = out + q * K;
+        if (cur.scan) {  // wave-uniform
+            ball_scan_row<IdxT>(N, K, r2, xyz + (size_t)cur.b * N * 3, cur.cx, cur.cy, cur.cz, orow, lane);
+            if (qn < total) cur = lookup(qn);
+            continue;
+        }
+        const float4 *__restrict__ rec = (const float4 *)(ws + (size_t)cur.b * cloud_bytes + rec_off);
+        const float cx = cur.cx, cy = cur.cy, cz = cur.cz;
+        const float s1 = sumsq3(cx, cy, cz);
+        // rows 0..3 serve runs 4*s3 .. 4*s3+3 in step s3 (runs >= 9 are empty): record range of my run in each step
+        int j0[3], je[3];
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            j0[s3] = __shfl(cur.rs, 4 * s3 + row) + col;
+            je[s3] = __shfl(cur.re, 4 * s3 + row);
+        }
+        // the first 32 records of every run: six loads in flight per lane
+        float4 p[3][2];
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int j = j0[s3] + 16 * i;
+                p[s3][i] = j < je[s3] ? rec[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        // the next query's cell-table look-ups go out behind them and land while this query is processed
+        BallRuns nxt;
+        nxt.scan = true;
+        nxt.rs = nxt.re = nxt.b = 0;
+        nxt.cx = nxt.cy = nxt.cz = 0.0f;
+        if (qn < total) nxt = lookup(qn);
+
+        int H = 0;
+        auto test = [&](const float4 &pp) -> bool {
+            const float d = sqdist_expanded(cx, cy, cz, s1, pp.x, pp.y, pp.z, sumsq3(pp.x, pp.y, pp.z));
+            return !(d > r2);
+        };
+        auto record = [&](bool hit, int pidx) {   // pass 0: set the bit, list the hit
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                if (hit) {
+                    atomicOr(&bm[(unsigned)pidx >> 5], 1u << (pidx & 31));
+                    const int pos = H + mbcnt(mask);
+                    if (pos < kBmHitCap) hits[pos] = pidx;
+                }
+                H += __popcll(mask);
+            }
+        };
+        bool more = false;   // some run holds more than 32 records
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool in = j0[s3] + 16 * i < je[s3];
+                record(in && test(p[s3][i]), __float_as_int(p[s3][i].w));
+            }
+            more |= j0[s3] + 32 < je[s3];
+        }
+        // rank of index v = number of set bits below it (valid once gbase is up to date)
+        auto rank_of = [&](int v) -> int {
+            const unsigned g = (unsigned)v >> 7, wsel = ((unsigned)v >> 5) & 3u, below = (1u << (v & 31)) - 1u;
+            const u32x4 w = *(const u32x4 *)&bm[g * 4u];
+            int r = (int)gbase[g];
+            r += __popc(w[0] & (wsel > 0u ? ~0u : below));
+            r += __popc(w[1] & (wsel > 1u ? ~0u : wsel == 1u ? below : 0u));
+            r += __popc(w[2] & (wsel > 2u ? ~0u : wsel == 2u ? below : 0u));
+            r += __popc(w[3] & (wsel == 3u ? below : 0u));
+            return r;
+        };
+        int first = 0x7FFFFFFF;   // the hit of rank 0, in the lane that holds it
+        // the records beyond the first 32 of a run (pass 0), or every record again (pass 1: the hit list overflowed and
+        // each hit is ranked straight from the bitmap)
+        auto walk = [&](const int pass) {
+#pragma unroll 1
+            for (int s3 = 0; s3 < 3; ++s3) {
+                int j = j0[s3] + (pass == 0 ? 32 : 0);
+                while (__any(j < je[s3])) {
+                    bool hit = false;
+                    int pidx = 0;
+                    if (j < je[s3]) {
+                        const float4 pp = rec[j];
+                        hit = test(pp);
+                        pidx = __float_as_int(pp.w);
+                    }
+                    if (pass == 0) {
+                        record(hit, pidx);
+                    } else if (hit) {
+                        const int r = rank_of(pidx);
+                        if (r < K) orow[r] = (IdxT)pidx;
+                        if (r == 0) first = pidx;
+                    }
+                    j += 16;
+                }
+            }
+        };
+        if (__any(more)) walk(0);
+        if (H == 0) {   // wave-uniform; the bitmap is still clean
+            for (int j = lane; j < K; j += kWave) orow[j] = (IdxT)N;  // no hit at all -> N (:136-141)
+            cur = nxt;
+            continue;
+        }
+        {   // base rank of every 128-index group
+            unsigned c[4] = {0u, 0u, 0u, 0u};   // nquad <= 4
+            unsigned tot = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < nquad) {
+                    const u32x4 w = *(const u32x4 *)&bm[(lane * nquad + t) * 4];
+                    c[t] = (unsigned)(__popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]));
+                    tot += c[t];
+                }
+            }
+            unsigned incl = tot;   // inclusive scan over the 64 lanes
+            incl += dpp_or_zero<0x111, 0xF>(incl);
+            incl += dpp_or_zero<0x112, 0xF>(incl);
+            incl += dpp_or_zero<0x114, 0xF>(incl);
+            incl += dpp_or_zero<0x118, 0xF>(incl);
+            incl += dpp_or_zero<0x142, 0xA>(incl);   // row_bcast:15 into rows 1, 3
+            incl += dpp_or_zero<0x143, 0xC>(incl);   // row_bcast:31 into rows 2, 3
+            unsigned run_ = incl - tot;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < nquad) {
+                    gbase[lane * nquad + t] = run_;
+                    run_ += c[t];
+                }
+            }
+        }
+        if (H <= kBmHitCap) {
+            for (int i = lane; i < H; i += kWave) {
+                const int v = hits[i];
+                const int r = rank_of(v);
+                if (r < K) orow[r] = (IdxT)v;
+                if (r == 0) first = v;
+            }
+        } else {
+            walk(1);
+        }
+        if (H < K) {   // pad with the first hit = the smallest index (:138-141)
+            const unsigned long long fm = __ballot(first != 0x7FFFFFFF);
+            const int fv = __builtin_amdgcn_readlane(first, (int)__builtin_ctzll(fm));
+            for (int j = H + lane; j < K; j += kWave) orow[j] = (IdxT)fv;
+        }
+        for (int t = 0; t < nquad; ++t) *(u32x4 *)&bm[(lane * nquad + t) * 4] = u32x4{0u, 0u, 0u, 0u};
+        cur = nxt;
+    }
+}
+
 static bool use_grid(int N, int S, int K) {
     // the grid pays off once the per-query scan (N/64 steps) clearly exceeds a neighbourhood visit
     return N >= 2048 && (long long)S * 8 >= N / 64 && K <= kGridMaxK;
@@ -424,6 +666,18 @@ static int ball_query_impl(int B, int N, int S, int nsample, float r2, const flo
             if (int rc = check_launch("ball_grid_build_kernel")) return rc;
         }
         if (!query) return TGN_OK;
+        static const int bitmap_ok = getenv("TGN_BALL_BITMAP") ? atoi(getenv("TGN_BALL_BITMAP")) : 1;   // 0: the rank-select kernel (experiments)
+        if (bitmap_ok && N <= kBmMaxN) {
+            const int nquad = (N + 8191) >> 13;
+            const size_t lds = (size_t)4 * (nquad * 256 + nquad * 64 + kBmHitCap) * sizeof(unsigned);   // <= 24 KiB per workgroup
+            if (idx_is_int64)
+                hipLaunchKernelGGL((ball_grid_query_bitmap_kernel<long long>), dim3((unsigned)blocks), dim3(256), lds, st, B, N, S,
+                                   nsample, r2, xyz, new_xyz, (const unsigned char *)workspace, (long long *)idx);
+            else
+                hipLaunchKernelGGL((ball_grid_query_bitmap_kernel<int>), dim3((unsigned)blocks), dim3(256), lds, st, B, N, S, nsample,
+                                   r2, xyz, new_xyz, (const unsigned char *)workspace, (int *)idx);
+            return check_launch("ball_grid_query_bitmap_kernel");
+        }
         if (idx_is_int64)
             hipLaunchKernelGGL((ball_grid_query_kernel<long long>), dim3((unsigned)blocks), dim3(256), 0, st, B, N, S,
                                nsample, r2, xyz, new_xyz, (const unsigned char *)workspace, (long long *)idx);

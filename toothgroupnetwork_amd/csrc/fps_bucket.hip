@@ -33,6 +33,27 @@
 #ifndef TGN_REFRESH_SKIP
 #define TGN_REFRESH_SKIP 1
 #endif
+// Which wave holds Z-order bucket b = 8*s + i in its register slot s.  Plain round robin (i) sends buckets b, b+8, b+16,
+// b+64 ... to the SAME wave, and those are exactly the index distances of spatial neighbours along a Z-order curve: the
+// ~9 buckets one sample touches then pile up on a few waves and everyone else waits at the barrier (wave 0 spends 38 % of
+// an iteration there).  XOR-folding the slot number into the wave number keeps every group of 8 consecutive buckets on
+// 8 different waves and moves the power-of-two neighbours apart as well.
+#ifndef TGN_FPS_PERM
+#define TGN_FPS_PERM 1
+#endif
+// (applied where the sorted order is written -- tab[] is stored in (slot, wave) order -- so the loop's look-ups are unchanged)
+template <int NW>
+__device__ __forceinline__ unsigned fps_bucket_slot(unsigned pos) {   // sorted position -> position in (slot, wave, lane) order
+    const unsigned b = pos >> 6, sl = b / NW, i = b & (NW - 1);
+#if TGN_FPS_PERM == 1
+    const unsigned w = i ^ ((sl ^ (sl >> 3)) & (NW - 1));
+#elif TGN_FPS_PERM == 2
+    const unsigned w = (i + 3u * sl + (sl >> 3)) & (NW - 1);
+#else
+    const unsigned w = i;
+#endif
+    return ((sl * NW + w) << 6) | (pos & 63u);
+}
 
 namespace tgn {
 
@@ -138,7 +159,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
         return spread5(cc[0]) | (spread5(cc[1]) << 1) | (spread5(cc[2]) << 2);
     };
     for (int i = tid; i < kCellWords; i += NT) cells[i] = 0u;
-    for (int i = n + tid; i < CAP; i += NT) tab[i] = (unsigned short)0xFFFF;
+    for (int i = n + tid; i < CAP; i += NT) tab[fps_bucket_slot<NW>((unsigned)i)] = (unsigned short)0xFFFF;
     __syncthreads();
     for (int i = tid; i < n; i += NT) {
         const unsigned code = cell_of(i);
@@ -176,7 +197,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
         const unsigned code = cell_of(i);
         const unsigned sh = (code & 1u) << 4;
         const unsigned old = atomicAdd(&cells[code >> 1], 1u << sh);  // cursor of the cell; never carries into its neighbour
-        tab[(old >> sh) & 0xFFFFu] = (unsigned short)i;
+        tab[fps_bucket_slot<NW>((old >> sh) & 0xFFFFu)] = (unsigned short)i;
     }
     __syncthreads();
 

@@ -67,7 +67,7 @@ class HotPath:
 
     def __init__(self, B, device, shape=SHAPE_A, xyz_first=True, index_dtype=torch.int32, pipeline=False,
                  fps_prefix=False, group_impl=0, group_policy=-1, group_max_blocks=None, fused=False, ball_stream=None,
-                 group_gate=None, early_grid=None):
+                 group_gate=None, early_grid=None, ball_split=True):
         self.B, self.device, self.shape = B, device, shape
         # launch knobs of the grouping kernel (include/tgn_pointops.h, tgn_group_points_ex).  In the pipelined schedule its
         # grid is bounded to what fits beside the FPS level-1 workgroups, so that those never wait for a CU to drain:
@@ -102,6 +102,10 @@ class HotPath:
             self.s_fps = torch.cuda.Stream(device=device, priority=-1)
             self.s_rest = torch.cuda.Stream(device=device, priority=0)
             self.s_ball = torch.cuda.Stream(device=device, priority=-1) if self.ball_stream else None
+            # phased: the queries of levels 2, 3 (small) on a stream of their own -- they depend on FPS levels 2, 3 only and
+            # would otherwise queue behind the level-1 query (1.3 of the 1.5 ms of phase 2)
+            self.s_ball2 = torch.cuda.Stream(device=device, priority=-1) if (self.ball_stream == 2 and ball_split) else None
+            self.ev_ball2 = [torch.cuda.Event() for _ in range(2)]
             self.ev_ball = [[torch.cuda.Event() for _ in shape["npoint"]] for _ in range(2)]
             self.ev_fps = [[torch.cuda.Event() for _ in shape["npoint"]] for _ in range(2)]
             self.ev_grid = [torch.cuda.Event() for _ in range(2)]
@@ -188,18 +192,19 @@ class HotPath:
             return [self._sa(lv, br, cur_xyz, pts, st) for br in lv["branches"]]
         return [self._group(lv, br, cur_xyz, feats[i], st, i) for br in lv["branches"]]
 
-    def enable_kernel_timing(self, steps):
-        """HIP events on the launch stream around each kernel class (start/stop per step)."""
+    def enable_kernel_timing(self, steps, stride=1):
+        """HIP events on the launch stream around each kernel class (start/stop), on every `stride`-th step: a timing
+        event is a barrier packet in its queue, and a dozen of them per step cost the pipelined schedule ~5 %."""
         names = [f"{k}_l{i + 1}" for i in range(len(self.levels)) for k in ("fps", "ball", "group")]
         self.events = {n: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                           for _ in range(steps)] for n in names}
+                           if s_ % stride == 0 else None for s_ in range(steps)] for n in names}
         self._step = 0
 
     def kernel_times_ms(self):
-        return {n: [a.elapsed_time(b) for a, b in evs[:self._step]] for n, evs in self.events.items()}
+        return {n: [e[0].elapsed_time(e[1]) for e in evs[:self._step] if e is not None] for n, evs in self.events.items()}
 
     def _timed(self, name, fn, stream=None):
-        if self.events is None or self._step >= len(self.events[name]):
+        if self.events is None or self._step >= len(self.events[name]) or self.events[name][self._step] is None:
             return fn()
         a, b = self.events[name][self._step]
         a.record(stream)
@@ -242,13 +247,14 @@ class HotPath:
     def _run_pipelined(self, xyz, feats, inputs_on_current_stream=True):
         p = self.step_no & 1
         levels = self.sets[p]
-        sf, sg, sb = self.s_fps, self.s_rest, self.s_ball
+        sf, sg, sb, sb2 = self.s_fps, self.s_rest, self.s_ball, self.s_ball2
         pf, pg = _lib.c_void_p(sf.cuda_stream), _lib.c_void_p(sg.cuda_stream)
         pb = _lib.c_void_p(sb.cuda_stream) if sb is not None else None
+        pb2 = _lib.c_void_p(sb2.cuda_stream) if sb2 is not None else None
         cur = torch.cuda.current_stream()
         if inputs_on_current_stream or self.step_no == 0:
             self.ev_start.record(cur)      # inputs produced on the caller's stream
-            for s_ in (sf, sg, sb):
+            for s_ in (sf, sg, sb, sb2):
                 if s_ is not None:
                     s_.wait_event(self.ev_start)
         if self.step_no >= 2:
@@ -261,6 +267,8 @@ class HotPath:
             self.ev_grid[p].record(sf)
         if self.ball_stream == 2 and self.step_no >= 1:
             sf.wait_event(self.ev_ball[1 - p][-1])   # phased: the previous step's ball queries are through
+            if sb2 is not None:
+                sf.wait_event(self.ev_ball[1 - p][0])
         cur_xyz = xyz
         for i, lv in enumerate(levels):
             self._timed(f"fps_l{i + 1}", lambda: self._fps(i, lv, cur_xyz, levels, pf), sf)
@@ -268,12 +276,13 @@ class HotPath:
                 self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, cur_xyz, pf) for br in lv["branches"]], sf)
             self.ev_fps[p][i].record(sf)
             if sb is not None:
-                sb.wait_event(self.ev_fps[p][i])
+                sq, pq = (sb2, pb2) if (sb2 is not None and i > 0) else (sb, pb)
+                sq.wait_event(self.ev_fps[p][i])
                 pre = self.early_grid and i == 0
                 if pre:
-                    sb.wait_event(self.ev_grid[p])
-                self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, cur_xyz, pb, prebuilt=pre) for br in lv["branches"]], sb)
-                self.ev_ball[p][i].record(sb)
+                    sq.wait_event(self.ev_grid[p])
+                self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, cur_xyz, pq, prebuilt=pre) for br in lv["branches"]], sq)
+                self.ev_ball[p][i].record(sq)
             cur_xyz = lv["new_xyz"]
         cur_xyz = xyz
         ev_q = self.ev_ball if sb is not None else self.ev_fps    # "the queries of level i are done"
@@ -281,6 +290,8 @@ class HotPath:
             if self.group_gate:
                 if i == 0:
                     sg.wait_event(ev_q[p][-1])   # all of this step's groupings run beside the NEXT step's FPS level 1
+                    if sb2 is not None:
+                        sg.wait_event(ev_q[p][0])
             else:
                 sg.wait_event(ev_q[p][i])
             self._timed(f"group_l{i + 1}", lambda: self._consume(i, lv, cur_xyz, feats, levels, pg), sg)
