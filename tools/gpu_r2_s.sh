@@ -1,0 +1,16 @@
+#!/bin/bash
+set -u
+export TMPDIR=/tmp
+run() {
+  echo "== bench $*"
+  timeout 300 python bench.py --steps 20 --warmup 5 --cpu-meshes 0 --no-alt "$@" 2>&1 | tail -1 | python -c "
+import json,sys
+try:
+    d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],3), d.get('kernel_ms_per_step'), 'group frac', round(d.get('roofline_group',{}).get('frac',0),3))
+except Exception as e: print('FAILED', e)"
+}
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_modules.py tests/test_gpu_random_sweep.py -m gpu -q -x -k "group or hotpath or pipelined or full_size or sample_and_group or modules or sweep" 2>&1 | tail -3
+echo "== group_bench rows (wide DMA)"; timeout 300 python tools/group_bench.py rows 2>&1 | grep -E "impl|^ +7" 
+echo "== group_bench rows (dword DMA)"; TGN_GROUP_WIDE_DMA=0 timeout 300 python tools/group_bench.py rows 2>&1 | grep -E "^ +7 +16"
+run --ball-split 0
+run --ball-split 0 --pipeline 0

@@ -411,10 +411,20 @@ __global__ __launch_bounds__(256) void ball_grid_query_kernel(int B, int N, int 
 constexpr int kBmMaxN = 32768;
 constexpr int kBmHitCap = 256;
 
-// Latency: a query is a chain of dependent round trips (query -> cell table -> records -> LDS -> stores) and the kernel
-// is bound by them, not by its instruction count.  So the first 32 records of every run are requested at once (six 16-byte
-// loads per lane in flight; runs longer than that take a tail loop), and the cell-table look-ups of the wave's NEXT
-// query are issued before the current one is processed, so that they have landed when its turn comes.
+// Cost: the kernel is bound by vector-ALU issue (a wave64 instruction holds its SIMD for 4 cycles; the rank-select kernel
+// spends ~430 of them per query), so this one is written for few instructions on the common path:
+//   * a run is served by 7 lanes (9 runs x 7 = 63 lanes), three records per lane: 21 records per run without a loop
+//     (a run holds ~15 on a scan surface; longer ones take a tail loop), run number and column are per-lane constants;
+//   * records, cell table and the output row go through buffer descriptors (32-bit offsets, out-of-range lanes read 0);
+//   * the cell-table look-ups of the wave's NEXT query are issued before the current one is processed.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ball_rsrc(const void *base, unsigned bytes) {   // wave-uniform base
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+
 struct BallRuns {      // what a query needs to start: lanes 0..8 hold the record range of one x-run each
     float cx, cy, cz;  // wave-uniform
     int rs, re;
@@ -441,15 +451,16 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
     const long long total = (long long)B * S;
     const size_t cloud_bytes = grid_cloud_bytes(N);
     const size_t rec_off = sizeof(GridHeader) + (size_t)((kGridCells + 1 + 3) / 4 * 4) * sizeof(int);
-    const int row = lane >> 4, col = lane & 15;
+    const int run = lane / 7, col = lane - run * 7;   // lanes 0..62 -> runs 0..8; lane 63 -> "run 9" (empty)
     const int dy = lane % 3 - 1, dz = lane / 3 - 1;   // lanes 0..8: the (dy, dz) x-run this lane looks up
     const unsigned nb = gridDim.x;   // XCD-aware block order, see ball_grid_query_kernel
     const unsigned lb = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
     const long long stride = (long long)nb * 4;
 
-    auto lookup = [&](long long q) -> BallRuns {   // issues the two cell-table loads of query q (lanes 0..8)
+    // (the scan a query belongs to is tracked incrementally: a 64-bit division per query costs ~100 instructions)
+    auto lookup = [&](long long q, int bq) -> BallRuns {   // issues the two cell-table loads of query q (lanes 0..8) of scan bq
         BallRuns r;
-        r.b = (int)(q / S);
+        r.b = bq;
         const unsigned char *base = ws + (size_t)r.b * cloud_bytes;
         const GridHeader *hdr = (const GridHeader *)base;
         r.cx = new_xyz[q * 3 + 0];
@@ -459,87 +470,87 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
         r.scan = hdr->use_scan || !q_finite;
         r.rs = r.re = 0;
         if (r.scan) return r;
-        const int *__restrict__ cell_start = (const int *)(base + sizeof(GridHeader));
+        const __amdgpu_buffer_rsrc_t rs_cells = ball_rsrc(base + sizeof(GridHeader), (kGridCells + 1) * 4u);
         const int gx = hdr->g[0], gy = hdr->g[1], gz = hdr->g[2];
         const float inv_h = hdr->inv_h;
         const int qx = cell_coord(r.cx, hdr->lo[0], inv_h, gx);
         const int qy = cell_coord(r.cy, hdr->lo[1], inv_h, gy);
         const int qz = cell_coord(r.cz, hdr->lo[2], inv_h, gz);
         const int x0 = max(qx - 1, 0), x1 = min(qx + 1, gx - 1);
-        if (lane < 9 && x0 <= x1) {
-            const int yy = qy + dy, zz = qz + dz;
-            if (yy >= 0 && yy < gy && zz >= 0 && zz < gz) {
-                const int c0 = (zz * gy + yy) * gx;
-                r.rs = cell_start[c0 + x0];
-                r.re = cell_start[c0 + x1 + 1];
-            }
-        }
+        const int yy = qy + dy, zz = qz + dz;
+        const bool ok = lane < 9 && x0 <= x1 && yy >= 0 && yy < gy && zz >= 0 && zz < gz;
+        const unsigned c0 = (unsigned)((zz * gy + yy) * gx);
+        // lanes without a run read out of range: the hardware returns 0 for both ends -> an empty run
+        r.rs = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_cells, ok ? (c0 + (unsigned)x0) * 4u : 0xFFFFFFF0u, 0, 0);
+        r.re = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_cells, ok ? (c0 + (unsigned)x1 + 1u) * 4u : 0xFFFFFFF0u, 0, 0);
         return r;
     };
 
     long long q = (long long)lb * 4 + wv;
     if (q >= total) return;
-    BallRuns cur = lookup(q);
+    int bcur = __builtin_amdgcn_readfirstlane((int)(q / S));
+    int rcur = __builtin_amdgcn_readfirstlane((int)(q - (long long)bcur * S));     // q = bcur*S + rcur
+    const int db = __builtin_amdgcn_readfirstlane((int)(stride / S));
+    const int dr = __builtin_amdgcn_readfirstlane((int)(stride - (long long)db * S));
+    BallRuns cur = lookup(q, bcur);
     for (; q < total; q += stride) {
         const long long qn = q + stride;
-        IdxT *__restrict__ orow = out + q * K;
+        bcur += db;
+        rcur += dr;
+        if (rcur >= S) {
+            rcur -= S;
+            ++bcur;
+        }   // (bcur, rcur) now describe qn
         if (cur.scan) {  // wave-uniform
-            ball_scan_row<IdxT>(N, K, r2, xyz + (size_t)cur.b * N * 3, cur.cx, cur.cy, cur.cz, orow, lane);
-            if (qn < total) cur = lookup(qn);
+            ball_scan_row<IdxT>(N, K, r2, xyz + (size_t)cur.b * N * 3, cur.cx, cur.cy, cur.cz, out + q * K, lane);
+            if (qn < total) cur = lookup(qn, bcur);
             continue;
         }
-        const float4 *__restrict__ rec = (const float4 *)(ws + (size_t)cur.b * cloud_bytes + rec_off);
+        const __amdgpu_buffer_rsrc_t rs_rec = ball_rsrc(ws + (size_t)cur.b * cloud_bytes + rec_off, (unsigned)N * 16u);
+        const __amdgpu_buffer_rsrc_t rs_out = ball_rsrc(out + q * K, (unsigned)K * (unsigned)sizeof(IdxT));
+        auto put = [&](int r, int v) {   // orow[r] = v
+            if constexpr (sizeof(IdxT) == 8) {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{(unsigned)v, 0u}, rs_out, (unsigned)r * 8u, 0, 0);   // indices are >= 0
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)v, rs_out, (unsigned)r * 4u, 0, 0);
+            }
+        };
         const float cx = cur.cx, cy = cur.cy, cz = cur.cz;
         const float s1 = sumsq3(cx, cy, cz);
-        // rows 0..3 serve runs 4*s3 .. 4*s3+3 in step s3 (runs >= 9 are empty): record range of my run in each step
-        int j0[3], je[3];
+        const int j0 = __shfl(cur.rs, run) + col;   // my first record of my run
+        const int je = __shfl(cur.re, run);
+        // three records per lane in flight: 21 per run
+        u32x4 p[3];
 #pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) {
-            j0[s3] = __shfl(cur.rs, 4 * s3 + row) + col;
-            je[s3] = __shfl(cur.re, 4 * s3 + row);
+        for (int i = 0; i < 3; ++i) {
+            const int j = j0 + 7 * i;
+            p[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, j < je ? (unsigned)j * 16u : 0xFFFFFFF0u, 0, 0);
         }
-        // the first 32 records of every run: six loads in flight per lane
-        float4 p[3][2];
-#pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int j = j0[s3] + 16 * i;
-                p[s3][i] = j < je[s3] ? rec[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
         // the next query's cell-table look-ups go out behind them and land while this query is processed
         BallRuns nxt;
         nxt.scan = true;
         nxt.rs = nxt.re = nxt.b = 0;
         nxt.cx = nxt.cy = nxt.cz = 0.0f;
-        if (qn < total) nxt = lookup(qn);
+        if (qn < total) nxt = lookup(qn, bcur);
 
         int H = 0;
-        auto test = [&](const float4 &pp) -> bool {
-            const float d = sqdist_expanded(cx, cy, cz, s1, pp.x, pp.y, pp.z, sumsq3(pp.x, pp.y, pp.z));
+        auto test = [&](const u32x4 &pp) -> bool {
+            const float px = __uint_as_float(pp[0]), py = __uint_as_float(pp[1]), pz = __uint_as_float(pp[2]);
+            const float d = sqdist_expanded(cx, cy, cz, s1, px, py, pz, sumsq3(px, py, pz));
             return !(d > r2);
         };
         auto record = [&](bool hit, int pidx) {   // pass 0: set the bit, list the hit
-            const unsigned long long mask = __ballot(hit);
-            if (mask) {
-                if (hit) {
-                    atomicOr(&bm[(unsigned)pidx >> 5], 1u << (pidx & 31));
-                    const int pos = H + mbcnt(mask);
-                    if (pos < kBmHitCap) hits[pos] = pidx;
-                }
-                H += __popcll(mask);
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+            if (hit) {
+                atomicOr(&bm[(unsigned)pidx >> 5], 1u << (pidx & 31));
+                const int pos = H + mbcnt(mask);
+                if (pos < kBmHitCap) hits[pos] = pidx;
             }
+            H += __popcll(mask);
         };
-        bool more = false;   // some run holds more than 32 records
 #pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const bool in = j0[s3] + 16 * i < je[s3];
-                record(in && test(p[s3][i]), __float_as_int(p[s3][i].w));
-            }
-            more |= j0[s3] + 32 < je[s3];
-        }
+        for (int i = 0; i < 3; ++i) record(j0 + 7 * i < je && test(p[i]), (int)p[i][3]);
         // rank of index v = number of set bits below it (valid once gbase is up to date)
         auto rank_of = [&](int v) -> int {
             const unsigned g = (unsigned)v >> 7, wsel = ((unsigned)v >> 5) & 3u, below = (1u << (v & 31)) - 1u;
@@ -552,34 +563,27 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
             return r;
         };
         int first = 0x7FFFFFFF;   // the hit of rank 0, in the lane that holds it
-        // the records beyond the first 32 of a run (pass 0), or every record again (pass 1: the hit list overflowed and
+        // the records beyond the first 21 of a run (pass 0), or every record again (pass 1: the hit list overflowed and
         // each hit is ranked straight from the bitmap)
         auto walk = [&](const int pass) {
-#pragma unroll 1
-            for (int s3 = 0; s3 < 3; ++s3) {
-                int j = j0[s3] + (pass == 0 ? 32 : 0);
-                while (__any(j < je[s3])) {
-                    bool hit = false;
-                    int pidx = 0;
-                    if (j < je[s3]) {
-                        const float4 pp = rec[j];
-                        hit = test(pp);
-                        pidx = __float_as_int(pp.w);
-                    }
-                    if (pass == 0) {
-                        record(hit, pidx);
-                    } else if (hit) {
-                        const int r = rank_of(pidx);
-                        if (r < K) orow[r] = (IdxT)pidx;
-                        if (r == 0) first = pidx;
-                    }
-                    j += 16;
+            int j = j0 + (pass == 0 ? 21 : 0);
+            while (__any(j < je)) {
+                const u32x4 pp = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, j < je ? (unsigned)j * 16u : 0xFFFFFFF0u, 0, 0);
+                const bool hit = j < je && test(pp);
+                const int pidx = (int)pp[3];
+                if (pass == 0) {
+                    record(hit, pidx);
+                } else if (hit) {
+                    const int r = rank_of(pidx);
+                    if (r < K) put(r, pidx);
+                    if (r == 0) first = pidx;
                 }
+                j += 7;
             }
         };
-        if (__any(more)) walk(0);
+        if (__any(j0 + 21 < je)) walk(0);
         if (H == 0) {   // wave-uniform; the bitmap is still clean
-            for (int j = lane; j < K; j += kWave) orow[j] = (IdxT)N;  // no hit at all -> N (:136-141)
+            for (int j = lane; j < K; j += kWave) put(j, N);  // no hit at all -> N (:136-141)
             cur = nxt;
             continue;
         }
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
             for (int i = lane; i < H; i += kWave) {
                 const int v = hits[i];
                 const int r = rank_of(v);
-                if (r < K) orow[r] = (IdxT)v;
+                if (r < K) put(r, v);
                 if (r == 0) first = v;
             }
         } else {
@@ -623,7 +627,7 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
         if (H < K) {   // pad with the first hit = the smallest index (:138-141)
             const unsigned long long fm = __ballot(first != 0x7FFFFFFF);
             const int fv = __builtin_amdgcn_readlane(first, (int)__builtin_ctzll(fm));
-            for (int j = H + lane; j < K; j += kWave) orow[j] = (IdxT)fv;
+            for (int j = H + lane; j < K; j += kWave) put(j, fv);
         }
         for (int t = 0; t < nquad; ++t) *(u32x4 *)&bm[(lane * nquad + t) * 4] = u32x4{0u, 0u, 0u, 0u};
         cur = nxt;

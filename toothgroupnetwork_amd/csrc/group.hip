@@ -434,7 +434,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(24))) void grou
 // The vector-memory operations of a wave retire in issue order on one counter (gfx9), loads and stores alike, so
 // "X has landed" is "at most (operations issued after X) outstanding" -- acknowledgements of stores are never waited
 // for.  DBG (tools/group_bench.py only): 1 = no gathers, 2 = no stores.
-template <typename IdxT, int POLICY, int DBG = 0>
+// W = dwords per lane of a feature-row piece: 4 (`buffer_load_dwordx4 ... lds`, gfx950: 1 KiB per instruction; it takes
+// LDS destinations and sources that are only 4-byte aligned -- tools/dma_test/lds_dma_align.hip) when D % 4 == 0, else 1.
+// A level-2 row (128 floats) is ONE instruction instead of three, a level-3 row two instead of nine: the kernel was bound
+// by the issue cost of its LDS-DMA instructions (~60-180 cycles each), not by bytes in flight.
+template <typename IdxT, int POLICY, int DBG = 0, int W = 1>
 __global__ __launch_bounds__(64) void group_points_rows_kernel(
     long long queries, long long q_per_xcd, int N, int S, int K, int D, int R, const float *__restrict__ xyz,
     const float *__restrict__ new_xyz, const float *__restrict__ points, const IdxT *__restrict__ idx, int xyz_first,
@@ -446,13 +450,14 @@ __global__ __launch_bounds__(64) void group_points_rows_kernel(
     const unsigned fo = xyz_first ? 3u : 0u;
     const unsigned IMG = 32u + (unsigned)R * C;          // floats per image buffer (multiple of 4)
     float *const srel = lds_img + 2u * IMG;
-    const unsigned pieces = ((unsigned)D + 63u) >> 6;    // 64-float pieces per feature row
-    const unsigned last_len = (unsigned)D - 64u * (pieces - 1u);
+    constexpr unsigned FP = 64u * (unsigned)W;           // floats per piece
+    const unsigned pieces = ((unsigned)D + FP - 1u) / FP;   // pieces per feature row
+    const unsigned last_len = ((unsigned)D - FP * (pieces - 1u)) / (unsigned)W;   // active lanes of a row's last piece
     const unsigned nb = ((unsigned)K + (unsigned)R - 1u) / (unsigned)R;
     const unsigned total = (unsigned)K * C;
     const unsigned max_stores = (IMG + 255u) / 256u;     // 1-KiB store instructions per image, at most
     const bool overlap = (unsigned)R * pieces + max_stores + 4u <= 62u;   // everything in flight fits the 6-bit counter
-    const unsigned lane4 = lane * 4u;
+    const unsigned lane4 = lane * 4u * (unsigned)W;
     const unsigned pr = lane / 3u, pi = lane - pr * 3u;  // coordinate patch: lane -> (row of the image, axis)
     const unsigned x = blockIdx.x & 7u, j = blockIdx.x >> 3, nbx = gridDim.x >> 3;
     long long q1 = (long long)(x + 1) * q_per_xcd;
@@ -524,12 +529,16 @@ __global__ __launch_bounds__(64) void group_points_rows_kernel(
             for (unsigned r = 0; r < rows; ++r) {
                 const unsigned soff = (unsigned)__builtin_amdgcn_readlane((int)r0, (int)(k0 + r));
                 float *dst = img + r * C + fo;
-                for (unsigned p = 0; p + 1u < pieces; ++p)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pts, (__attribute__((address_space(3))) void *)(dst + p * 64u), 4,
-                                                             lane4, soff + p * 256u, 0, 0);
-                if (lane < last_len)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pts, (__attribute__((address_space(3))) void *)(dst + (pieces - 1u) * 64u),
-                                                             4, lane4, soff + (pieces - 1u) * 256u, 0, 0);
+                auto piece = [&](unsigned p) {   // (the size operand must be a literal)
+                    if constexpr (W == 4)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pts, (__attribute__((address_space(3))) void *)(dst + p * FP), 16,
+                                                                 lane4, soff + p * FP * 4u, 0, 0);
+                    else
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pts, (__attribute__((address_space(3))) void *)(dst + p * FP), 4,
+                                                                 lane4, soff + p * FP * 4u, 0, 0);
+                };
+                for (unsigned p = 0; p + 1u < pieces; ++p) piece(p);
+                if (lane < last_len) piece(pieces - 1u);
             }
             return rows;
         };
@@ -810,6 +819,8 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
         if (R > 20) R = 20;
         if (R > K) R = K;
         const size_t lds = (size_t)(2 * (32 + R * C) + 64 * 3 + 64 * 5) * sizeof(float);
+        static const int env_wide = env_int("TGN_GROUP_WIDE_DMA", 1);
+        const bool wide_dma = env_wide && D % 4 == 0;   // 16-byte LDS-DMA pieces
         long long qx = B >= 8 ? (long long)((B + 7) / 8) * S : (queries + 7) / 8;
         long long nb = qx;                       // workgroups (= waves) per XCD
         long long per_cu = (long long)(160 * 1024) / (long long)lds;   // resident workgroups per CU (LDS-bound)
@@ -821,7 +832,7 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
 #define TGN_GROUP_ROWS(IT, POL)                                                                                       \
     do {                                                                                                              \
         auto kfn = impl == 8 ? group_points_rows_kernel<IT, POL, 1> : impl == 9 ? group_points_rows_kernel<IT, POL, 2> \
-                                                                                 : group_points_rows_kernel<IT, POL, 0>; \
+                   : (wide_dma ? group_points_rows_kernel<IT, POL, 0, 4> : group_points_rows_kernel<IT, POL, 0>);    \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, dim3((unsigned)(nb * 8)), dim3(64), lds, st, queries, qx, N, S, K, D, R, xyz, new_xyz, pts, \
                            (const IT *)idx, xyz_first, out, err);                                                     \
