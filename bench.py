@@ -103,7 +103,7 @@ def main():
                     "[128,512,1024], eval-mode BatchNorm folded): the grouped tensor is never written -- a second, non-headline line")
     ap.add_argument("--ball-stream", type=int, default=-1, help="-1: default (2 = phased: ball queries on a third stream beside FPS levels "
                     "2-3, fenced off from the next step's FPS level 1); 0: in line on the FPS stream; 1: third stream, free-running")
-    ap.add_argument("--ball-split", type=int, default=1, help="phased schedule: ball queries of levels 2-3 on a stream of their own")
+    ap.add_argument("--ball-split", type=int, default=0, help="phased schedule: ball queries of levels 2-3 on a stream of their own")
     ap.add_argument("--early-grid", type=int, default=-1, help="phased schedule: build the level-1 ball-query grid ahead of the fence (-1 default on)")
     ap.add_argument("--group-gate", type=int, default=-1, help="1: groupings of a step wait for its last ball query, i.e. run beside the next "
                     "step's FPS level 1 (-1: default on when pipelined)")

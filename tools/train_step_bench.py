@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 3: one full training step of the tgnet_fps first-stage network (Point-Transformer U-Net with the
+tgnet_fps stage sizes, semantic + offset heads, the reference's loss terms) on ONE 24 000-point scan, batch 1, under
+torch.autocast(bfloat16) and in fp32 -- forward (BatchNorm in training mode), losses, backward through this package's
+differentiable operators (kNN gathers, fused softmax+aggregation, interpolation, square_distance), Adam step.
+
+The network is built from the mirror modules of toothgroupnetwork_amd.point_transformer (same parameter names as the
+reference's blocks.py classes); the heads and losses restate models/modules/grouping_network_module.py:38-58 and
+models/tgn_loss.py:6-60,110-129 (tooth_class_loss, batch_center_offset_loss) on synthetic labels -- the reference checkout,
+its dataset and its sklearn clustering stage are not on the GPU box.  Index kernels stay fp32 under autocast (the operators
+declare custom_fwd(cast_inputs=float32)); the learned layers run in bf16."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from toothgroupnetwork_amd import point_transformer as PT, pointnet2_utils as U, synth
+
+
+class FirstStage(nn.Module):
+    """U-Net + the two heads of the first module (grouping_network_module.py: offset (3) and semantic (17) per point)."""
+
+    def __init__(self, planes=(32, 64, 128, 256, 512), blocks=(2, 3, 4, 6, 3), classes=17):
+        super().__init__()
+        self.unet = PT.PointTransformerUNet(6, planes, blocks)
+        c = planes[0]
+        self.offset_head = nn.Sequential(nn.Linear(c, c), nn.BatchNorm1d(c), nn.ReLU(inplace=True), nn.Linear(c, 3))
+        self.sem_head = nn.Sequential(nn.Linear(c, c), nn.BatchNorm1d(c), nn.ReLU(inplace=True), nn.Linear(c, classes))
+
+    def forward(self, feat):   # (B, 6, N)
+        x = self.unet(feat)
+        return self.offset_head(x), self.sem_head(x)
+
+
+def losses(offset, sem, xyz, label):
+    """tooth_class_loss (cross entropy, tgn_loss.py:110-129) + batch_center_offset_loss (tgn_loss.py:6-60): per tooth, the
+    mean squared distance of the moved points to the tooth centroid (through square_distance) and the direction term."""
+    ce = F.cross_entropy(sem.float(), label)
+    cen, dirl, cnt = 0.0, 0.0, 0
+    for t in range(1, 17):
+        m = label == t
+        if int(m.sum()) < 5:
+            continue
+        pts, off = xyz[m][None], offset[m][None].float()
+        c = pts.mean(1, keepdim=True)
+        cen = cen + U.square_distance(pts + off, c).sum() / pts.shape[1]
+        on = off.norm(dim=2, keepdim=True)
+        d = (c - pts) / (c - pts).norm(dim=2, keepdim=True).clamp_min(1e-12)
+        keep = on[0, :, 0] > 2e-4
+        if bool(keep.any()):
+            dot = ((off / on.clamp_min(1e-12))[0][keep] * d[0][keep]).sum(1) - 1.0
+            dirl = dirl + (dot * dot).mean()
+        cnt += 1
+    cnt = max(cnt, 1)
+    return ce + 0.03 * cen / cnt + 0.03 * dirl / cnt, ce
+
+
+def make_scan(n, seed, dev):
+    pts = synth.scan_batch(1, n, "arch", seed)            # (1, n, 6): xyz + normal
+    xyz = torch.from_numpy(pts[0, :, :3]).to(dev)
+    ang = torch.atan2(xyz[:, 1] + 0.45, xyz[:, 0])        # position along the arch -> 16 "teeth", crown height -> gingiva
+    tooth = (ang.clamp(0, 3.14159) / 3.1416 * 16).long().clamp(0, 15) + 1
+    label = torch.where(xyz[:, 2] < xyz[:, 2].median(), torch.zeros_like(tooth), tooth)
+    return torch.from_numpy(pts.transpose(0, 2, 1).copy()).to(dev), xyz, label
+
+
+def run(net, opt, feat, xyz, label, steps, amp):
+    out = []
+    for _ in range(steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            offset, sem = net(feat)
+            loss, ce = losses(offset, sem, xyz, label)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        bad = [n for n, p in net.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+        opt.step()
+        b.record()
+        torch.cuda.synchronize()
+        out.append(dict(ms=a.elapsed_time(b), loss=float(loss.detach()), ce=float(ce.detach()), bad_grads=len(bad),
+                        out_dtype=str(sem.dtype).replace("torch.", "")))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=24000)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--small", action="store_true", help="reduced widths / depths (tests)")
+    args = ap.parse_args()
+    dev = torch.device("cuda")
+    feat, xyz, label = make_scan(args.points, 3, dev)
+    res = {}
+    for amp in (False, True):
+        torch.manual_seed(0)
+        net = (FirstStage((16, 32, 32, 64, 64), (1, 2, 2, 2, 1)) if args.small else FirstStage()).to(dev).train()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        r = run(net, opt, feat, xyz, label, args.steps, amp)
+        res["bf16_autocast" if amp else "fp32"] = dict(ms_per_step=float(np.median([x["ms"] for x in r[1:]])), first_loss=r[0]["loss"],
+                                                       last_loss=r[-1]["loss"], bad_grads=sum(x["bad_grads"] for x in r),
+                                                       head_dtype=r[0]["out_dtype"], params=sum(p.numel() for p in net.parameters()))
+    print(json.dumps({"workload": f"tgnet_fps first-stage train step, 1 x {args.points} points" + (" (small net)" if args.small else ""), **res}))
+    return res
+
+
+if __name__ == "__main__":
+    main()

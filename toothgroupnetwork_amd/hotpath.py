@@ -67,7 +67,7 @@ class HotPath:
 
     def __init__(self, B, device, shape=SHAPE_A, xyz_first=True, index_dtype=torch.int32, pipeline=False,
                  fps_prefix=False, group_impl=0, group_policy=-1, group_max_blocks=None, fused=False, ball_stream=None,
-                 group_gate=None, early_grid=None, ball_split=True):
+                 group_gate=None, early_grid=None, ball_split=False):
         self.B, self.device, self.shape = B, device, shape
         # launch knobs of the grouping kernel (include/tgn_pointops.h, tgn_group_points_ex).  In the pipelined schedule its
         # grid is bounded to what fits beside the FPS level-1 workgroups, so that those never wait for a CU to drain:
@@ -102,8 +102,9 @@ class HotPath:
             self.s_fps = torch.cuda.Stream(device=device, priority=-1)
             self.s_rest = torch.cuda.Stream(device=device, priority=0)
             self.s_ball = torch.cuda.Stream(device=device, priority=-1) if self.ball_stream else None
-            # phased: the queries of levels 2, 3 (small) on a stream of their own -- they depend on FPS levels 2, 3 only and
-            # would otherwise queue behind the level-1 query (1.3 of the 1.5 ms of phase 2)
+            # ball_split (experiment, off): the queries of levels 2, 3 on a stream of their own -- they depend on FPS levels 2, 3
+            # only and otherwise queue behind the level-1 query.  Measured: 5.79 ms per step against 5.65 -- phase 2 is bound by
+            # vector-ALU issue, the queries only take each other's issue slots
             self.s_ball2 = torch.cuda.Stream(device=device, priority=-1) if (self.ball_stream == 2 and ball_split) else None
             self.ev_ball2 = [torch.cuda.Event() for _ in range(2)]
             self.ev_ball = [[torch.cuda.Event() for _ in shape["npoint"]] for _ in range(2)]

@@ -127,15 +127,20 @@ class PointTransformerLayer(nn.Module):
         if (_frozen(self, p, x) and self.nsample <= 64 and self.out_planes % 4 == 0 and g in (4, 8, 16, 32, 64)
                 and x_q.dtype == torch.float32):
             return pt_attention(p.contiguous(), x_q.contiguous(), x_k.contiguous(), x_v.contiguous(), idx, fold_pt_layer(self))
-        # training: the reference's composition with the softmax + weighted sum as one differentiable kernel pair
-        x_kg = pointops.queryandgroup(self.nsample, p, p, x_k.contiguous(), idx, o, o, use_xyz=True)   # (n, nsample, 3+c)
-        p_r, x_kg = x_kg[:, :, 0:3], x_kg[:, :, 3:]
-        for i, layer in enumerate(self.linear_p):
-            p_r = layer(p_r.transpose(1, 2).contiguous()).transpose(1, 2).contiguous() if i == 1 else layer(p_r)
-        w = x_kg - x_q.unsqueeze(1) + p_r
-        for i, layer in enumerate(self.linear_w):
-            w = layer(w.transpose(1, 2).contiguous()).transpose(1, 2).contiguous() if i % 3 == 0 else layer(w)
-        return pt_softmax_aggregate(x_v.contiguous(), p_r.contiguous(), w.contiguous(), idx)
+        # training: the reference's composition with the softmax + weighted sum as one differentiable kernel pair.
+        # Under autocast this section stays in fp32: it is bandwidth-bound over (n, nsample, c) tensors that the gather
+        # kernels produce and consume as fp32, its learned layers are 3- to c/8-wide, and letting autocast flip every other
+        # operator to bf16 costs a cast pass over those tensors each time (measured: 298 ms per step against 114 in fp32).
+        with torch.autocast("cuda", enabled=False):
+            x_q, x_k, x_v = x_q.float(), x_k.float(), x_v.float()
+            x_kg = pointops.queryandgroup(self.nsample, p, p, x_k.contiguous(), idx, o, o, use_xyz=True)   # (n, nsample, 3+c)
+            p_r, x_kg = x_kg[:, :, 0:3], x_kg[:, :, 3:]
+            for i, layer in enumerate(self.linear_p):
+                p_r = layer(p_r.transpose(1, 2).contiguous()).transpose(1, 2).contiguous() if i == 1 else layer(p_r)
+            w = x_kg - x_q.unsqueeze(1) + p_r
+            for i, layer in enumerate(self.linear_w):
+                w = layer(w.transpose(1, 2).contiguous()).transpose(1, 2).contiguous() if i % 3 == 0 else layer(w)
+            return pt_softmax_aggregate(x_v.contiguous(), p_r.contiguous(), w.contiguous(), idx)
 
 
 class TransitionDown(nn.Module):
