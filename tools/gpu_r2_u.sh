@@ -1,0 +1,16 @@
+#!/bin/bash
+set -u
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+run() {
+  echo "== bench $*"
+  timeout 300 python bench.py --steps 20 --warmup 5 --cpu-meshes 0 --no-alt "$@" 2>&1 | tail -1 | python -c "
+import json,sys
+try:
+    d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],3), d.get('kernel_ms_per_step'), 'group frac', round(d.get('roofline_group',{}).get('frac',0),3))
+except Exception as e: print('FAILED', e)"
+}
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_modules.py tests/test_gpu_random_sweep.py -m gpu -q -x -k "ball or hotpath or pipelined or full_size or sample_and_group or sweep" 2>&1 | tail -2
+run
+run --pipeline 0
+bash tools/gpu_pmc.sh 2>&1 | grep -E "ball_grid_query|== "
