@@ -348,17 +348,16 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
         if (dbg) t2 = clock64();
         // ---- B. wave candidate = max over my bucket maxima (recomputed only if a bucket changed) ---------
         if (dirty) {
+            // the arg-max records of ALL my buckets (coordinates, tie key) are requested BEFORE the reduction that says which
+            // one is wanted: the LDS round trip then hides behind the six DPP steps instead of following them (this is the
+            // winner's wave, the one everybody else is waiting for at the barrier)
+            const int ml = lane < P ? lane : 0;
+            const float4 pm = make_float4(bmeta[0][wave][ml], bmeta[1][wave][ml], bmeta[2][wave][ml], bmeta[3][wave][ml]);
             const float v = lane < P ? bmax : -1.0f;
             wm = wave_max_f32_dpp(v);
             const unsigned long long cm = wm >= 0.0f ? (ballot64(v == wm) & kSlotMask) : 0ull;
             const bool cand = ((cm >> lane) & 1ull) != 0ull;
-            // coordinates and tie key of each candidate bucket's arg-max point (one LDS round trip; usually a single lane)
-            unsigned kl = 0xFFFFFFFFu;
-            float4 pm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (cand) {
-                pm = make_float4(bmeta[0][wave][lane], bmeta[1][wave][lane], bmeta[2][wave][lane], bmeta[3][wave][lane]);
-                kl = __float_as_uint(pm.w);
-            }
+            const unsigned kl = cand ? __float_as_uint(pm.w) : 0xFFFFFFFFu;
             int sl = cm ? __builtin_ctzll(cm) : 0;
             if (__popcll(cm) > 1) {
                 const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kl));
