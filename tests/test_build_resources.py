@@ -38,7 +38,8 @@ def test_fps_and_group_kernels_can_share_a_cu():
     # levels 2 and 3 (rows of >= 64 floats): the row-piece kernel, ONE wave per SIMD beside the FPS workgroup, 4 per CU
     # (dynamic LDS: 2 images of 32 + R*C floats + 512 floats of set-up planes, R*C <= 2176 -- group.hip launcher)
     rows_lds = (2 * (32 + 2176) + 64 * 3 + 64 * 5) * 4
-    for name in ("tgn::group_points_rows_kernel<int, 16, 0>", "tgn::group_points_rows_kernel<long long, 16, 0>"):
+    for name in ("tgn::group_points_rows_kernel<int, 16, 0, 4>", "tgn::group_points_rows_kernel<long long, 16, 0, 4>",
+                 "tgn::group_points_rows_kernel<int, 16, 0, 1>"):
         gv, gs, _ = g[name]
         assert gs == 0 and gv <= 48, f"{name} uses {gv} VGPRs (> 48: does not fit beside the FPS workgroup)"
     assert lds + 4 * rows_lds <= 160 * 1024
