@@ -43,6 +43,9 @@ typedef void *tgn_stream_t; /* a hipStream_t; NULL = the null stream */
 #define TGN_FPS_INDEX64 4     /* idx is int64_t* instead of int32_t* */
 #define TGN_FPS_TREE_TIES 8   /* equal distances resolved like the CUDA kernel's shared-memory tree (:5-10,64-123) */
 #define TGN_FPS_CUDA_COMPAT (TGN_FPS_FMA | TGN_FPS_TREE_TIES)
+#define TGN_FPS_LOW_VALU 16   /* scheduling hint, same results: clouds of 2048 - 4096 points also take the bucket-skipping kernel.
+                                 Alone it is ~15 % slower there than the plain register-resident kernel, but it issues a tenth of
+                                 the vector instructions -- the right choice when the launch runs beside ALU-bound work */
 
 const char *tgn_version(void);
 const char *tgn_last_error(void);     /* per host thread */

@@ -92,6 +92,7 @@ SIGNATURES = {
 FPS_FMA = 1
 FPS_LOCAL_INDEX = 2
 FPS_INDEX64 = 4
+FPS_LOW_VALU = 16   # scheduling hint (include/tgn_pointops.h): small clouds on the bucket-skipping kernel too
 FPS_TREE_TIES = 8
 FPS_CUDA_COMPAT = FPS_FMA | FPS_TREE_TIES
 

@@ -796,7 +796,7 @@ int fps_bucket_launch(int mode, int b, int n_max, const FpsArgs &a, hipStream_t 
     // Measured (profiles/r01_fps_bucket_sweep.txt): 24 000 points 0.89 vs 2.25 us per iteration, 6000 points 0.79 vs
     // 0.98, 4096 points 0.78 vs 0.72 -- there the plain kernel wins (8 points per lane: its whole iteration is already
     // fixed cost).  TGN_FPS_BUCKET_MIN overrides.
-    int min_n = 4097;
+    int min_n = (a.flags & TGN_FPS_LOW_VALU) ? 2048 : 4097;
     if (const char *e = getenv("TGN_FPS_BUCKET_MIN")) min_n = atoi(e);
     if (n_max < min_n) return -1;
     switch (mode) {  // bit 0 FMA, bit 1 tree ties, bit 2 certificate tracking (never with tree ties)

@@ -237,13 +237,17 @@ class HotPath:
 
     def _fps(self, i, lv, cur_xyz, levels, st):
         L = self.L
+        # phased schedule: FPS levels 2-3 run beside the ball queries, which are bound by vector-ALU issue -- the bucket-skipping
+        # kernel issues a tenth of the plain kernel's vector instructions (0.86 vs 0.75 ms for level 2 itself, but the level-1
+        # ball query beside it 1.10 instead of 1.28 ms)
+        flags = _lib.FPS_LOCAL_INDEX | (_lib.FPS_LOW_VALU if (self.pipeline and self.ball_stream == 2 and i > 0) else 0)
         if not self.fps_prefix:
             return check(L.tgn_furthestsampling_dense(self.B, lv["N"], lv["S"], ptr(cur_xyz), None, ptr(lv["fps_idx"]),
-                                                      ptr(lv["new_xyz"]), _lib.FPS_LOCAL_INDEX, st), "fps")
+                                                      ptr(lv["new_xyz"]), flags, st), "fps")
         cert_in = levels[i - 1]["cert"] if i > 0 else None   # level i samples level i-1's new_xyz
         return check(L.tgn_furthestsampling_dense_prefix(self.B, lv["N"], lv["S"], ptr(cur_xyz), None, 0, ptr(lv["fps_idx"]),
                                                          ptr(lv["new_xyz"]), ptr(cert_in), None, ptr(lv["cert"]),
-                                                         _lib.FPS_LOCAL_INDEX, st), "fps")
+                                                         flags, st), "fps")
 
     def _run_pipelined(self, xyz, feats, inputs_on_current_stream=True):
         p = self.step_no & 1
