@@ -74,6 +74,24 @@ def test_fps_bucket_kernel_equals_plain_kernel(dev, monkeypatch):
     assert torch.equal(a, b)
 
 
+def test_fps_low_valu_hint_changes_the_kernel_not_the_result(dev, oracle):
+    """TGN_FPS_LOW_VALU (include/tgn_pointops.h): clouds of 2048-4096 points on the bucket-skipping kernel -- a scheduling
+    hint of the phased HotPath schedule; indices and coordinates must be those of the default launch and of the oracle."""
+    from toothgroupnetwork_amd import _lib
+    L = _lib.lib()
+    for n, m in [(4096, 1024), (3000, 700), (2048, 2048)]:
+        xyz_np = np.stack([synth.arch_cloud(n, s, False) for s in (50, 51, 52)])
+        xyz = T(xyz_np, dev)
+        outs = []
+        for flags in (_lib.FPS_LOCAL_INDEX, _lib.FPS_LOCAL_INDEX | _lib.FPS_LOW_VALU):
+            idx = torch.empty(3, m, dtype=torch.int32, device=dev)
+            nx = torch.empty(3, m, 3, dtype=torch.float32, device=dev)
+            _lib.check(L.tgn_furthestsampling_dense(3, n, m, _lib.ptr(xyz), None, _lib.ptr(idx), _lib.ptr(nx), flags, _lib.stream()), "fps")
+            outs.append((idx.cpu().numpy(), nx.cpu().numpy()))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), (n, m)
+        assert np.array_equal(outs[1][0], oracle.farthest_point_sample(xyz_np, m)), (n, m)
+
+
 def test_fps_packed_ragged_batch_and_modes(dev, oracle, regression):
     from toothgroupnetwork_amd import _lib, pointops as P
     r = regression
