@@ -133,7 +133,8 @@ class PointTransformerLayer(nn.Module):
         # operator to bf16 costs a cast pass over those tensors each time (measured: 298 ms per step against 114 in fp32).
         with torch.autocast("cuda", enabled=False):
             x_q, x_k, x_v = x_q.float(), x_k.float(), x_v.float()
-            x_kg = pointops.queryandgroup(self.nsample, p, p, x_k.contiguous(), idx, o, o, use_xyz=True)   # (n, nsample, 3+c)
+            # (idx comes from this package's kNN: no index check, i.e. no host round trip per layer)
+            x_kg = pointops._QueryGroup.apply(p, p, x_k.contiguous(), idx, True)                            # (n, nsample, 3+c)
             p_r, x_kg = x_kg[:, :, 0:3], x_kg[:, :, 3:]
             for i, layer in enumerate(self.linear_p):
                 p_r = layer(p_r.transpose(1, 2).contiguous()).transpose(1, 2).contiguous() if i == 1 else layer(p_r)
