@@ -413,8 +413,8 @@ constexpr int kBmHitCap = 256;
 
 // Cost: the kernel is bound by vector-ALU issue (a wave64 instruction holds its SIMD for 4 cycles; the rank-select kernel
 // spends ~430 of them per query), so this one is written for few instructions on the common path:
-//   * a run is served by 7 lanes (9 runs x 7 = 63 lanes), three records per lane: 21 records per run without a loop
-//     (a run holds ~15 on a scan surface; longer ones take a tail loop), run number and column are per-lane constants;
+//   * the candidates are one flattened list over the <= 9 runs; the first 192 of them (three per lane) are requested at
+//     once, so the common query never loops and pays one record-load latency;
 //   * records, cell table and the output row go through buffer descriptors (32-bit offsets, out-of-range lanes read 0);
 //   * the cell-table look-ups of the wave's NEXT query are issued before the current one is processed.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t ball_rsrc(const void *base, unsigned bytes) {   // wave-uniform base
@@ -451,7 +451,6 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
     const long long total = (long long)B * S;
     const size_t cloud_bytes = grid_cloud_bytes(N);
     const size_t rec_off = sizeof(GridHeader) + (size_t)((kGridCells + 1 + 3) / 4 * 4) * sizeof(int);
-    const int run = lane / 7, col = lane - run * 7;   // lanes 0..62 -> runs 0..8; lane 63 -> "run 9" (empty)
     const int dy = lane % 3 - 1, dz = lane / 3 - 1;   // lanes 0..8: the (dy, dz) x-run this lane looks up
     // XCD x (hardware block i runs on XCD i % 8) owns the contiguous query range [x*q_per_xcd, (x+1)*q_per_xcd) -- whole
     // clouds when there are at least 8 -- and its blocks, no more than are resident at a time, walk it together: a cloud's
@@ -523,14 +522,33 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
         };
         const float cx = cur.cx, cy = cur.cy, cz = cur.cz;
         const float s1 = sumsq3(cx, cy, cz);
-        const int j0 = __shfl(cur.rs, run) + col;   // my first record of my run
-        const int je = __shfl(cur.re, run);
-        // three records per lane in flight: 21 per run
+        // The <= 9 runs are walked as ONE flattened candidate list (on a scan surface the candidates sit in ~3 long runs,
+        // not 9 short ones: fixed lane groups per run leave most lanes idle and the rest looping).  Lane r < 9 holds run
+        // r's [rs, re); pre = records before it (inclusive scan over one DPP row); candidate g lives in run
+        // #{t : ends[t] <= g} at record g + delta[run].  The first 192 candidates are requested at once.
+        const int len = cur.re - cur.rs;
+        int pre = len;
+        pre += (int)dpp_or_zero<0x111, 0xF>((unsigned)pre);
+        pre += (int)dpp_or_zero<0x112, 0xF>((unsigned)pre);
+        pre += (int)dpp_or_zero<0x114, 0xF>((unsigned)pre);
+        pre += (int)dpp_or_zero<0x118, 0xF>((unsigned)pre);
+        const int T = __builtin_amdgcn_readlane(pre, 8);   // lanes 9.. have len 0
+        const int delta = cur.rs - (pre - len);
+        int ends[8];                                        // wave-uniform run ends in the flattened list
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ends[r] = __builtin_amdgcn_readlane(pre, r);
+        auto record_of = [&](int g) -> int {               // flattened candidate -> record index
+            int r = 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) r += (g >= ends[t]) ? 1 : 0;
+            return g + __shfl(delta, r);
+        };
         u32x4 p[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int j = j0 + 7 * i;
-            p[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, j < je ? (unsigned)j * 16u : 0xFFFFFFF0u, 0, 0);
+            const int g = 64 * i + lane;
+            const int j = record_of(g);
+            p[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, g < T ? (unsigned)j * 16u : 0xFFFFFFF0u, 0, 0);
         }
         // the next query's cell-table look-ups go out behind them and land while this query is processed
         BallRuns nxt;
@@ -555,7 +573,7 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
             H += __popcll(mask);
         };
 #pragma unroll
-        for (int i = 0; i < 3; ++i) record(j0 + 7 * i < je && test(p[i]), (int)p[i][3]);
+        for (int i = 0; i < 3; ++i) record(64 * i + lane < T && test(p[i]), (int)p[i][3]);
         // rank of index v = number of set bits below it (valid once gbase is up to date)
         auto rank_of = [&](int v) -> int {
             const unsigned g = (unsigned)v >> 7, wsel = ((unsigned)v >> 5) & 3u, below = (1u << (v & 31)) - 1u;
@@ -568,13 +586,14 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
             return r;
         };
         int first = 0x7FFFFFFF;   // the hit of rank 0, in the lane that holds it
-        // the records beyond the first 21 of a run (pass 0), or every record again (pass 1: the hit list overflowed and
-        // each hit is ranked straight from the bitmap)
+        // the candidates beyond the first 192 (pass 0), or every candidate again (pass 1: the hit list overflowed and each
+        // hit is ranked straight from the bitmap)
         auto walk = [&](const int pass) {
-            int j = j0 + (pass == 0 ? 21 : 0);
-            while (__any(j < je)) {
-                const u32x4 pp = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, j < je ? (unsigned)j * 16u : 0xFFFFFFF0u, 0, 0);
-                const bool hit = j < je && test(pp);
+            for (int g0 = pass == 0 ? 192 : 0; g0 < T; g0 += kWave) {
+                const int g = g0 + lane;
+                const int j = record_of(g);
+                const u32x4 pp = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, g < T ? (unsigned)j * 16u : 0xFFFFFFF0u, 0, 0);
+                const bool hit = g < T && test(pp);
                 const int pidx = (int)pp[3];
                 if (pass == 0) {
                     record(hit, pidx);
@@ -583,10 +602,9 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
                     if (r < K) put(r, pidx);
                     if (r == 0) first = pidx;
                 }
-                j += 7;
             }
         };
-        if (__any(j0 + 21 < je)) walk(0);
+        if (T > 192) walk(0);
         if (H == 0) {   // wave-uniform; the bitmap is still clean
             for (int j = lane; j < K; j += kWave) put(j, N);  // no hit at all -> N (:136-141)
             cur = nxt;
