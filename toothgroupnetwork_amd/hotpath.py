@@ -67,7 +67,7 @@ class HotPath:
 
     def __init__(self, B, device, shape=SHAPE_A, xyz_first=True, index_dtype=torch.int32, pipeline=False,
                  fps_prefix=False, group_impl=0, group_policy=-1, group_max_blocks=None, fused=False, ball_stream=None,
-                 group_gate=None, early_grid=None, ball_split=False):
+                 group_gate=None, early_grid=None, ball_split=False, grid_stream=False, low_valu=True):
         self.B, self.device, self.shape = B, device, shape
         # launch knobs of the grouping kernel (include/tgn_pointops.h, tgn_group_points_ex).  In the pipelined schedule its
         # grid is bounded to what fits beside the FPS level-1 workgroups, so that those never wait for a CU to drain:
@@ -98,6 +98,7 @@ class HotPath:
         self.ball_stream = (2 if dflt else 0) if ball_stream is None else (int(ball_stream) if pipeline else 0)
         self.group_gate = dflt if group_gate is None else (bool(group_gate) and pipeline)
         self.early_grid = (self.ball_stream == 2) if early_grid is None else (bool(early_grid) and self.ball_stream == 2)
+        self.low_valu = bool(low_valu)
         if pipeline:
             self.s_fps = torch.cuda.Stream(device=device, priority=-1)
             self.s_rest = torch.cuda.Stream(device=device, priority=0)
@@ -110,6 +111,9 @@ class HotPath:
             self.ev_ball = [[torch.cuda.Event() for _ in shape["npoint"]] for _ in range(2)]
             self.ev_fps = [[torch.cuda.Event() for _ in shape["npoint"]] for _ in range(2)]
             self.ev_grid = [torch.cuda.Event() for _ in range(2)]
+            # the early level-1 grid on a stream of its own (released when the previous step's FPS level 1 is done, i.e. at
+            # the start of phase 2) instead of behind FPS level 3 on stream F
+            self.s_grid = torch.cuda.Stream(device=device, priority=-1) if (self.early_grid and grid_stream) else None
             self.ev_done = [torch.cuda.Event() for _ in range(2)]
             self.ev_start = torch.cuda.Event()
 
@@ -240,7 +244,7 @@ class HotPath:
         # phased schedule: FPS levels 2-3 run beside the ball queries, which are bound by vector-ALU issue -- the bucket-skipping
         # kernel issues a tenth of the plain kernel's vector instructions (0.86 vs 0.75 ms for level 2 itself, but the level-1
         # ball query beside it 1.10 instead of 1.28 ms)
-        flags = _lib.FPS_LOCAL_INDEX | (_lib.FPS_LOW_VALU if (self.pipeline and self.ball_stream == 2 and i > 0) else 0)
+        flags = _lib.FPS_LOCAL_INDEX | (_lib.FPS_LOW_VALU if (self.low_valu and self.pipeline and self.ball_stream == 2 and i > 0) else 0)
         if not self.fps_prefix:
             return check(L.tgn_furthestsampling_dense(self.B, lv["N"], lv["S"], ptr(cur_xyz), None, ptr(lv["fps_idx"]),
                                                       ptr(lv["new_xyz"]), flags, st), "fps")
@@ -267,9 +271,19 @@ class HotPath:
         if self.early_grid:
             # the level-1 grid depends on the input cloud only: it goes onto stream F BEFORE the fence below, i.e. behind
             # the previous step's FPS level 3, where stream F would otherwise idle until that step's ball queries are done
+            sq = self.s_grid if self.s_grid is not None else sf
+            if self.s_grid is not None:
+                if inputs_on_current_stream or self.step_no == 0:
+                    sq.wait_event(self.ev_start)
+                if self.step_no >= 1:
+                    sq.wait_event(self.ev_fps[1 - p][0])     # not beside an FPS level-1 workgroup: phase 2 of the previous step
+                if self.step_no >= 2:
+                    sq.wait_event(self.ev_done[p])
             for br in levels[0]["branches"]:
-                self._ball_build(levels[0], br, xyz, pf)
-            self.ev_grid[p].record(sf)
+                self._ball_build(levels[0], br, xyz, _lib.c_void_p(sq.cuda_stream))
+            self.ev_grid[p].record(sq)
+            if self.s_grid is not None:
+                sf.wait_event(self.ev_grid[p])               # ... and out of the way before this step's level 1 starts
         if self.ball_stream == 2 and self.step_no >= 1:
             sf.wait_event(self.ev_ball[1 - p][-1])   # phased: the previous step's ball queries are through
             if sb2 is not None:
