@@ -127,7 +127,7 @@ def main():
                  group_max_blocks=None if mb == -1 else mb, fused=bool(args.fused),
                  ball_stream=None if args.ball_stream < 0 else args.ball_stream,
                  group_gate=None if args.group_gate < 0 else bool(args.group_gate),
-                 early_grid=None if args.early_grid < 0 else bool(args.early_grid), ball_split=bool(args.ball_split), grid_stream=bool(args.grid_stream),
+                 early_grid=None if args.early_grid < 0 else bool(args.early_grid), ball_split=int(args.ball_split), grid_stream=bool(args.grid_stream),
                  low_valu=bool(args.low_valu))
     if args.fused and args.shape != "A":
         raise SystemExit("--fused is defined for shape A (single-scale levels)")

@@ -67,7 +67,7 @@ class HotPath:
 
     def __init__(self, B, device, shape=SHAPE_A, xyz_first=True, index_dtype=torch.int32, pipeline=False,
                  fps_prefix=False, group_impl=0, group_policy=-1, group_max_blocks=None, fused=False, ball_stream=None,
-                 group_gate=None, early_grid=None, ball_split=False, grid_stream=False, low_valu=True):
+                 group_gate=None, early_grid=None, ball_split=0, grid_stream=False, low_valu=True):
         self.B, self.device, self.shape = B, device, shape
         # launch knobs of the grouping kernel (include/tgn_pointops.h, tgn_group_points_ex).  In the pipelined schedule its
         # grid is bounded to what fits beside the FPS level-1 workgroups, so that those never wait for a CU to drain:
@@ -103,11 +103,14 @@ class HotPath:
             self.s_fps = torch.cuda.Stream(device=device, priority=-1)
             self.s_rest = torch.cuda.Stream(device=device, priority=0)
             self.s_ball = torch.cuda.Stream(device=device, priority=-1) if self.ball_stream else None
-            # ball_split (experiment, off): the queries of levels 2, 3 on a stream of their own -- they depend on FPS levels 2, 3
-            # only and otherwise queue behind the level-1 query.  Measured: 5.79 ms per step against 5.65 -- phase 2 is bound by
-            # vector-ALU issue, the queries only take each other's issue slots
-            self.s_ball2 = torch.cuda.Stream(device=device, priority=-1) if (self.ball_stream == 2 and ball_split) else None
-            self.ev_ball2 = [torch.cuda.Event() for _ in range(2)]
+            # ball_split (experiments, off).  2: the LAST level's query (a scan over 1024-point clouds, it needs FPS level 3
+            # only) on a second query stream instead of behind the level-2 query, and the grids of levels > 1 built there as
+            # soon as the FPS level that produces their cloud is done: 5.195 ms per step against 5.18 -- the small kernels at
+            # the tail of phase 2 slow each other down by what the overlap gains.  1: levels 2 AND 3 on the second stream:
+            # 5.44 ms (the level-2 query then takes issue slots from the level-1 query)
+            self.ball_split = int(ball_split) if self.ball_stream == 2 else 0
+            self.s_ball2 = torch.cuda.Stream(device=device, priority=-1) if self.ball_split else None
+            self.ev_lgrid = [[torch.cuda.Event() for _ in shape["npoint"]] for _ in range(2)]
             self.ev_ball = [[torch.cuda.Event() for _ in shape["npoint"]] for _ in range(2)]
             self.ev_fps = [[torch.cuda.Event() for _ in shape["npoint"]] for _ in range(2)]
             self.ev_grid = [torch.cuda.Event() for _ in range(2)]
@@ -285,21 +288,31 @@ class HotPath:
             if self.s_grid is not None:
                 sf.wait_event(self.ev_grid[p])               # ... and out of the way before this step's level 1 starts
         if self.ball_stream == 2 and self.step_no >= 1:
-            sf.wait_event(self.ev_ball[1 - p][-1])   # phased: the previous step's ball queries are through
-            if sb2 is not None:
-                sf.wait_event(self.ev_ball[1 - p][0])
+            for ev in (self.ev_ball[1 - p] if sb2 is not None else self.ev_ball[1 - p][-1:]):
+                sf.wait_event(ev)                    # phased: the previous step's ball queries are through
         cur_xyz = xyz
+        nl = len(levels)
+        split = self.ball_split if sb2 is not None else 0
         for i, lv in enumerate(levels):
             self._timed(f"fps_l{i + 1}", lambda: self._fps(i, lv, cur_xyz, levels, pf), sf)
             if sb is None:
                 self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, cur_xyz, pf) for br in lv["branches"]], sf)
             self.ev_fps[p][i].record(sf)
             if sb is not None:
-                sq, pq = (sb2, pb2) if (sb2 is not None and i > 0) else (sb, pb)
+                if split == 2 and i + 1 < nl:
+                    # the next level's grid: its cloud (this level's samples) exists now
+                    sb2.wait_event(self.ev_fps[p][i])
+                    for br in levels[i + 1]["branches"]:
+                        self._ball_build(levels[i + 1], br, lv["new_xyz"], pb2)
+                    self.ev_lgrid[p][i + 1].record(sb2)
+                on2 = (split == 1 and i > 0) or (split == 2 and i == nl - 1 and i > 0)
+                sq, pq = (sb2, pb2) if on2 else (sb, pb)
                 sq.wait_event(self.ev_fps[p][i])
-                pre = self.early_grid and i == 0
-                if pre:
+                pre = (self.early_grid and i == 0) or (split == 2 and i > 0)
+                if self.early_grid and i == 0:
                     sq.wait_event(self.ev_grid[p])
+                if split == 2 and i > 0:
+                    sq.wait_event(self.ev_lgrid[p][i])
                 self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, cur_xyz, pq, prebuilt=pre) for br in lv["branches"]], sq)
                 self.ev_ball[p][i].record(sq)
             cur_xyz = lv["new_xyz"]
@@ -308,9 +321,8 @@ class HotPath:
         for i, lv in enumerate(levels):
             if self.group_gate:
                 if i == 0:
-                    sg.wait_event(ev_q[p][-1])   # all of this step's groupings run beside the NEXT step's FPS level 1
-                    if sb2 is not None:
-                        sg.wait_event(ev_q[p][0])
+                    for ev in (ev_q[p] if sb2 is not None else ev_q[p][-1:]):
+                        sg.wait_event(ev)            # all of this step's groupings run beside the NEXT step's FPS level 1
             else:
                 sg.wait_event(ev_q[p][i])
             self._timed(f"group_l{i + 1}", lambda: self._consume(i, lv, cur_xyz, feats, levels, pg), sg)
