@@ -526,19 +526,29 @@ __global__ __launch_bounds__(64) void group_points_rows_kernel(
             float *img = lds_img + (ib & 1u) * IMG + (k0 * C & 31u);
             const unsigned rows = (unsigned)K - k0 < (unsigned)R ? (unsigned)K - k0 : (unsigned)R;
             if (DBG & 1) return rows;
+            auto piece = [&](float *dst, unsigned soff, unsigned p) {   // (the size operand must be a literal)
+                if constexpr (W == 4)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pts, (__attribute__((address_space(3))) void *)(dst + p * FP), 16,
+                                                             lane4, soff + p * FP * 4u, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pts, (__attribute__((address_space(3))) void *)(dst + p * FP), 4,
+                                                             lane4, soff + p * FP * 4u, 0, 0);
+            };
+            if (pieces == 1u) {
+                // one (partial) instruction per row -- level 2: the lane mask is set ONCE around the whole loop and the loop is
+                // readlane + M0 + DMA (the general form below re-derives the mask and tests an empty inner loop per row: ~22
+                // scalar instructions per 512 B, which is what a lone wave beside an FPS workgroup is bound by)
+                if (lane < last_len) {
+                    for (unsigned r = 0; r < rows; ++r)
+                        piece(img + r * C + fo, (unsigned)__builtin_amdgcn_readlane((int)r0, (int)(k0 + r)), 0u);
+                }
+                return rows;
+            }
             for (unsigned r = 0; r < rows; ++r) {
                 const unsigned soff = (unsigned)__builtin_amdgcn_readlane((int)r0, (int)(k0 + r));
                 float *dst = img + r * C + fo;
-                auto piece = [&](unsigned p) {   // (the size operand must be a literal)
-                    if constexpr (W == 4)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pts, (__attribute__((address_space(3))) void *)(dst + p * FP), 16,
-                                                                 lane4, soff + p * FP * 4u, 0, 0);
-                    else
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pts, (__attribute__((address_space(3))) void *)(dst + p * FP), 4,
-                                                                 lane4, soff + p * FP * 4u, 0, 0);
-                };
-                for (unsigned p = 0; p + 1u < pieces; ++p) piece(p);
-                if (lane < last_len) piece(pieces - 1u);
+                for (unsigned p = 0; p + 1u < pieces; ++p) piece(dst, soff, p);
+                if (lane < last_len) piece(dst, soff, pieces - 1u);
             }
             return rows;
         };
