@@ -324,7 +324,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
                             const unsigned long long eq = ballot64(nd == mx);
                             bool win = nd == mx;
                             const unsigned ko = TREE ? compat_key((int)o, log2bs) : o;
-                            if (__popcll(eq) != 1) {  // exact tie inside the bucket (rare): the smallest tie key wins
+                            if (__builtin_expect(__popcll(eq) != 1, 0)) {  // exact tie inside the bucket (rare): the smallest tie key wins
                                 const unsigned kl = win ? ko : 0xFFFFFFFFu;
                                 const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kl));
                                 win = win && kl == kmin;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             const bool cand = ((cm >> lane) & 1ull) != 0ull;
             const unsigned kl = cand ? __float_as_uint(pm.w) : 0xFFFFFFFFu;
             int sl = cm ? __builtin_ctzll(cm) : 0;
-            if (__popcll(cm) > 1) {
+            if (__builtin_expect(__popcll(cm) > 1, 0)) {
                 const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kl));
                 sl = __builtin_ctzll(ballot64(kl == kmin));
             }
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             if constexpr (CERT) cert.update(mb);
             const unsigned long long wmask = ballot64(vb == mb) & ((1ull << NW) - 1ull);  // lanes 0..NW-1 hold the records
             int wl = __builtin_ctzll(wmask);
-            if (__popcll(wmask) > 1) {  // equal maxima in several waves (rare): the smallest tie key wins
+            if (__builtin_expect(__popcll(wmask) > 1, 0)) {  // equal maxima in several waves (rare): the smallest tie key wins
                 const unsigned kk = ((wmask >> lane) & 1ull) ? r0.y : 0xFFFFFFFFu;
                 const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kk));
                 wl = __builtin_ctzll(ballot64(kk == kmin));
