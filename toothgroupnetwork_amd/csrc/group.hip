@@ -824,7 +824,8 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
     if (impl >= 7 && !(ring_ok && K % 4 == 0 && queries < (1LL << 31))) impl = 3;
     if (impl >= 7) {
         // v5: one wave per workgroup; R rows per LDS image (multiple of 4, about 8 KiB, at most 20 rows)
-        int R = (int)(2176 / C) / 4 * 4;
+        static const int env_img = env_int("TGN_GROUP_IMAGE_FLOATS", 2176);   // floats per LDS image (experiments)
+        int R = (int)(env_img / C) / 4 * 4;
         if (R < 4) R = 4;
         if (R > 20) R = 20;
         if (R > K) R = K;
