@@ -539,8 +539,24 @@ __global__ __launch_bounds__(64) void group_points_rows_kernel(
                 // readlane + M0 + DMA (the general form below re-derives the mask and tests an empty inner loop per row: ~22
                 // scalar instructions per 512 B, which is what a lone wave beside an FPS workgroup is bound by)
                 if (lane < last_len) {
-                    for (unsigned r = 0; r < rows; ++r)
-                        piece(img + r * C + fo, (unsigned)__builtin_amdgcn_readlane((int)r0, (int)(k0 + r)), 0u);
+                    // rows is a multiple of 4 (R and K are): four rows per trip -- a taken branch costs a lone wave ~25 cycles
+                    for (unsigned r = 0; r < rows; r += 4u) {
+#pragma unroll
+                        for (unsigned i = 0; i < 4u; ++i)
+                            piece(img + (r + i) * C + fo, (unsigned)__builtin_amdgcn_readlane((int)r0, (int)(k0 + r + i)), 0u);
+                    }
+                }
+                return rows;
+            }
+            if (pieces == 2u && last_len == 64u) {   // level 3 (512-float rows): two whole instructions per row, two rows per trip
+                for (unsigned r = 0; r < rows; r += 2u) {
+#pragma unroll
+                    for (unsigned i = 0; i < 2u; ++i) {
+                        const unsigned soff = (unsigned)__builtin_amdgcn_readlane((int)r0, (int)(k0 + r + i));
+                        float *dst = img + (r + i) * C + fo;
+                        piece(dst, soff, 0u);
+                        piece(dst, soff, 1u);
+                    }
                 }
                 return rows;
             }
