@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--ball-stream", type=int, default=-1, help="-1: default (2 = phased: ball queries on a third stream beside FPS levels "
                     "2-3, fenced off from the next step's FPS level 1); 0: in line on the FPS stream; 1: third stream, free-running")
     ap.add_argument("--ball-split", type=int, default=0, help="phased schedule: ball queries of levels 2-3 on a stream of their own")
+    ap.add_argument("--group-delay-us", type=int, default=-1, help="gated schedule: hold the groupings back by this long behind the start of "
+                    "FPS level 1 (-1: default = the FPS set-up time, ~150 us at 24 000 points)")
+    ap.add_argument("--group-order", type=ilist, default=None, help="gated schedule: order of the grouping launches, e.g. 2,1,0")
     ap.add_argument("--grid-stream", type=int, default=0, help="phased schedule: the early level-1 grid on a stream of its own (experiment)")
     ap.add_argument("--low-valu", type=int, default=1, help="phased schedule: FPS level 2 on the bucket-skipping kernel (TGN_FPS_LOW_VALU)")
     ap.add_argument("--early-grid", type=int, default=-1, help="phased schedule: build the level-1 ball-query grid ahead of the fence (-1 default on)")
@@ -128,7 +131,7 @@ def main():
                  ball_stream=None if args.ball_stream < 0 else args.ball_stream,
                  group_gate=None if args.group_gate < 0 else bool(args.group_gate),
                  early_grid=None if args.early_grid < 0 else bool(args.early_grid), ball_split=int(args.ball_split), grid_stream=bool(args.grid_stream),
-                 low_valu=bool(args.low_valu))
+                 low_valu=bool(args.low_valu), group_order=args.group_order, group_delay_us=None if args.group_delay_us < 0 else args.group_delay_us)
     if args.fused and args.shape != "A":
         raise SystemExit("--fused is defined for shape A (single-scale levels)")
     hp = hotpath.HotPath(B, device, shape=shape, pipeline=bool(args.pipeline), fps_prefix=bool(args.fps_prefix), **gopts)

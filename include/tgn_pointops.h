@@ -228,6 +228,9 @@ int tgn_ball_query(int B, int N, int S, int nsample, float r2, const float *xyz,
  * not on the queries -- it can run while the sampling that produces new_xyz is still in flight), _prebuilt answers the
  * queries from a workspace filled by _build with the same (B, N, S, nsample, r2, xyz).  Same results as tgn_ball_query.
  */
+/* scheduling spacer: a one-wave kernel that idles for about `microseconds` on `stream` (planners: hold one stream's work
+ * back behind another's start without a host round trip) */
+int tgn_stream_delay(int microseconds, tgn_stream_t stream);
 int tgn_ball_query_build(int B, int N, int S, int nsample, float r2, const float *xyz, void *workspace,
                          size_t workspace_bytes, tgn_stream_t stream);
 int tgn_ball_query_prebuilt(int B, int N, int S, int nsample, float r2, const float *xyz, const float *new_xyz, void *idx,

@@ -61,3 +61,17 @@ TGN_API int tgn_take_index_error(tgn_stream_t stream) {
     if (h) (void)hipMemsetAsync(w, 0, sizeof(int), (hipStream_t)stream);
     return h;
 }
+
+// A planner's spacer: one wave that sleeps for about `microseconds` on `stream` (100 MHz wall clock).  HotPath uses it to
+// hold the groupings back until the FPS level-1 workgroups have read their clouds.
+namespace tgn {
+__global__ void delay_kernel(unsigned ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace tgn
+TGN_API int tgn_stream_delay(int microseconds, tgn_stream_t stream) {
+    if (microseconds <= 0) return TGN_OK;
+    hipLaunchKernelGGL(tgn::delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned)microseconds * 100u);
+    return tgn::check_launch("delay_kernel");
+}

@@ -67,7 +67,7 @@ class HotPath:
 
     def __init__(self, B, device, shape=SHAPE_A, xyz_first=True, index_dtype=torch.int32, pipeline=False,
                  fps_prefix=False, group_impl=0, group_policy=-1, group_max_blocks=None, fused=False, ball_stream=None,
-                 group_gate=None, early_grid=None, ball_split=0, grid_stream=False, low_valu=True):
+                 group_gate=None, early_grid=None, ball_split=0, grid_stream=False, low_valu=True, group_order=None, group_delay_us=None):
         self.B, self.device, self.shape = B, device, shape
         # launch knobs of the grouping kernel (include/tgn_pointops.h, tgn_group_points_ex).  In the pipelined schedule its
         # grid is bounded to what fits beside the FPS level-1 workgroups, so that those never wait for a CU to drain:
@@ -99,6 +99,13 @@ class HotPath:
         self.group_gate = dflt if group_gate is None else (bool(group_gate) and pipeline)
         self.early_grid = (self.ball_stream == 2) if early_grid is None else (bool(early_grid) and self.ball_stream == 2)
         self.low_valu = bool(low_valu)
+        # The first ~0.17 ms of an FPS level-1 workgroup is its set-up: it streams its cloud three times (latency-bound loads),
+        # and a grouping launch that saturates HBM at the same moment stretches it (3.59 instead of 3.46 ms for the launch).
+        # The gated groupings are therefore held back by a one-wave spacer kernel for about as long as the set-up takes
+        # (~7 ns per point of the level-1 cloud); they have the slack: 3.2 of the 3.46 ms beside FPS.
+        self.group_delay_us = (min(300, shape["n"] // 160) if (self.group_gate and not self.fused) else 0) \
+            if group_delay_us is None else int(group_delay_us)
+        self.group_order = list(group_order) if group_order else None   # gated schedule: order of the grouping launches
         if pipeline:
             self.s_fps = torch.cuda.Stream(device=device, priority=-1)
             self.s_rest = torch.cuda.Stream(device=device, priority=0)
@@ -318,15 +325,19 @@ class HotPath:
             cur_xyz = lv["new_xyz"]
         cur_xyz = xyz
         ev_q = self.ev_ball if sb is not None else self.ev_fps    # "the queries of level i are done"
-        for i, lv in enumerate(levels):
+        clouds = [xyz] + [lv["new_xyz"] for lv in levels[:-1]]      # the cloud level i groups from
+        order = self.group_order if (self.group_gate and self.group_order) else list(range(len(levels)))
+        for n_, i in enumerate(order):
+            lv, cur_xyz = levels[i], clouds[i]
             if self.group_gate:
-                if i == 0:
+                if n_ == 0:
                     for ev in (ev_q[p] if sb2 is not None else ev_q[p][-1:]):
                         sg.wait_event(ev)            # all of this step's groupings run beside the NEXT step's FPS level 1
+                    if self.group_delay_us:
+                        check(self.L.tgn_stream_delay(self.group_delay_us, pg), "stream_delay")
             else:
                 sg.wait_event(ev_q[p][i])
             self._timed(f"group_l{i + 1}", lambda: self._consume(i, lv, cur_xyz, feats, levels, pg), sg)
-            cur_xyz = lv["new_xyz"]
         self.ev_done[p].record(sg)
         cur.wait_event(self.ev_done[p])     # the caller's stream sees this step's results
         self.step_no += 1
