@@ -113,6 +113,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
     // ---- 1. bounding box of the cloud (finite values only; NaN is ignored by fmin/fmax) ----------------
     {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        #pragma unroll 4
         for (int k = tid; k < n; k += NT) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
     for (int i = tid; i < kCellWords; i += NT) cells[i] = 0u;
     for (int i = n + tid; i < CAP; i += NT) tab[fps_bucket_slot<NW>((unsigned)i)] = (unsigned short)0xFFFF;
     __syncthreads();
+    #pragma unroll 4
     for (int i = tid; i < n; i += NT) {
         const unsigned code = cell_of(i);
         atomicAdd(&cells[code >> 1], 1u << ((code & 1u) << 4));
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
         }
     }
     __syncthreads();
+    #pragma unroll 4
     for (int i = tid; i < n; i += NT) {
         const unsigned code = cell_of(i);
         const unsigned sh = (code & 1u) << 4;
