@@ -81,8 +81,8 @@ def cpu_baseline(scans, budget_meshes, shape):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="scans per step per GPU (one FPS workgroup per scan)")
     ap.add_argument("--cpu-meshes", type=int, default=-1, help="CPU-baseline sample size (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
