@@ -274,6 +274,9 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
     // compile-time switch: even never-taken `if (dbg)` branches cost a lone wave ~10 cycles each per iteration
     constexpr bool dbg = DBG;
     unsigned long long st_skip = 0, st_touched = 0, st_waves = 0, cyA = 0, cyU = 0, cyB = 0, cyC = 0, cyC1 = 0, cyC2 = 0;
+    unsigned long long dbg_sum_max = 0, dbg_crit_is_winner = 0, dbg_crit_dirty = 0, dbg_crit_touched = 0, dbg_sum_winner = 0;
+    unsigned dbg_prev_winner = 0;
+    bool dbg_dirty = false;
 
     for (int j = 1; j < m; ++j) {
         long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
@@ -351,6 +354,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
         }
         if (dbg) t2 = clock64();
         // ---- B. wave candidate = max over my bucket maxima (recomputed only if a bucket changed) ---------
+        if (dbg) dbg_dirty = dirty;
         if (dirty) {
             // the arg-max records of ALL my buckets (coordinates, tie key) are requested BEFORE the reduction that says which
             // one is wanted: the LDS round trip then hides behind the six DPP steps instead of following them (this is the
@@ -391,7 +395,13 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
                 *(float3 *)(recb + wr_off + 16) = make_float3(wx, wy, wz);
             }
             long long tc1 = 0, tc2 = 0;
-            if (dbg) tc1 = clock64();
+            if (dbg) {
+                tc1 = clock64();
+                // (instrumented build) my pre-barrier time, my touched / refreshed bucket counts and whether I searched for a
+                // new candidate, into the spare bytes of my record
+                if (lane == 0)
+                    *(uint2 *)(recb + wr_off + 8) = make_uint2((unsigned)(tc1 - t0), (unsigned)__popcll(mask) | (dbg_dirty ? 0x100u : 0u));
+            }
             __syncthreads();
             if (dbg) {
                 tc2 = clock64();
@@ -402,6 +412,25 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             // every lane reads record lane % NW (no exec juggling); lanes 0..NW-1 are the ones that count
             const uint2 r0 = *(const uint2 *)(recb + rd_off);
             const float3 r1 = *(const float3 *)(recb + rd_off + 16);  // same LDS round trip
+            if (dbg && wave == 0) {   // who was the slowest wave of this iteration, and was it last iteration's winner?
+                const uint2 dd_ = *(const uint2 *)(recb + rd_off + 8);
+                unsigned tmax = 0, wmax_ = 0, info = 0;
+                for (int w = 0; w < NW; ++w) {
+                    const unsigned tw = (unsigned)__builtin_amdgcn_readlane((int)dd_.x, w);
+                    const unsigned iw = (unsigned)__builtin_amdgcn_readlane((int)dd_.y, w);
+                    if (tw > tmax) {
+                        tmax = tw;
+                        wmax_ = (unsigned)w;
+                        info = iw;
+                    }
+                }
+                dbg_sum_max += tmax;
+                dbg_crit_is_winner += (wmax_ == dbg_prev_winner) ? 1 : 0;
+                dbg_crit_dirty += (info >> 8) & 1u;
+                dbg_crit_touched += info & 0xFFu;
+                const unsigned tw_ = (unsigned)__builtin_amdgcn_readlane((int)dd_.x, (int)dbg_prev_winner);
+                dbg_sum_winner += tw_;
+            }
             rd_off ^= kRecParity;  // double-buffered by iteration parity: one barrier per iteration is enough
             wr_off ^= kRecParity;
             const unsigned vb = r0.x;
@@ -427,6 +456,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
                 const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kk));
                 wl = __builtin_ctzll(ballot64(kk == kmin));
             }
+            if (dbg) dbg_prev_winner = (unsigned)wl;
             kwin = (unsigned)__builtin_amdgcn_readlane((int)r0.y, wl);
             qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.x), wl));
             qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.y), wl));
@@ -470,6 +500,11 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             st[6] = (unsigned long long)(m - 1);
             st[7] = cyC1;
             st[8] = cyC2;
+            st[10] = dbg_sum_max;
+            st[11] = dbg_crit_is_winner;
+            st[12] = dbg_crit_dirty;
+            st[13] = dbg_crit_touched;
+            st[14] = dbg_sum_winner;
         }
         atomicAdd(&st[9], st_skip);
         if (false) {
