@@ -55,3 +55,28 @@ def test_fps_and_group_kernels_can_share_a_cu():
     for name, (v, s, _) in fps.items():
         if ", 0, false, 4>" in name and "56" not in name:
             assert s == 0, f"{name} spills"
+
+
+def _isa(src):
+    out = os.path.join("/tmp", "tgn_isa_" + src.replace(".hip", ".s"))
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-munsafe-fp-atomics",
+                    "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, src)], check=True, capture_output=True)
+    return open(out).read()
+
+
+def _kernel_body(isa, mangled_prefix):
+    start = isa.index("\n" + mangled_prefix)
+    return isa[start:isa.index("s_endpgm", start)]
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_wide_builtin_loads_are_not_narrowed():
+    """hipcc 7.2 has narrowed `raw_buffer_load_b64 / _b96 / _b128` whose components are used one by one to a single dword
+     -- silently wrong data.  The kernels that rely on 16-byte builtin loads must still contain them."""
+    ball = _isa("ball_query.hip")
+    for idx_t in ("i", "x"):
+        body = _kernel_body(ball, f"_ZN3tgn29ball_grid_query_bitmap_kernelI{idx_t}EE")
+        assert body.count("buffer_load_dwordx4") >= 3, "the record loads of the ball query were narrowed"
+    sa = _isa("sa.hip")
+    for name in ("_ZN3tgn20sa_gather_max_kernelIiEE", "_ZN3tgn20sa_gather_max_kernelIxEE"):
+        assert _kernel_body(sa, name).count("buffer_load_dwordx4") >= 1, name
