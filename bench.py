@@ -81,7 +81,7 @@ def cpu_baseline(scans, budget_meshes, shape):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="scans per step per GPU (one FPS workgroup per scan)")
     ap.add_argument("--cpu-meshes", type=int, default=-1, help="CPU-baseline sample size (0 = skip)")
@@ -202,6 +202,16 @@ def main():
         if kind == "fps":
             S = shape["npoint"][lvl]
             out["roofline"]["us_per_fps_iteration"] = 1e3 * avg[dom] / max(S - 1, 1)
+            # the vector-ALU view of the same launch: what the reference's brute-force update -- 3 sub, 3 mul, 2 add, 1 min per
+            # point and sample (sampling_cuda_kernel.cu:50-56) -- amounts to, against the fp32 vector peak
+            n_in = shape["n"] if lvl == 0 else shape["npoint"][lvl - 1]
+            flops = 9.0 * n_in * max(S - 1, 0) * B
+            out["roofline"]["valu"] = {"algorithmic_flops_per_launch": flops, "achieved_TFLOPs": flops / (avg[dom] * 1e-3) / 1e12,
+                                       "peak_TFLOPs_fp32_vector": 157.3, "frac": flops / (avg[dom] * 1e-3) / 1e12 / 157.3,
+                                       "note": "9 flop per point and sample is the brute-force update; the bucket kernel skips most of "
+                                               "it (~55 VALU instructions per wave and iteration instead of ~420, "
+                                               "profiles/r02_pmc_sq_counters.txt) and is bound by the dependency chain of one "
+                                               "iteration in the wave that holds the new sample, so this is not a utilisation figure"}
         # HBM bytes per launch from the PMC passes committed under profiles/ (tools/gpu_pmc.sh; same workload)
         pmc = {}
         for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):

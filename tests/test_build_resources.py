@@ -44,9 +44,10 @@ def test_fps_and_group_kernels_can_share_a_cu():
         assert gs == 0 and gv <= 48, f"{name} uses {gv} VGPRs (> 48: does not fit beside the FPS workgroup)"
     assert lds + 4 * rows_lds <= 160 * 1024
     # level 1 (9-float rows): the pairs kernel, one wave per SIMD = one 256-thread workgroup per CU
-    nv, ns, nlds = g["tgn::group_points_pairs_kernel<int, 6, 16>"]
-    assert ns == 0 and nv <= 48, f"pairs grouping kernel uses {nv} VGPRs (> 48: does not fit beside the FPS workgroup)"
-    assert lds + nlds <= 160 * 1024
+    for idx_t in ("int", "long long"):
+        nv, ns, nlds = g[f"tgn::group_points_pairs_kernel<{idx_t}, 6, 16>"]
+        assert ns == 0 and nv <= 48, f"pairs grouping kernel ({idx_t}) uses {nv} VGPRs (> 48: does not fit beside the FPS workgroup)"
+        assert lds + nlds <= 160 * 1024
     # the LDS-light fallback (shapes the two above do not take): two waves per SIMD
     gv, gs, glds = g["tgn::group_points_v2_kernel<int, 16, true>"]
     assert gs == 0 and gv <= 24, f"v2 grouping kernel uses {gv} VGPRs (> 24: only one wave fits beside the FPS workgroup)"

@@ -629,7 +629,8 @@ __global__ __launch_bounds__(64) void group_points_rows_kernel(
 // they lie in memory (row stride C floats, odd for the usual C = 9: conflict-free); the image -- 64*C*4 bytes, whole
 // 128-B lines, line-aligned -- then leaves as 16 B per lane.  ~45 instructions per 2.3 KiB instead of the per-element
 // walk of v2<WIDE = false> (5 four-byte gathers and a multiply-high per lane and KiB).  Two chunks per loop trip, all
-// loads of both issued before either is consumed; chunk = 64 consecutive pairs of one scan (S*K % 64 == 0, K a power of
+// loads of both issued before either is consumed, and the index loads of the NEXT trip issued right behind them (one
+// exposed round trip per trip instead of two); chunk = 64 consecutive pairs of one scan (S*K % 64 == 0, K a power of
 // two, so a query never straddles lanes of different chunks in a way that matters: q = pair >> log2(K)).
 // XCD x walks the contiguous chunk range [x*cpx, (x+1)*cpx): whole scans when B is a multiple of 8.
 template <typename IdxT, int D, int POLICY>
@@ -708,10 +709,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void grou
     // scan of a chunk, tracked incrementally in SGPRs (b = c / cps, r = c % cps): no division in the loop
     unsigned b1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(c / cps));
     unsigned r1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(c - b1 * cps));
+    // The indices of a trip are fetched one trip ahead, behind the gathers of the trip before: a lone wave per SIMD (the
+    // kernel's place beside the sampling) pays every dependent round trip in full, and index -> gather -> store was two.
+    // (not with 64-bit indices and 9-float rows: the four extra registers would push the kernel past 48 VGPRs)
+    constexpr bool AHEAD = !(sizeof(IdxT) == 8 && D == 6);
+    auto second = [&](unsigned cc) { return cc + nwx < c_end ? cc + nwx : cc; };   // no second chunk: the first again
+    long long raw1 = 0, raw2 = 0;
+    if constexpr (AHEAD) {
+        raw1 = load_index(c);
+        raw2 = load_index(second(c));
+    }
 #pragma unroll 1
     for (; c < c_end; c += 2u * nwx) {
         const bool has2 = c + nwx < c_end;                       // wave-uniform
-        const unsigned c2 = has2 ? c + nwx : c;                   // no second chunk: the first again, its stores disabled
+        const unsigned c2 = has2 ? c + nwx : c;                   // (its stores disabled when it is the first again)
         unsigned b2 = b1, r2 = r1;
         if (has2) {
             r2 += nwx;
@@ -721,11 +732,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void grou
             }
         }
         Chunk k1, k2;
-        const long long raw1 = load_index(c), raw2 = load_index(c2);   // both in flight before either is looked at
+        if constexpr (!AHEAD) {
+            raw1 = load_index(c);
+            raw2 = load_index(c2);
+        }
         k1.v = checked_index(raw1, N, bad);
         k2.v = checked_index(raw2, N, bad);
         gather(c, b1, k1);
         gather(c2, b2, k2);
+        if constexpr (AHEAD) {
+            const unsigned cn = c + 2u * nwx < c_end ? c + 2u * nwx : c;   // next trip (or this one again: in range, unused)
+            raw1 = load_index(cn);
+            raw2 = load_index(second(cn));
+        }
         emit(c, k1, img[wv][0], true);
         emit(c2, k2, img[wv][1], has2);
         b1 = b2;
