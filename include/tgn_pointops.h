@@ -245,7 +245,7 @@ int tgn_group_points(int B, int N, int S, int K, int D, const float *xyz, const 
 /*
  * The same with the launch knobs exposed.  impl: 0 = choose, 1 = 4-B stores, 2 = 16-B stores through LDS (needs
  * K*(3+D) % 4 == 0).  store_policy: cache-policy bits of the 16-B output stores (0 plain, 2 nt, 16 sc1 = write-through,
- * the output lines do not stay in L2; -1 = default).  max_blocks: upper bound on the grid (0 = none) for callers
+ * the output lines do not stay in L2; -1 = the kernel's default: nt for the LDS-image kernels, sc1 for the others).  max_blocks: upper bound on the grid (0 = none) for callers
  * that overlap the grouping with a kernel that needs most of every CU (the FPS level-1 workgroups).
  */
 int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *xyz, const float *new_xyz,

@@ -787,7 +787,7 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
         return TGN_ERR_UNSUPPORTED;
     }
     static const int env_impl = env_int("TGN_GROUP_IMPL", 0);
-    static const int env_policy = env_int("TGN_GROUP_POLICY", 16);
+    static const int env_policy = env_int("TGN_GROUP_POLICY", -1);   // -1: per kernel, below
     static const int env_blocks = env_int("TGN_GROUP_MAX_BLOCKS", 0);
     const bool exact = impl != 4;   // impl 4: the ring kernel with the conservative wait counts (stores not counted)
     if (impl == 4) impl = 3;
@@ -810,6 +810,10 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
         if (impl == 10 && !pairs_ok) impl = 0;
         if (impl == 0 && pairs_ok && C < 64) impl = 10;
         if (impl == 10) {
+            // default policy of the image kernels (pairs, row pieces): nt.  Measured at every grid bound and beside the FPS
+            // workgroups (profiles/r02_run8_extra_bench.txt): pairs 0.65 vs 0.67-0.86 ms with sc1, rows 1.29 / 1.00 vs 1.30-1.35 /
+            // 1.06-1.09 ms; their gather source stays in L2 either way (1.0x traffic, r02_pmc_traffic.json)
+            if (store_policy < 0) store_policy = 2;
             const unsigned cps = (unsigned)(pairs_per_scan / 64), chunks = (unsigned)B * cps;
             const unsigned cpx = B % 8 == 0 ? (unsigned)(B / 8) * cps : (chunks + 7u) / 8u;
             int log2K = 0;
@@ -839,7 +843,8 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
             return check_launch("group_points_pairs_kernel");
         }
     }
-    if ((impl == 5 || impl == 6 || impl == 8 || impl == 9) && !(ring_ok && store_policy == 16)) impl = 3;   // debug variants: default policy only
+    if ((impl == 5 || impl == 6 || impl == 8 || impl == 9) && store_policy < 0) store_policy = 16;
+    if ((impl == 5 || impl == 6 || impl == 8 || impl == 9) && !(ring_ok && store_policy == 16)) impl = 3;   // debug variants: sc1 only
     if (impl >= 3 && !ring_ok) impl = 2;
     if (impl == 2 && !v2_ok) impl = 1;
     // default: the row-piece kernel for wide rows (a bounded grid means "runs beside something that owns most of every
@@ -858,6 +863,7 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
     }
     if (impl >= 7 && !(ring_ok && K % 4 == 0 && queries < (1LL << 31))) impl = 3;
     if (impl >= 7) {
+        if (store_policy < 0) store_policy = 2;   // nt, see the pairs kernel above
         // v5: one wave per workgroup; R rows per LDS image (multiple of 4, about 8 KiB, at most 20 rows)
         static const int env_img = env_int("TGN_GROUP_IMAGE_FLOATS", 2176);   // floats per LDS image (experiments)
         int R = (int)(env_img / C) / 4 * 4;
@@ -919,6 +925,7 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
             hipLaunchKernelGGL((group_points_v2_kernel<IT, POL, false>), grid, dim3(256), 0, st, queries, q_per_xcd, N,  \
                                S, K, D, magicC, xyz, new_xyz, pts, (const IT *)idx, xyz_first, out, err);                \
     } while (0)
+    if (store_policy < 0) store_policy = 16;   // v2 / ring kernels: write-through (profiles/r01_store_bench.txt)
 #define TGN_GROUP_V2_POL(IT)                                   \
     switch (store_policy) {                                    \
         case 0: TGN_GROUP_V2(IT, 0); break;                    \
