@@ -103,7 +103,7 @@ def main():
                     "[128,512,1024], eval-mode BatchNorm folded): the grouped tensor is never written -- a second, non-headline line")
     ap.add_argument("--ball-stream", type=int, default=-1, help="-1: default (2 = phased: ball queries on a third stream beside FPS levels "
                     "2-3, fenced off from the next step's FPS level 1); 0: in line on the FPS stream; 1: third stream, free-running")
-    ap.add_argument("--ball-split", type=int, default=0, help="phased schedule: ball queries of levels 2-3 on a stream of their own")
+    ap.add_argument("--ball-split", type=int, default=-1, help="phased schedule: where the ball queries of levels 2-3 run (hotpath.py; -1 = default: the last level in front of the groupings)")
     ap.add_argument("--group-delay-us", type=int, default=-1, help="gated schedule: hold the groupings back by this long behind the start of "
                     "FPS level 1 (-1: default = the FPS set-up time, ~150 us at 24 000 points)")
     ap.add_argument("--group-order", type=ilist, default=None, help="gated schedule: order of the grouping launches, e.g. 2,1,0")
@@ -130,7 +130,7 @@ def main():
                  group_max_blocks=None if mb == -1 else mb, fused=bool(args.fused),
                  ball_stream=None if args.ball_stream < 0 else args.ball_stream,
                  group_gate=None if args.group_gate < 0 else bool(args.group_gate),
-                 early_grid=None if args.early_grid < 0 else bool(args.early_grid), ball_split=int(args.ball_split), grid_stream=bool(args.grid_stream),
+                 early_grid=None if args.early_grid < 0 else bool(args.early_grid), ball_split=None if args.ball_split < 0 else int(args.ball_split), grid_stream=bool(args.grid_stream),
                  low_valu=bool(args.low_valu), group_order=args.group_order, group_delay_us=None if args.group_delay_us < 0 else args.group_delay_us)
     if args.fused and args.shape != "A":
         raise SystemExit("--fused is defined for shape A (single-scale levels)")

@@ -57,8 +57,9 @@ class HotPath:
                 FPS workgroups leave free -- one wave of <= 48 VGPRs per SIMD and ~95 KiB of LDS per CU, which is what the
                 row-piece / pairs grouping kernels are built for (4 waves per CU each);
       phase 2   stream F: FPS levels 2, 3 (small workgroups, VALU bound)  ||  stream H: the three ball queries (VALU bound,
-                57 VGPRs: they cannot run beside an FPS level-1 workgroup, so stream F does not start the next step's level 1
-                before the last query is through) -- and, on F behind FPS level 3, the level-1 ball-query grid of step k+1.
+                45 VGPRs at full occupancy: stream F does not start the next step's level 1 before the level-2 query is
+                through; the last level's query -- a 22-VGPR scan -- moves in front of the groupings of phase 1 when those leave
+                room) -- and, on F behind FPS level 3, the level-1 ball-query grid of step k+1.
 
     Buffers are double-buffered by step parity; HIP events order FPS level l before the ball query of level l, the last ball
     query of a step before its groupings (group_gate) and before the next step's FPS level 1 (ball_stream = 2), and step
@@ -67,7 +68,7 @@ class HotPath:
 
     def __init__(self, B, device, shape=SHAPE_A, xyz_first=True, index_dtype=torch.int32, pipeline=False,
                  fps_prefix=False, group_impl=0, group_policy=-1, group_max_blocks=None, fused=False, ball_stream=None,
-                 group_gate=None, early_grid=None, ball_split=0, grid_stream=False, low_valu=True, group_order=None, group_delay_us=None):
+                 group_gate=None, early_grid=None, ball_split=None, grid_stream=False, low_valu=True, group_order=None, group_delay_us=None):
         self.B, self.device, self.shape = B, device, shape
         # launch knobs of the grouping kernel (include/tgn_pointops.h, tgn_group_points_ex).  In the pipelined schedule its
         # grid is bounded to what fits beside the FPS level-1 workgroups, so that those never wait for a CU to drain:
@@ -115,8 +116,22 @@ class HotPath:
             # soon as the FPS level that produces their cloud is done: 5.195 ms per step against 5.18 -- the small kernels at
             # the tail of phase 2 slow each other down by what the overlap gains.  1: levels 2 AND 3 on the second stream:
             # 5.44 ms (the level-2 query then takes issue slots from the level-1 query)
+            # 4 (default) / 5: the queries of the last level / of every level after the first move in front of this step's
+            # groupings, i.e. beside the NEXT step's FPS level 1 (they fit there: 22 and 45 VGPRs), and the fence in front of
+            # that FPS launch waits for the queries that stayed in phase 2 only.  4: the level-3 query takes 0.20 instead of
+            # 0.07 ms there, but the groupings leave 0.4 ms of the 3.4 free and phase 2 ends 0.07 ms earlier: 4.69 -> 4.63 ms
+            # per step.  5: the level-2 query needs 1.2-4 ms with one workgroup per CU: 5.2-7.6 ms per step
+            if ball_split is None:
+                # 4 pays when the groupings leave room beside FPS level 1 (Shape A: 3.0 of 3.4 ms; Shape B's groupings take ten
+                # times the FPS launch and the same move costs 2 %): grouping bytes at the ~3.8 TB/s the kernels reach there
+                # against (S1 - 1) iterations of ~0.83 us
+                _, per = algorithmic_bytes(**shape)
+                group_ms = sum(l["group"] for l in per) * B / 3.8e9
+                fps_ms = (shape["npoint"][0] - 1) * 0.83e-3
+                ball_split = 4 if (self.group_gate and nl >= 2 and group_ms + 0.3 <= fps_ms) else 0
             self.ball_split = int(ball_split) if self.ball_stream == 2 else 0
-            self.s_ball2 = torch.cuda.Stream(device=device, priority=-1) if self.ball_split else None
+            self.s_ball2 = torch.cuda.Stream(device=device, priority=-1) if self.ball_split in (1, 2, 3) else None
+            self.shadow_from = {4: nl - 1, 5: 1}.get(self.ball_split, nl) if self.group_gate else nl
             self.ev_lgrid = [[torch.cuda.Event() for _ in shape["npoint"]] for _ in range(2)]
             self.ev_ball = [[torch.cuda.Event() for _ in shape["npoint"]] for _ in range(2)]
             self.ev_fps = [[torch.cuda.Event() for _ in shape["npoint"]] for _ in range(2)]
@@ -133,7 +148,9 @@ class HotPath:
         if self.ball_stream == 2:
             return ("3 HIP streams, 2 phases per step: FPS level 1 of step k beside the groupings of step k-1" +
                     ("" if self.group_gate else " (released level by level)") +
-                    ", then FPS levels 2-3 beside the three ball queries" +
+                    (", then FPS levels 2-3 beside the ball queries of levels 1-%d (level %d: in front of the groupings)"
+                     % (self.shadow_from, self.shadow_from + 1) if getattr(self, "shadow_from", 99) < len(self.shape["npoint"])
+                     else ", then FPS levels 2-3 beside the three ball queries") +
                     (" and the next step's level-1 ball-query grid" if self.early_grid else ""))
         if self.ball_stream == 1:
             return "3 HIP streams, free-running (FPS chain | ball queries | groupings)"
@@ -294,9 +311,11 @@ class HotPath:
             self.ev_grid[p].record(sq)
             if self.s_grid is not None:
                 sf.wait_event(self.ev_grid[p])               # ... and out of the way before this step's level 1 starts
+        shadow_from = getattr(self, "shadow_from", len(levels))
         if self.ball_stream == 2 and self.step_no >= 1:
-            for ev in (self.ev_ball[1 - p] if sb2 is not None else self.ev_ball[1 - p][-1:]):
-                sf.wait_event(ev)                    # phased: the previous step's ball queries are through
+            last = min(shadow_from, len(levels)) - 1
+            for ev in (self.ev_ball[1 - p] if sb2 is not None else self.ev_ball[1 - p][last:last + 1]):
+                sf.wait_event(ev)                    # phased: the previous step's ball queries (of phase 2) are through
         cur_xyz = xyz
         nl = len(levels)
         split = self.ball_split if sb2 is not None else 0
@@ -305,7 +324,9 @@ class HotPath:
             if sb is None:
                 self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, cur_xyz, pf) for br in lv["branches"]], sf)
             self.ev_fps[p][i].record(sf)
-            if sb is not None:
+            if sb is not None and i >= shadow_from:
+                pass                                 # queried on stream G, in front of the groupings (below)
+            elif sb is not None:
                 if split == 2 and i + 1 < nl:
                     # the next level's grid: its cloud (this level's samples) exists now
                     sb2.wait_event(self.ev_fps[p][i])
@@ -331,10 +352,19 @@ class HotPath:
             lv, cur_xyz = levels[i], clouds[i]
             if self.group_gate:
                 if n_ == 0:
-                    for ev in (ev_q[p] if sb2 is not None else ev_q[p][-1:]):
-                        sg.wait_event(ev)            # all of this step's groupings run beside the NEXT step's FPS level 1
+                    if sb is not None and shadow_from < nl:
+                        sg.wait_event(ev_q[p][shadow_from - 1])
+                        sg.wait_event(self.ev_fps[p][nl - 1])
+                    else:
+                        for ev in (ev_q[p] if sb2 is not None else ev_q[p][-1:]):
+                            sg.wait_event(ev)        # all of this step's groupings run beside the NEXT step's FPS level 1
                     if self.group_delay_us:
                         check(self.L.tgn_stream_delay(self.group_delay_us, pg), "stream_delay")
+                    if sb is not None:
+                        for j in range(shadow_from, nl):
+                            lj, cj = levels[j], clouds[j]
+                            self._timed(f"ball_l{j + 1}", lambda: [self._ball(lj, br, cj, pg) for br in lj["branches"]], sg)
+                            self.ev_ball[p][j].record(sg)
             else:
                 sg.wait_event(ev_q[p][i])
             self._timed(f"group_l{i + 1}", lambda: self._consume(i, lv, cur_xyz, feats, levels, pg), sg)
