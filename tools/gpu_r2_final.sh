@@ -9,7 +9,7 @@ echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 
 echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6
 echo "== bench"; timeout 600 python bench.py > gpurun_out/bench.log 2>&1; tail -1 gpurun_out/bench.log | cut -c1-2500
 echo "== rocprof"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r2 -- python $R/bench.py --steps 3 --warmup 1 --cpu-meshes 0 --no-alt > $R/gpurun_out/rocprof.log 2>&1); cat $(find gpurun_out/prof -name "*kernel_stats.csv" | head -1) | cut -c1-170 | head -16
-echo "== rocprof fused"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_fused -o r2f -- python $R/bench.py --fused 1 --pipeline 0 --steps 3 --warmup 1 --cpu-meshes 0 > $R/gpurun_out/rocprof_fused.log 2>&1); tail -1 gpurun_out/rocprof_fused.log | cut -c1-600; cat $(find gpurun_out/prof_fused -name "*kernel_stats.csv" | head -1) | cut -c1-170 | head -10
+echo "== rocprof fused"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_fused -o r2f -- python $R/bench.py --fused 1 --pipeline 0 --steps 3 --warmup 1 --cpu-meshes 0 > $R/gpurun_out/rocprof_fused.log 2>&1); grep "^{\"metric\"" gpurun_out/rocprof_fused.log | tail -1 | cut -c1-600; cat $(find gpurun_out/prof_fused -name "*kernel_stats.csv" | head -1) | cut -c1-170 | head -10
 echo "== pmc"; bash tools/gpu_pmc.sh 2>&1 | tail -30
 {
 echo "## bench.py --shape B (not the headline)"; timeout 300 python bench.py --shape B --steps 10 --warmup 3 --cpu-meshes 0 --no-alt 2>&1 | tail -1 | cut -c1-1200
