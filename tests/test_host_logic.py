@@ -131,3 +131,32 @@ def test_algorithmic_bytes_match_the_survey():
     assert hotpath.algorithmic_bytes(**hotpath.SHAPE_A)[0] == 46109952
     assert hotpath.algorithmic_bytes(**hotpath.SHAPE_B)[0] == 165863680
     assert hotpath.algorithmic_bytes(**hotpath.SHAPE_A, fused=True)[0] == 12588288
+
+
+def test_known_offsets_spare_the_device_to_host_copy():
+    """pointops.register_offsets / offsets_host: host values a caller already knows are used instead of a device->host copy
+    (what makes a dense-batch Point-Transformer forward free of host round trips); an in-place write drops the entry."""
+    import torch
+
+    from toothgroupnetwork_amd import pointops as P
+
+    o = torch.tensor([5, 9], dtype=torch.int32)
+    q = torch.tensor([2, 4], dtype=torch.int32)
+    assert P.offsets_host(o, q) == [[5, 9], [2, 4]]          # unknown: read from the tensors (one copy for both)
+    P.register_offsets(o, [5, 9])
+    calls = []
+    orig = P._offsets_host
+    P._offsets_host = lambda t: calls.append(t.numel()) or orig(t)
+    try:
+        assert P.offsets_host(o) == [[5, 9]] and calls == []   # known: no copy
+        assert P.offsets_host(o, q) == [[5, 9], [2, 4]] and calls == [2]   # only the unknown one is fetched
+        o.add_(1)                                             # written in place: the registered values are stale
+        assert P.offsets_host(o) == [[6, 10]] and calls == [2, 2]
+    finally:
+        P._offsets_host = orig
+    with pytest.raises(AssertionError):
+        P.register_offsets(q, [1, 2, 3])
+    with torch.inference_mode():                              # no version counter there: still usable
+        r = torch.tensor([7], dtype=torch.int32)
+        P.register_offsets(r, [7])
+        assert P.offsets_host(r) == [[7]]

@@ -162,6 +162,13 @@ class TransitionDown(nn.Module):
             return [p, self.relu(self.bn(self.linear(x))), o]
         counts = torch.diff(o, prepend=o.new_zeros(1)) // self.stride     # per-cloud sample counts (blocks.py:64-68), no host loop
         n_o = torch.cumsum(counts, 0).to(torch.int32)
+        # the same on the host, from the host copy of `o` (known for a dense batch: no device->host copy, HIP-graph capturable)
+        o_h, prev, acc, n_o_h = pointops.offsets_host(o)[0], 0, 0, []
+        for v in o_h:
+            acc += (v - prev) // self.stride
+            n_o_h.append(acc)
+            prev = v
+        pointops.register_offsets(n_o, n_o_h)
         idx, n_p = pointops.fps_with_coords(p, o, n_o)                     # blocks.py:69-70: indices and p[idx] from one kernel
         C1 = self.linear.out_features
         if _frozen(self, p, x) and self.nsample <= 64 and C1 % 4 == 0 and x.dtype == torch.float32:
@@ -200,7 +207,8 @@ class TransitionUp(nn.Module):
         if pxo2 is None:
             _, x, o = pxo1
             # x = mlp[x, mlp[mean of the cloud]] (blocks.py:103-116) without the per-cloud host loop
-            seg = torch.repeat_interleave(torch.arange(o.shape[0], device=x.device), torch.diff(o, prepend=o.new_zeros(1)).long())
+            seg = torch.repeat_interleave(torch.arange(o.shape[0], device=x.device), torch.diff(o, prepend=o.new_zeros(1)).long(),
+                                          output_size=x.shape[0])   # (the size is known: no device->host round trip)
             cnt = torch.diff(o, prepend=o.new_zeros(1)).to(x.dtype).unsqueeze(1)
             mean = torch.zeros(o.shape[0], x.shape[1], dtype=x.dtype, device=x.device).index_add_(0, seg, x) / cnt
             return self.linear1(torch.cat((x, self.linear2(mean)[seg]), 1))
@@ -259,7 +267,8 @@ class PointTransformerUNet(nn.Module):
         pxo = inputs.permute(0, 2, 1)
         x = pxo.reshape(-1, C).contiguous()
         p = pxo[:, :, :3].reshape(-1, 3).contiguous()
-        o = torch.arange(1, B + 1, dtype=torch.int32, device=inputs.device) * N
+        o = pointops.register_offsets(torch.arange(1, B + 1, dtype=torch.int32, device=inputs.device) * N,
+                                      [N * (i + 1) for i in range(B)])
         stages = []
         cur = [p, x, o]
         for e in self.enc:

@@ -13,6 +13,7 @@ from collections import OrderedDict
 
 import torch
 from torch.autograd import Function
+from torch.utils.weak import WeakTensorKeyDictionary
 
 from . import _lib
 from ._fps_prefix import PrefixBook
@@ -30,6 +31,45 @@ def _offsets_host(offset):
     """Offsets are device tensors in the reference API; the output size depends on their values, so one
     device->host copy per call is inherent (the reference syncs b+1 times, pointops.py:18-21)."""
     return [int(v) for v in offset.detach().cpu().tolist()]
+
+
+# Host copies of offset tensors whose values the caller already knows (a dense batch: b * n; a transition-down level:
+# counts // stride).  With them the sampling call needs no device->host copy at all, which is what makes a whole
+# Point-Transformer forward capturable in a HIP graph (tools/pt_forward_bench.py).  Keyed by tensor identity (weakly) and
+# version counter: an in-place write invalidates the entry.
+_known_offsets = WeakTensorKeyDictionary()
+
+
+def _version(t):
+    try:
+        return t._version
+    except RuntimeError:      # inference tensors carry no version counter; they cannot be written in place either
+        return -1
+
+
+def register_offsets(offset, values):
+    """Tell this module the host values of a device offset tensor (a list of ints of the same length)."""
+    values = [int(v) for v in values]
+    assert len(values) == offset.numel()
+    _known_offsets[offset] = (_version(offset), values)
+    return offset
+
+
+def offsets_host(*offsets):
+    """Host values of offset tensors: from register_offsets where known, else ONE device->host copy for the rest."""
+    out, missing = [None] * len(offsets), []
+    for i, t in enumerate(offsets):
+        hit = _known_offsets.get(t)
+        if hit is not None and hit[0] == _version(t):
+            out[i] = hit[1]
+        else:
+            missing.append(i)
+    if missing:
+        flat = _offsets_host(torch.cat([offsets[i].reshape(-1) for i in missing]))
+        for i in missing:
+            n = offsets[i].numel()
+            out[i], flat = flat[:n], flat[n:]
+    return out
 
 
 def _max_segment(off_h):
@@ -65,9 +105,8 @@ def fps_with_coords(xyz, offset, new_offset, cuda_compat=False):
     require_cuda(xyz, offset, new_offset)
     assert xyz.is_contiguous()
     xyz = xyz.float() if xyz.dtype != torch.float32 else xyz
+    off_h, noff_h = offsets_host(offset, new_offset)   # one device->host copy, or none (register_offsets)
     offset, new_offset = _i32(offset).contiguous(), _i32(new_offset).contiguous()
-    both = _offsets_host(torch.cat([offset.reshape(-1), new_offset.reshape(-1)]))  # one device->host copy
-    off_h, noff_h = both[:offset.numel()], both[offset.numel():]
     b = offset.shape[0]
     if b == 0 or noff_h[-1] == 0:      # nothing to sample (no segments, or only empty ones): an empty result, no launch
         return (torch.zeros(0, dtype=torch.int32, device=xyz.device),
