@@ -137,3 +137,47 @@ def test_unet_forward_at_24000_points(dev):
     assert y.shape == (24000, 32) and torch.isfinite(y).all()
     y2 = net(inp.clone().requires_grad_(True))
     close(y.cpu().numpy(), y2.detach().cpu().numpy(), "fused vs composition through 23 blocks", tol=1e-3)
+
+
+def test_unet_sampling_on_a_side_stream_changes_nothing(dev):
+    """PointTransformerUNet runs its sampling pyramid on a side stream beside the first stage (presample): every level's
+    indices and coordinates are the ones of the in-place order bit for bit, and the network output agrees (the head's
+    per-cloud mean is an atomic float sum, so the output itself is compared to rounding)."""
+    from toothgroupnetwork_amd import point_transformer as PT, pointops as P, synth
+    torch.manual_seed(0)
+    net = PT.PointTransformerUNet(6, (16, 32, 32, 64, 64), (1, 2, 2, 2, 1)).to(dev).eval()
+    _randomise_bn(net, 2)
+    for B, n in ((1, 24000), (3, 4000)):
+        inp = T(synth.scan_batch(B, n, "arch", 5).transpose(0, 2, 1).copy(), dev)
+        p = inp.permute(0, 2, 1)[:, :, :3].reshape(-1, 3).contiguous()
+        o = P.register_offsets(torch.arange(1, B + 1, dtype=torch.int32, device=dev) * n, [n * (i + 1) for i in range(B)])
+        # the pyramid, sampled where the reference samples it
+        P.fps_prefix_clear()
+        want, pp, oo = [], p, o
+        for e in net.enc:
+            if e[0].stride != 1:
+                n_o = e[0].sample_offsets(oo)
+                idx, n_p = P.fps_with_coords(pp, oo, n_o)
+                want.append((idx.clone(), n_p.clone(), n_o.clone()))
+                pp, oo = n_p, n_o
+        # ... and ahead of time on the side stream
+        P.fps_prefix_clear()
+        net._presample(p, o)
+        torch.cuda.synchronize()
+        got = [e[0]._presampled for e in net.enc if e[0].stride != 1]
+        assert len(got) == len(want) == 4
+        for (idx, n_p, n_o), g in zip(want, got):
+            assert torch.equal(idx, g[3]) and torch.equal(n_p, g[4]) and torch.equal(n_o, g[2])
+            g[5].synchronize()
+        for e in net.enc:
+            e[0]._presampled = None
+        outs = []
+        for pre in (False, True, True):
+            net.presample = pre
+            P.knn_cache_clear()
+            P.fps_prefix_clear()
+            with torch.no_grad():
+                outs.append(net(inp))
+            torch.cuda.synchronize()
+        for y in outs[1:]:
+            close(outs[0].cpu().numpy(), y.cpu().numpy(), "side-stream sampling vs in-place", tol=1e-5)

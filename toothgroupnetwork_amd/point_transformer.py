@@ -156,20 +156,30 @@ class TransitionDown(nn.Module):
         self.bn = nn.BatchNorm1d(out_planes)
         self.relu = nn.ReLU(inplace=True)
 
-    def forward(self, pxo):
-        p, x, o = pxo  # (n, 3), (n, c), (b)
-        if self.stride == 1:
-            return [p, self.relu(self.bn(self.linear(x))), o]
-        counts = torch.diff(o, prepend=o.new_zeros(1)) // self.stride     # per-cloud sample counts (blocks.py:64-68), no host loop
+    def sample_offsets(self, o):
+        """Offsets of the down-sampled clouds (blocks.py:64-68: count // stride per cloud), on the device without a host loop
+        and -- from the host copy of `o`, known for a dense batch -- on the host without a device->host copy."""
+        counts = torch.diff(o, prepend=o.new_zeros(1)) // self.stride
         n_o = torch.cumsum(counts, 0).to(torch.int32)
-        # the same on the host, from the host copy of `o` (known for a dense batch: no device->host copy, HIP-graph capturable)
         o_h, prev, acc, n_o_h = pointops.offsets_host(o)[0], 0, 0, []
         for v in o_h:
             acc += (v - prev) // self.stride
             n_o_h.append(acc)
             prev = v
-        pointops.register_offsets(n_o, n_o_h)
-        idx, n_p = pointops.fps_with_coords(p, o, n_o)                     # blocks.py:69-70: indices and p[idx] from one kernel
+        return pointops.register_offsets(n_o, n_o_h)
+
+    def forward(self, pxo):
+        p, x, o = pxo  # (n, 3), (n, c), (b)
+        if self.stride == 1:
+            return [p, self.relu(self.bn(self.linear(x))), o]
+        pre, self._presampled = getattr(self, "_presampled", None), None
+        if pre is not None and pre[0] is p and pre[1] is o:
+            # sampled ahead on a side stream (PointTransformerUNet._presample): sampling depends on the coordinates only
+            n_o, idx, n_p, ev = pre[2:]
+            torch.cuda.current_stream().wait_event(ev)
+        else:
+            n_o = self.sample_offsets(o)
+            idx, n_p = pointops.fps_with_coords(p, o, n_o)                 # blocks.py:69-70: indices and p[idx] from one kernel
         C1 = self.linear.out_features
         if _frozen(self, p, x) and self.nsample <= 64 and C1 % 4 == 0 and x.dtype == torch.float32:
             # the whole down-sampling step fused: (m, nsample, 3+c) is never built (blocks.py:71-73)
@@ -262,6 +272,33 @@ class PointTransformerUNet(nn.Module):
             dec.append(nn.Sequential(*layers))
         self.enc, self.dec = nn.ModuleList(enc), nn.ModuleList(dec)   # dec[0] = dec5 ... dec[4] = dec1
 
+    presample = True   # the sampling pyramid on a side stream, beside the first stage (False: sampled where the reference does)
+
+    def _presample(self, p, o):
+        """The four sampling launches depend on the coordinates only (24 000 -> 6000 is a 4.8 ms serial chain on ONE CU; the
+        levels below it are answered by the FPS-of-an-FPS-result identity): they go onto a side stream at the start of the
+        forward and run beside the first stage's kNN / attention / linear layers; each transition-down level waits for its
+        event.  Same kernels, same results."""
+        cur = torch.cuda.current_stream()
+        side = getattr(self, "_side_stream", None)
+        if side is None or side.device != p.device:
+            side = self._side_stream = torch.cuda.Stream(device=p.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            pp, oo = p, o
+            for e in self.enc:
+                td = e[0]
+                if td.stride == 1:
+                    continue
+                n_o = td.sample_offsets(oo)
+                idx, n_p = pointops.fps_with_coords(pp, oo, n_o)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                for t in (n_o, idx, n_p):
+                    t.record_stream(cur)
+                td._presampled = (pp, oo, n_o, idx, n_p, ev)
+                pp, oo = n_p, n_o
+
     def forward(self, inputs):
         B, C, N = inputs.shape
         pxo = inputs.permute(0, 2, 1)
@@ -269,6 +306,8 @@ class PointTransformerUNet(nn.Module):
         p = pxo[:, :, :3].reshape(-1, 3).contiguous()
         o = pointops.register_offsets(torch.arange(1, B + 1, dtype=torch.int32, device=inputs.device) * N,
                                       [N * (i + 1) for i in range(B)])
+        if self.presample and p.is_cuda:
+            self._presample(p, o)
         stages = []
         cur = [p, x, o]
         for e in self.enc:
