@@ -111,16 +111,17 @@ class HotPath:
             self.s_fps = torch.cuda.Stream(device=device, priority=-1)
             self.s_rest = torch.cuda.Stream(device=device, priority=0)
             self.s_ball = torch.cuda.Stream(device=device, priority=-1) if self.ball_stream else None
-            # ball_split (experiments, off).  2: the LAST level's query (a scan over 1024-point clouds, it needs FPS level 3
-            # only) on a second query stream instead of behind the level-2 query, and the grids of levels > 1 built there as
-            # soon as the FPS level that produces their cloud is done: 5.195 ms per step against 5.18 -- the small kernels at
-            # the tail of phase 2 slow each other down by what the overlap gains.  1: levels 2 AND 3 on the second stream:
-            # 5.44 ms (the level-2 query then takes issue slots from the level-1 query)
-            # 4 (default) / 5: the queries of the last level / of every level after the first move in front of this step's
-            # groupings, i.e. beside the NEXT step's FPS level 1 (they fit there: 22 and 45 VGPRs), and the fence in front of
-            # that FPS launch waits for the queries that stayed in phase 2 only.  4: the level-3 query takes 0.20 instead of
-            # 0.07 ms there, but the groupings leave 0.4 ms of the 3.4 free and phase 2 ends 0.07 ms earlier: 4.69 -> 4.63 ms
-            # per step.  5: the level-2 query needs 1.2-4 ms with one workgroup per CU: 5.2-7.6 ms per step
+            # ball_split: where the queries of the levels after the first run.
+            #   0  behind the level-1 query on stream H (phase 2);
+            #   4  (default where it pays, below) the LAST level's query -- a 22-VGPR scan over 1024-point clouds -- in front of
+            #      this step's groupings on stream G, i.e. beside the NEXT step's FPS level 1, and the fence in front of that
+            #      FPS launch waits for the level-2 query only: 0.20 instead of 0.07 ms for the query, but the groupings leave
+            #      0.4 of the 3.4 ms free and phase 2 ends 0.07 ms earlier: 4.69 -> 4.62 ms per step;
+            #   5  the same for every level after the first: the level-2 query (45 VGPRs: one workgroup per CU there) needs
+            #      1.2-4 ms beside FPS: 5.2-7.6 ms per step;
+            #   1, 2  (experiments of the first half of round 2) levels 2-3 / the last level on a second query
+            #      stream in phase 2: 5.44 / 5.195 ms against 5.18 then -- the small kernels at the tail of phase 2 slow each
+            #      other down by what the overlap gains.
             if ball_split is None:
                 # 4 pays when the groupings leave room beside FPS level 1 (Shape A: 3.0 of 3.4 ms; Shape B's groupings take ten
                 # times the FPS launch and the same move costs 2 %): grouping bytes at the ~3.8 TB/s the kernels reach there
