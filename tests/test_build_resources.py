@@ -38,16 +38,22 @@ def test_fps_and_group_kernels_can_share_a_cu():
     # levels 2 and 3 (rows of >= 64 floats): the row-piece kernel, ONE wave per SIMD beside the FPS workgroup, 4 per CU
     # (dynamic LDS: 2 images of 32 + R*C floats + 512 floats of set-up planes, R*C <= 2176 -- group.hip launcher)
     rows_lds = (2 * (32 + 2176) + 64 * 3 + 64 * 5) * 4
-    for name in ("tgn::group_points_rows_kernel<int, 16, 0, 4>", "tgn::group_points_rows_kernel<long long, 16, 0, 4>",
-                 "tgn::group_points_rows_kernel<int, 16, 0, 1>"):
+    # (store policy 2 = nt is what the launcher picks by default, 16 = sc1)
+    for name in ("tgn::group_points_rows_kernel<int, 2, 0, 4>", "tgn::group_points_rows_kernel<long long, 2, 0, 4>",
+                 "tgn::group_points_rows_kernel<int, 2, 0, 1>", "tgn::group_points_rows_kernel<int, 16, 0, 4>",
+                 "tgn::group_points_rows_kernel<long long, 16, 0, 4>", "tgn::group_points_rows_kernel<int, 16, 0, 1>"):
         gv, gs, _ = g[name]
         assert gs == 0 and gv <= 48, f"{name} uses {gv} VGPRs (> 48: does not fit beside the FPS workgroup)"
     assert lds + 4 * rows_lds <= 160 * 1024
     # level 1 (9-float rows): the pairs kernel, one wave per SIMD = one 256-thread workgroup per CU
-    for idx_t in ("int", "long long"):
-        nv, ns, nlds = g[f"tgn::group_points_pairs_kernel<{idx_t}, 6, 16>"]
+    for idx_t, pol in (("int", 2), ("long long", 2), ("int", 16), ("long long", 16)):
+        nv, ns, nlds = g[f"tgn::group_points_pairs_kernel<{idx_t}, 6, {pol}>"]
         assert ns == 0 and nv <= 48, f"pairs grouping kernel ({idx_t}) uses {nv} VGPRs (> 48: does not fit beside the FPS workgroup)"
         assert lds + nlds <= 160 * 1024
+    # the last level's ball query (a scan) runs there too, in front of the groupings: two of its waves per SIMD
+    bq = _usage("ball_query.hip")
+    qv, qs, _ = bq["tgn::ball_query_scan_kernel<int>"]
+    assert qs == 0 and qv <= 24, f"scan ball query uses {qv} VGPRs (> 24: one wave per SIMD beside the FPS workgroup)"
     # the LDS-light fallback (shapes the two above do not take): two waves per SIMD
     gv, gs, glds = g["tgn::group_points_v2_kernel<int, 16, true>"]
     assert gs == 0 and gv <= 24, f"v2 grouping kernel uses {gv} VGPRs (> 24: only one wave fits beside the FPS workgroup)"
