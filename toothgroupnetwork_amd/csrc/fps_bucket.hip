@@ -273,6 +273,10 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
     // optional instrumentation (flag 0x100 + tmp): touched-bucket census and per-phase cycles of one wave
     // compile-time switch: even never-taken `if (dbg)` branches cost a lone wave ~10 cycles each per iteration
     constexpr bool dbg = DBG;
+    // The hand-off record is written by EVERY lane of the wave (same address, same data) in the 8-wave kernels: the
+    // lane-0 form costs an exec save / branch / restore on the chain everybody waits for (3.39 -> 3.32 ms for 24 000 -> 4096;
+    // the 4-wave kernels, which run beside the level-1 ball query, measured no better with it and keep lane 0)
+    constexpr bool kRecAllLanes = NT >= 512;
     unsigned long long st_skip = 0, st_touched = 0, st_waves = 0, cyA = 0, cyU = 0, cyB = 0, cyC = 0, cyC1 = 0, cyC2 = 0;
     unsigned long long dbg_sum_max = 0, dbg_crit_is_winner = 0, dbg_crit_dirty = 0, dbg_crit_touched = 0, dbg_sum_winner = 0;
     unsigned dbg_prev_winner = 0;
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             qy = wy;
             qz = wz;
         } else {
-            if (lane == 0) {  // {value bits, tie key} and {x, y, z}: 8 + 12 bytes of the wave's 32-byte record
+            if (kRecAllLanes || lane == 0) {  // {value bits, tie key} and {x, y, z}: 8 + 12 bytes of the wave's 32-byte record
                 *(uint2 *)(recb + wr_off) = make_uint2(pub_bits, pub_key);
                 *(float3 *)(recb + wr_off + 16) = make_float3(wx, wy, wz);
             }

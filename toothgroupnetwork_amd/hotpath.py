@@ -103,8 +103,9 @@ class HotPath:
         # The first ~0.17 ms of an FPS level-1 workgroup is its set-up: it streams its cloud three times (latency-bound loads),
         # and a grouping launch that saturates HBM at the same moment stretches it (3.59 instead of 3.46 ms for the launch).
         # The gated groupings are therefore held back by a one-wave spacer kernel for about as long as the set-up takes
-        # (~7 ns per point of the level-1 cloud); they have the slack: 3.2 of the 3.46 ms beside FPS.
-        self.group_delay_us = (min(300, shape["n"] // 160) if (self.group_gate and not self.fused) else 0) \
+        # (~4 ns per point of the level-1 cloud: 100 us for 24 000 points; 0: 3.43 instead of 3.32 ms for the launch; 150: the
+        # work beside FPS then ends after it and runs into phase 2).
+        self.group_delay_us = (min(300, shape["n"] // 240) if (self.group_gate and not self.fused) else 0) \
             if group_delay_us is None else int(group_delay_us)
         self.group_order = list(group_order) if group_order else None   # gated schedule: order of the grouping launches
         if pipeline:
