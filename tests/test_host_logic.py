@@ -160,3 +160,17 @@ def test_known_offsets_spare_the_device_to_host_copy():
         r = torch.tensor([7], dtype=torch.int32)
         P.register_offsets(r, [7])
         assert P.offsets_host(r) == [[7]]
+
+
+def test_default_placement_of_the_last_ball_query():
+    """hotpath.default_ball_split: the last level's query moves in front of the groupings only where those leave room beside
+    the FPS level-1 launch -- the headline shape at a full batch (measured: 4.69 -> 4.62 ms per step), not the
+    multi-scale shape whose groupings take ten times the FPS launch (measured: 2 % slower)."""
+    from toothgroupnetwork_amd import hotpath as H
+
+    assert H.default_ball_split(H.SHAPE_A, 256) == 4
+    assert H.default_ball_split(H.SHAPE_A, 16) == 4
+    assert H.default_ball_split(H.SHAPE_B, 256) == 0
+    one_level = dict(H.SHAPE_A, npoint=H.SHAPE_A["npoint"][:1], radius=H.SHAPE_A["radius"][:1],
+                     nsample=H.SHAPE_A["nsample"][:1], d=H.SHAPE_A["d"][:1])
+    assert H.default_ball_split(one_level, 256) == 0

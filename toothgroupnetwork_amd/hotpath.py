@@ -47,6 +47,19 @@ def algorithmic_bytes(n, npoint, nsample, d, fused=False, radius=None, c_out=Non
     return sum(l["total"] for l in levels), levels
 
 
+def default_ball_split(shape, B):
+    """Where the last level's ball query goes in the phased schedule (HotPath, ball_split): 4 = in front of the groupings,
+    beside the next step's FPS level 1 -- which pays when the groupings leave room there (Shape A: 3.0 of 3.3 ms; Shape B's
+    groupings take ten times the FPS launch and the same move costs 2 %) -- else 0.  Estimate: grouping bytes at the ~3.8 TB/s
+    the kernels reach beside FPS against (S1 - 1) iterations of ~0.81 us."""
+    if len(shape["npoint"]) < 2:
+        return 0
+    _, per = algorithmic_bytes(**shape)
+    group_ms = sum(l["group"] for l in per) * B / 3.8e9
+    fps_ms = (shape["npoint"][0] - 1) * 0.81e-3
+    return 4 if group_ms + 0.25 <= fps_ms else 0
+
+
 class HotPath:
     """Pre-planned FPS -> ball query -> group over `levels` for a fixed batch of B scans.
 
@@ -124,13 +137,7 @@ class HotPath:
             #      stream in phase 2: 5.44 / 5.195 ms against 5.18 then -- the small kernels at the tail of phase 2 slow each
             #      other down by what the overlap gains.
             if ball_split is None:
-                # 4 pays when the groupings leave room beside FPS level 1 (Shape A: 3.0 of 3.4 ms; Shape B's groupings take ten
-                # times the FPS launch and the same move costs 2 %): grouping bytes at the ~3.8 TB/s the kernels reach there
-                # against (S1 - 1) iterations of ~0.83 us
-                _, per = algorithmic_bytes(**shape)
-                group_ms = sum(l["group"] for l in per) * B / 3.8e9
-                fps_ms = (shape["npoint"][0] - 1) * 0.83e-3
-                ball_split = 4 if (self.group_gate and nl >= 2 and group_ms + 0.3 <= fps_ms) else 0
+                ball_split = default_ball_split(shape, B) if self.group_gate else 0
             self.ball_split = int(ball_split) if self.ball_stream == 2 else 0
             self.s_ball2 = torch.cuda.Stream(device=device, priority=-1) if self.ball_split in (1, 2, 3) else None
             self.shadow_from = {4: nl - 1, 5: 1}.get(self.ball_split, nl) if self.group_gate else nl
