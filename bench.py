@@ -105,7 +105,7 @@ def main():
                     "2-3, fenced off from the next step's FPS level 1); 0: in line on the FPS stream; 1: third stream, free-running")
     ap.add_argument("--ball-split", type=int, default=-1, help="phased schedule: where the ball queries of levels 2-3 run (hotpath.py; -1 = default: the last level in front of the groupings)")
     ap.add_argument("--group-delay-us", type=int, default=-1, help="gated schedule: hold the groupings back by this long behind the start of "
-                    "FPS level 1 (-1: default = the FPS set-up time, ~150 us at 24 000 points)")
+                    "FPS level 1 (-1: default, ~100 us at 24 000 points: most of the FPS set-up)")
     ap.add_argument("--group-order", type=ilist, default=None, help="gated schedule: order of the grouping launches, e.g. 2,1,0")
     ap.add_argument("--grid-stream", type=int, default=0, help="phased schedule: the early level-1 grid on a stream of its own (experiment)")
     ap.add_argument("--low-valu", type=int, default=1, help="phased schedule: FPS level 2 on the bucket-skipping kernel (TGN_FPS_LOW_VALU)")
