@@ -731,10 +731,8 @@ __global__ __launch_bounds__(kStreamThreads) void fps_bucket_stream_kernel(FpsAr
                 const unsigned o = (unsigned)sidx[p];
                 const unsigned kl = (nd == mx) ? (TREE ? compat_key((int)o, log2bs) : o) : 0xFFFFFFFFu;
                 const unsigned key = wave_min_u32_dpp(kl);
-                if (lane == 0) {
-                    pmax[bk] = mx;
-                    pkey[bk] = key;
-                }
+                pmax[bk] = mx;   // wave-uniform values: every lane stores them (no exec juggling around two LDS stores)
+                pkey[bk] = key;
             }
         }
         __syncthreads();

@@ -123,7 +123,7 @@ __device__ __forceinline__ unsigned long long fps_block_max(unsigned long long p
     if constexpr (NW == 1) {
         return wmax;
     } else {
-        if (lane == 0) slots[parity][wave] = wmax;
+        slots[parity][wave] = wmax;   // wave-uniform: every lane stores it (no exec juggling on the way to the barrier)
         __syncthreads();
         unsigned long long v = lane < NW ? slots[parity][lane] : 0ull;
         return row0_max_u64(v);
@@ -194,7 +194,8 @@ __device__ __forceinline__ unsigned fps_block_argmax(float best, unsigned key, u
         return wkey;
     } else {
         // distances are >= 0: their bit patterns order like unsigned integers
-        if (lane == 0) slots[parity][wave] = pack64(wm < 0.0f ? 0u : __float_as_uint(wm), wkey);
+        // (every lane stores the same word: `if (lane == 0)` would be an exec save / branch / restore on the way to the barrier)
+        slots[parity][wave] = pack64(wm < 0.0f ? 0u : __float_as_uint(wm), wkey);
         __syncthreads();
         // every lane reads slot lane % NW (no exec juggling); the max over lanes 0..NW-1 lands in lane NW-1 after
         // log2(NW) row_shr steps (one asm statement: between statements the compiler adds wait states of its own)
