@@ -85,13 +85,14 @@ def test_pipeline_with_oracle_fps_writes_the_reference_files(tmp_path, golden_r2
 
 
 def test_sharded_runner_two_ranks_gloo(tmp_path, golden_r2):
-    """tools/preprocess_sharded.py under torch.distributed.run with 2 gloo ranks (oracle FPS: no GPU here): each rank
-    writes its shard, one all_gather combines the counters, the files are the reference's."""
+    """tools/preprocess_sharded.py's main() under torch.distributed.run with 2 gloo ranks; there is no GPU here, so the
+    test-side launcher (tests/sharded_launcher.py) injects the oracle's FPS as the sampler: each rank writes its shard,
+    one all_gather combines the counters, the files are the reference's."""
     write_dataset(str(tmp_path))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29631", os.path.join(REPO, "tools", "preprocess_sharded.py"), "--source_obj_data_path",
+           "--master-port", "29631", os.path.join(REPO, "tests", "sharded_launcher.py"), "--source_obj_data_path",
            str(tmp_path / "obj"), "--source_json_data_path", str(tmp_path / "json"), "--save_data_path", str(tmp_path / "out"),
-           "--fps", "oracle", "--backend", "gloo"]
+           "--backend", "gloo"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]

@@ -17,8 +17,6 @@ import sys
 import tempfile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np  # noqa: E402
-
 from toothgroupnetwork_amd import preprocess, sharding, synth  # noqa: E402
 
 
@@ -34,16 +32,17 @@ def write_synthetic(root, n, rank, world):
             json.dump({"jaw": jaw, "labels": synth.fdi_labels(nu * nv, jaw, i)}, f)
 
 
-def main():
+def main(argv=None, fps_batch=None):
+    """fps_batch: the sampler handed to preprocess.preprocess_sharded (None = the GPU kernel, the only one this runner
+    knows; tests of the control flow pass their own callable through tests/sharded_launcher.py)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--source_obj_data_path", default=None)
     ap.add_argument("--source_json_data_path", default=None)
     ap.add_argument("--save_data_path", default="data_preprocessed_path")
     ap.add_argument("--synthetic", type=int, default=0, help="generate this many synthetic raw scans instead of reading a dataset")
     ap.add_argument("--batch", type=int, default=16, help="scans per FPS launch")
-    ap.add_argument("--fps", default="gpu", choices=["gpu", "oracle"], help="oracle: CPU FPS of oracle/ (tests of the control flow only)")
     ap.add_argument("--backend", default=None)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     rank, local_rank, world, device = sharding.init_from_env(backend=args.backend)
     tmp = None
     if args.synthetic:
@@ -52,10 +51,6 @@ def main():
         sharding.barrier()
         args.source_obj_data_path, args.source_json_data_path = os.path.join(root, "obj"), os.path.join(root, "json")
     pairs = preprocess.list_scans(args.source_obj_data_path, args.source_json_data_path)
-    fps_batch = None
-    if args.fps == "oracle":
-        from oracle import cpu as O   # test-only: the product path is the GPU kernel
-        fps_batch = lambda xs, m: [O.furthestsampling(np.ascontiguousarray(x, dtype=np.float32), [x.shape[0]], [m]).reshape(-1) for x in xs]
     res = preprocess.preprocess_sharded(pairs, args.save_data_path, rank, world, batch=args.batch, fps_batch=fps_batch,
                                         device=device if device.type == "cuda" else None)
     if rank == 0:
