@@ -47,3 +47,9 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="session")
+def golden_r3():
+    """Whole reference networks and the KDTree label transfer on CPU (tests/golden/make_golden_r3.py)."""
+    return dict(np.load(os.path.join(GOLDEN, "reference_cpu_r3.npz")))

@@ -331,3 +331,44 @@ def test_pipelined_schedule_at_full_size_matches_one_stream(dev, oracle):
                 assert float(l["grouped"].double().sum()) == c
             if pair in (0, 5):
                 check_against_oracle(lv, which, f"pipelined pair {pair}")
+
+
+def test_shape_b_at_full_size_matches_the_oracle(dev, oracle):
+    """Shape B -- what the reference net instantiates (pointnet_pp.py:13-15: npoint [1024, 512, 256], TWO radii per level,
+    nsample [32, 64], D = [6, 256, 1024], grouped layout [features, centred xyz]) -- on 24 000-point scans, the phased
+    schedule and one stream, against the CPU ORACLE's chain at all three levels and both radii, bit for bit."""
+    from toothgroupnetwork_amd import hotpath
+    shape, B = hotpath.SHAPE_B, 8
+    pts = torch.from_numpy(synth.scan_batch(B, 24000, "arch", 910)).to(dev)
+    xyz = pts[:, :, :3].contiguous()
+    g = torch.Generator().manual_seed(5)
+    feats = [pts, torch.randn(B, 1024, 256, generator=g).to(dev), torch.randn(B, 512, 1024, generator=g).to(dev)]
+    probes = (0, 5)
+    want = {}
+    for b in probes:
+        cur, per_level = xyz[b].cpu().numpy()[None], []
+        for li, S in enumerate(shape["npoint"]):
+            fidx = oracle.farthest_point_sample(cur, S)
+            new_xyz = oracle.index_points(cur, fidx)
+            brs = []
+            for r, K in hotpath._branches(shape["radius"][li], shape["nsample"][li]):
+                gidx = oracle.query_ball_point(r, K, cur, new_xyz)
+                brs.append((gidx[0], oracle.group_points(cur, new_xyz, feats[li][b].cpu().numpy()[None], gidx, False)[0]))
+            per_level.append((fidx[0], new_xyz[0], brs))
+            cur = new_xyz
+        want[b] = per_level
+    for pipeline in (False, True):
+        hp = hotpath.HotPath(B, dev, shape=shape, pipeline=pipeline)
+        for _ in range(3):
+            levels = hp.run(xyz, feats)
+        torch.cuda.synchronize()
+        for b in probes:
+            for li, (lv, (fidx, new_xyz, brs)) in enumerate(zip(levels, want[b])):
+                assert np.array_equal(lv["fps_idx"][b].cpu().numpy(), fidx), (pipeline, b, li, "fps")
+                assert np.array_equal(lv["new_xyz"][b].cpu().numpy(), new_xyz), (pipeline, b, li, "new_xyz")
+                assert len(lv["branches"]) == 2
+                for bi, (br, (gidx, grouped)) in enumerate(zip(lv["branches"], brs)):
+                    assert np.array_equal(br["group_idx"][b].cpu().numpy(), gidx), (pipeline, b, li, bi, "ball")
+                    assert np.array_equal(br["grouped"][b].cpu().numpy(), grouped), (pipeline, b, li, bi, "group")
+        del hp
+        torch.cuda.empty_cache()

@@ -2,7 +2,7 @@
 tgn_sa_gather_act, tgn_sa_direct_max) against the CPU oracle's float64 restatement of the reference layer
 (oracle/cpu.py::set_abstraction_first_layer, pointnet2_utils.py:162-169/229-236/281-294) and against outputs of the
 reference's own modules (tests/golden/make_golden_r2_sa.py) -- at shapes where the fused path is taken on its own.
-Tolerance: 1e-5 of the output's magnitude (the kernels and the reference's BLAS differ in summation order only)."""
+Tolerance: elementwise, |got - want| <= 1e-5 * (1 + |want|) (the kernels and the reference's BLAS differ in summation order only)."""
 import os
 
 import numpy as np
@@ -18,11 +18,16 @@ def T(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-def close(got, want, what=""):
+def close(got, want, what="", tol=1e-5):
+    """ELEMENTWISE: |got - want| <= tol * (1 + |want|) for every entry (north_star: grouped features within 1e-5 fp32) --
+    a small output next to a large one is held to its own size, not to the tensor's maximum."""
     want = np.asarray(want, dtype=np.float64)
-    scale = max(1.0, float(np.abs(want).max()))
-    err = float(np.abs(np.asarray(got, dtype=np.float64) - want).max())
-    assert err <= 1e-5 * scale, f"{what}: max abs error {err:.3e} > 1e-5 * {scale:.3f}"
+    got = np.asarray(got, dtype=np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    rel = np.abs(got - want) / (1.0 + np.abs(want))
+    worst = int(np.argmax(rel)) if rel.size else 0
+    assert rel.size == 0 or rel.flat[worst] <= tol, (f"{what}: worst elementwise error {rel.flat[worst]:.3e} > {tol} "
+                                                    f"(got {got.flat[worst]!r}, want {want.flat[worst]!r})")
 
 
 @pytest.mark.parametrize("M,D,C1", [(1000, 128, 512), (4096, 512, 1024), (777, 61, 24), (300, 125, 784), (129, 0, 32),
@@ -94,7 +99,7 @@ def test_fused_level_and_first_layer_vs_oracle(dev, oracle, N, S, K, D, C1, xyz_
 
 def test_fused_modules_match_the_reference_modules(dev, golden_r2, monkeypatch):
     """The drop-in modules in eval mode take the fused path BY THEMSELVES at these shapes (nothing is patched; a spy only
-    counts) and reproduce the reference modules' outputs (same weights) within 1e-5 of the output magnitude."""
+    counts) and reproduce the reference modules' outputs (same weights) within 1e-5 elementwise."""
     from toothgroupnetwork_amd import pointnet2_utils as U
     g = golden_r2
     state = torch.load(os.path.join(GOLDEN, "module_weights_r2.pt"))

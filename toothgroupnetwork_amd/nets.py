@@ -1,0 +1,139 @@
+"""Whole-network compositions of the drop-in modules, state_dict-compatible with the reference's networks.
+
+The reference's own model files import this package's operators unchanged; these mirrors exist for the
+places where the reference checkout is not available -- the GPU box's parity tests and benches -- and as the entry points
+of the fused eval paths.  Parameter names and shapes equal the reference classes', so trained weights load into them
+(tests/test_host_logic.py compares the key lists with the reference's own classes in the build container):
+
+  PointNetPPSeg        models/modules/pointnet_pp.py:6-70 (`get_model`): three multi-scale set-abstraction levels, three
+                       feature-propagation levels, offset / distance / class heads; BASELINE.json config 2's network.
+  PointTransformerSeg  models/modules/cbl_point_transformer/cbl_point_transformer_module.py:28-216 with the configuration
+                       the reference ships (default.yaml: five stages, `multi` heads over the decoder stages, latent
+                       features concatenated); BASELINE.json configs 3 / 4's network.  Inference outputs only: the
+                       contrastive-boundary criterion of training (heads.py:62-253) is the reference's own Python.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import point_transformer as PT, pointops
+from .pointnet2_utils import PointNetFeaturePropagation, PointNetSetAbstractionMsg
+
+
+class PointNetPPSeg(nn.Module):
+    def __init__(self, input_feature_num=6, scale=4, cls_pred=True):
+        super().__init__()
+        s, self.cls_pred = scale, cls_pred
+        self.sa1 = PointNetSetAbstractionMsg(1024, [0.025, 0.05], [32, 64], input_feature_num, [[32 * s, 32 * s]] * 2)
+        self.sa2 = PointNetSetAbstractionMsg(512, [0.05, 0.1], [32, 64], 64 * s, [[64 * s, 128 * s]] * 2)
+        self.sa3 = PointNetSetAbstractionMsg(256, [0.1, 0.2], [32, 64], 256 * s, [[196 * s, 256 * s]] * 2)
+        self.fp3 = PointNetFeaturePropagation(768 * s, [256 * s, 256 * s])
+        self.fp2 = PointNetFeaturePropagation(320 * s, [128 * s, 128 * s])
+        self.fp1 = PointNetFeaturePropagation(128 * s + input_feature_num, [64 * s, 32 * s])
+        for head, width in (("offset", 3), ("dist", 1)):
+            setattr(self, f"{head}_conv_1", nn.Conv1d(32 * s, 16, 1))
+            setattr(self, f"{head}_bn_1", nn.BatchNorm1d(16))
+        self.offset_conv_2, self.dist_conv_2 = nn.Conv1d(16, 3, 1), nn.Conv1d(16, 1, 1)
+        if cls_pred:
+            self.cls_conv_1, self.cls_bn_1, self.cls_conv_2 = nn.Conv1d(32 * s, 17, 1), nn.BatchNorm1d(17), nn.Conv1d(17, 17, 1)
+        nn.init.zeros_(self.offset_conv_2.weight)
+        nn.init.zeros_(self.dist_conv_2.weight)
+        self.conv1, self.bn1 = nn.Conv1d(32, 16, 1), nn.BatchNorm1d(16)     # declared and unused in the reference too (:38-40)
+
+    def _head(self, name, x):
+        y = F.relu(getattr(self, f"{name}_bn_1")(getattr(self, f"{name}_conv_1")(x)))
+        return getattr(self, f"{name}_conv_2")(y)
+
+    def forward(self, xyz_in):
+        """xyz_in: [features (B, C, N)] with xyz in the first three channels -> the reference's output list
+        [l0_points, l3_points, l0_xyz, l3_xyz, offset, dist(, cls)] (pointnet_pp.py:60-68)."""
+        feats = xyz_in[0]
+        xyz = [feats[:, :3, :]]
+        pts = [feats]
+        for sa in (self.sa1, self.sa2, self.sa3):
+            x, p = sa(xyz[-1], pts[-1])
+            xyz.append(x)
+            pts.append(p)
+        up = pts[3]
+        for lvl, fp in ((2, self.fp3), (1, self.fp2), (0, self.fp1)):
+            up = fp(xyz[lvl], xyz[lvl + 1], pts[lvl], up)
+        out = [up, pts[3], xyz[0], xyz[3], self._head("offset", up), self._head("dist", up)]
+        if self.cls_pred:
+            out.append(self._head("cls", up))
+        return out
+
+
+class _LatentMLP(nn.Module):
+    """blocks.py:159-194 with ftype 'latent': Linear + BatchNorm + ReLU to base_fdim, held as `.infer`."""
+
+    def __init__(self, fdim, d_out):
+        super().__init__()
+        self.infer = nn.Sequential(nn.Linear(fdim, d_out), nn.BatchNorm1d(d_out), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return self.infer(x)
+
+
+class MultiHead(nn.Module):
+    """heads.py:13-61 for `multi: {stage: Ua, ftype: latent, combine: concat}`: every decoder stage's features go through
+    their own latent MLP, are carried to the finest stage by nearest-neighbour interpolation (pointops.interpolation, k = 1)
+    and concatenated in front of one linear classifier."""
+
+    def __init__(self, fdims, k, base_fdim=32):
+        super().__init__()
+        self.infer_list = nn.ModuleList([_LatentMLP(f, base_fdim) for f in fdims])
+        self.cls = nn.Linear(base_fdim * len(fdims), k)
+
+    def forward(self, up_list):
+        p0, _, o0 = up_list[0]
+        cols = []
+        for i, ((p, x, o), mlp) in enumerate(zip(up_list, self.infer_list)):
+            y = mlp(x)
+            cols.append(y if i == 0 else pointops.interpolation(p, p0, y.contiguous(), o, o0, k=1))
+        return self.cls(torch.cat(cols, 1))
+
+
+class PointTransformerSeg(nn.Module):
+    def __init__(self, c=6, k=17, planes=(32, 64, 128, 256, 512), blocks=(2, 3, 4, 6, 3), stride=(1, 4, 4, 4, 4),
+                 nsample=(36, 24, 24, 24, 24), share_planes=8):
+        super().__init__()
+        self.c, self.k = c, k
+        in_planes = c
+        for i in range(5):
+            layers = [PT.TransitionDown(in_planes, planes[i], stride[i], nsample[i])]
+            in_planes = planes[i]
+            layers += [PT.PointTransformerBlock(in_planes, in_planes, share_planes, nsample[i]) for _ in range(1, blocks[i])]
+            setattr(self, f"enc{i + 1}", nn.Sequential(*layers))
+        for i in range(4, -1, -1):
+            layers = [PT.TransitionUp(in_planes, None if i == 4 else planes[i])]
+            in_planes = planes[i]
+            layers.append(PT.PointTransformerBlock(in_planes, in_planes, share_planes, nsample[i]))
+            setattr(self, f"dec{i + 1}", nn.Sequential(*layers))
+        self.mask_head = MultiHead(planes, 2, planes[0])
+        self.cls_head = MultiHead(planes, k, planes[0])
+        self.offset_head = MultiHead(planes, 3, planes[0])
+
+    def forward(self, inputs):
+        """inputs: [features (B, C, N)] -> [cls (B, k, N), offset (1, 3, N) or None, None, x1 (B*N, planes[0])]
+        (cbl_point_transformer_module.py:196-216 without the training criterion)."""
+        feats = inputs[0]
+        B, C, N = feats.shape
+        pxo = feats.permute(0, 2, 1)
+        x = pxo.reshape(-1, C).contiguous()
+        p = pxo[:, :, :3].reshape(-1, 3).contiguous()
+        o = pointops.register_offsets(torch.arange(1, B + 1, dtype=torch.int32, device=feats.device) * N,
+                                      [N * (i + 1) for i in range(B)])
+        down, cur = [], [p, x, o]
+        for i in range(1, 6):
+            cur = getattr(self, f"enc{i}")(cur)
+            down.append(cur)
+        up, above = [None] * 5, None
+        for i in range(4, -1, -1):
+            pi, xi, oi = down[i]
+            dec = getattr(self, f"dec{i + 1}")
+            head = dec[0]([pi, xi, oi]) if above is None else dec[0]([pi, xi, oi], above)
+            xi = dec[1:]([pi, head, oi])[1]
+            above = up[i] = [pi, xi, oi]
+        cls = self.cls_head(up).view(B, N, self.k).permute(0, 2, 1)
+        offset = self.offset_head(up).view(B, N, 3).permute(0, 2, 1) if B == 1 else None
+        return [cls, offset, None, up[0][1]]

@@ -177,16 +177,25 @@ def preprocess_sharded(pairs, save_path, rank, world, batch=16, fps_batch=None, 
             "per_rank_scans": [int(round(v)) for v in mat[:, 0]], "meshes_per_s": float(tot[0] / seconds) if seconds > 0 else 0.0}
 
 
-def transfer_labels(sampled_xyz, sampled_labels, vertices):
+def transfer_labels(sampled_xyz, sampled_labels, vertices, candidates=4):
     """Labels of the 24 000 sampled points back onto every vertex: the 1-nearest-neighbour query of
-    inference_pipeline_sem.py:37-39 (sklearn KDTree there) as the GPU kNN with k = 1 -- fp32 distances: the same
-    neighbour wherever the nearest one is unique at fp32 resolution."""
+    inference_pipeline_sem.py:37-39 (sklearn KDTree on float64 coordinates there).  The GPU kNN proposes the `candidates`
+    nearest samples per vertex in fp32 (the kernel's arithmetic) and the nearest of those is picked by float64 distances
+    on the original coordinates -- the KDTree's answer wherever the nearest sample is unique in float64 (equidistant
+    samples: the lower sample index)."""
     import torch
     from . import pointops
     dev = torch.device("cuda")
-    s = torch.from_numpy(np.ascontiguousarray(sampled_xyz[:, :3], dtype=np.float32)).to(dev)
-    v = torch.from_numpy(np.ascontiguousarray(vertices[:, :3], dtype=np.float32)).to(dev)
-    o = torch.tensor([s.shape[0]], dtype=torch.int32, device=dev)
-    n_o = torch.tensor([v.shape[0]], dtype=torch.int32, device=dev)
-    idx, _ = pointops.knnquery(1, s, v, o, n_o)
+    s64 = torch.from_numpy(np.ascontiguousarray(np.asarray(sampled_xyz)[:, :3], dtype=np.float64)).to(dev)
+    v64 = torch.from_numpy(np.ascontiguousarray(np.asarray(vertices)[:, :3], dtype=np.float64)).to(dev)
+    k = max(1, min(int(candidates), s64.shape[0]))
+    o = torch.tensor([s64.shape[0]], dtype=torch.int32, device=dev)
+    n_o = torch.tensor([v64.shape[0]], dtype=torch.int32, device=dev)
+    idx, _ = pointops.knnquery(k, s64.float().contiguous(), v64.float().contiguous(), o, n_o)     # (V, k) int32
+    idx = idx.long()
+    if k > 1:
+        d = ((s64[idx.reshape(-1)].view(-1, k, 3) - v64[:, None, :]) ** 2).sum(-1)               # float64, (V, k)
+        best = d.min(1, keepdim=True).values
+        cand = torch.where(d == best, idx, torch.full_like(idx, s64.shape[0]))                    # exact ties: lowest index
+        idx = cand.min(1).values
     return np.asarray(sampled_labels).reshape(-1)[idx.reshape(-1).cpu().numpy()]
