@@ -112,10 +112,12 @@ def main():
     ap.add_argument("--early-grid", type=int, default=-1, help="phased schedule: build the level-1 ball-query grid ahead of the fence (-1 default on)")
     ap.add_argument("--group-gate", type=int, default=-1, help="1: groupings of a step wait for its last ball query, i.e. run beside the next "
                     "step's FPS level 1 (-1: default on when pipelined)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL; gloo lets several ranks share "
+                    "one GPU, e.g. to exercise the N > 1 branch on a one-GPU box)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra with_fps_prefix_identity measurement (profiling runs)")
     args = ap.parse_args()
 
-    rank, local_rank, world, device = sharding.init_from_env()
+    rank, local_rank, world, device = sharding.init_from_env(backend=args.backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU implementation")
     if world != max(args.gpus, 1):
@@ -149,7 +151,8 @@ def main():
     torch.cuda.synchronize()
     sharding.barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(elapsed, device=device)
+    per_rank_s = sharding.gather_metrics([elapsed], device=device).reshape(-1).cpu().tolist()   # the one collective of the run
+    elapsed = max(per_rank_s)
 
     total_meshes = B * args.steps * world
     value = total_meshes / elapsed
@@ -163,6 +166,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        "per_rank_seconds": [round(v, 6) for v in per_rank_s],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

@@ -311,6 +311,9 @@ int tgn_three_interpolate(int B, int N, int S, int C, const float *points2, cons
  * last call; it synchronises `stream`.  (The Python operators call it and raise IndexError.)
  */
 int tgn_take_index_error(tgn_stream_t stream);
+/* Clears the flag in stream order without synchronising: what a checked operator issues in front of its own launch, so
+ * that a bit latched by an earlier UNCHECKED launch is not attributed to it. */
+int tgn_clear_index_error(tgn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * 4. Mesh input of the preprocess path (HOST pointers, CPU code): gen_utils.read_txt_obj_ls (gen_utils.py:207-233).

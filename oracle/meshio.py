@@ -40,9 +40,10 @@ def vertex_normals(vertices, triangles):
         out[a] += n
         out[b] += n
         out[c] += n
-    with np.errstate(invalid="ignore", divide="ignore"):
-        ln = np.sqrt(out[:, 0] * out[:, 0] + out[:, 1] * out[:, 1] + out[:, 2] * out[:, 2])
-        out = out / ln[:, None]
+    # Eigen's normalize() (>= 3.3) divides only when the squared norm is > 0: a zero sum stays (0, 0, 0)
+    z = out[:, 0] * out[:, 0] + out[:, 1] * out[:, 1] + out[:, 2] * out[:, 2]
+    pos = z > 0
+    out[pos] = out[pos] / np.sqrt(z[pos])[:, None]
     bad = np.isnan(out[:, 0])
     out[bad] = (0.0, 0.0, 1.0)
     return out

@@ -1,6 +1,8 @@
 """FPS of an FPS result is the identity (include/tgn_pointops.h, tgn_furthestsampling_dense_prefix): the certificate
 each kernel writes, the on-device shortcut, and the tensor-identity bookkeeping of the drop-in modules.  Whatever
 path is taken, the indices must be the ones the oracle computes by actually sampling."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -184,11 +186,12 @@ def test_hotpath_with_prefix_certificates_equals_plain(dev):
         assert all(int(lv["cert"].min()) == lv["S"] for lv in levels)
 
 
-def test_packed_transition_down_chain_with_content_checked_certificates(dev, oracle):
+def test_packed_transition_down_chain_with_content_checked_certificates(dev, oracle, monkeypatch):
     """the Point-Transformer idiom (blocks.py:62-74): idx = furthestsampling(p, o, n_o); n_p = p[idx]; next level
     samples n_p.  Provenance is checked by content on the device; ragged batch with one degenerate cloud (falls back
     inside the same launch) and a perturbed copy (must not be believed)."""
     from toothgroupnetwork_amd import pointops as P
+    monkeypatch.setattr(P, "FPS_PREFIX", True)      # the plain operator takes part only when asked to (TGN_FPS_PREFIX=1)
     P.fps_prefix_clear()
     P.fps_prefix_stats["offered"] = 0
     dup = np.repeat(synth.uniform_cloud(150, 4), 8, axis=0)                  # 150 distinct points in 1200 rows
@@ -213,9 +216,29 @@ def test_packed_transition_down_chain_with_content_checked_certificates(dev, ora
     got = P.furthestsampling(q, o, n_o2)
     assert np.array_equal(got.cpu().numpy(), oracle.furthestsampling(q.cpu().numpy(), o_np, n_o2.cpu().numpy()))
     # TGN_FPS_PREFIX off: identical indices
-    P.FPS_PREFIX, keep = False, P.FPS_PREFIX
-    try:
-        off_idx = P.furthestsampling(T(xyz, dev), T(off, dev), T(np.cumsum([c.shape[0] // 4 for c in clouds]).astype(np.int32), dev))
-    finally:
-        P.FPS_PREFIX = keep
+    monkeypatch.setattr(P, "FPS_PREFIX", False)
+    off_idx = P.furthestsampling(T(xyz, dev), T(off, dev), T(np.cumsum([c.shape[0] // 4 for c in clouds]).astype(np.int32), dev))
     assert np.array_equal(off_idx.cpu().numpy(), oracle.furthestsampling(xyz, off, np.cumsum([c.shape[0] // 4 for c in clouds]).astype(np.int32)))
+
+
+def test_shortcut_is_opt_in_and_survives_raw_writes_into_the_callers_tensor(dev, oracle, monkeypatch):
+    """(1) The plain operators never take the shortcut by themselves (only call sites that chain levels ask for it).
+    (2) The book compares against a PRIVATE copy: a write into the caller's new_xyz that no version counter sees
+    (`.data`) must fail the content check -- the stale certificate is not believed."""
+    from toothgroupnetwork_amd import pointnet2_utils as U, pointops as P
+    assert U.FPS_PREFIX is None and P.FPS_PREFIX is None or os.environ.get("TGN_FPS_PREFIX") is not None
+    U.fps_prefix_clear()
+    U.fps_prefix_stats["offered"] = 0
+    xyz = T(synth.scan_batch(2, 5000, "arch", 77)[:, :, :3].copy(), dev)
+    nx = U.index_points(xyz, U.farthest_point_sample(xyz, 700))
+    U.farthest_point_sample(nx, 100)
+    if U.FPS_PREFIX is None:
+        assert U.fps_prefix_stats["offered"] == 0
+    monkeypatch.setattr(U, "FPS_PREFIX", True)
+    U.fps_prefix_clear()
+    _, nx = U._fps_dense(xyz, 700, want_coords=True)
+    nx.data[1, 10:20] = nx.data[1, 10:20].flip(0)          # in place, version counter untouched
+    got = U.farthest_point_sample(nx, 300)
+    want = oracle.farthest_point_sample(nx.cpu().numpy(), 300)
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(want[0], np.arange(300)) and not np.array_equal(want[1], np.arange(300))

@@ -51,9 +51,12 @@ def test_obj_reader_quirks_and_errors(tmp_path):
             preprocess.read_obj(str(p))
     with pytest.raises(ValueError):
         preprocess.read_obj(str(tmp_path / "missing.obj"))
-    # a vertex no triangle touches gets open3d's (0,0,1); a triangle index out of range is an error
+    # a vertex no triangle touches keeps its zero sum (Eigen's normalize() leaves a zero vector alone; open3d's (0,0,1)
+    # is for NaN only); a triangle index out of range is an error
     n = preprocess.vertex_normals(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [5, 5, 5]], float), np.array([[0, 1, 2]]))
-    assert np.array_equal(n, [[0, 0, 1]] * 4)
+    assert np.array_equal(n, [[0, 0, 1]] * 3 + [[0, 0, 0]])
+    n = preprocess.vertex_normals(np.array([[0, 0, 0], [1, 0, 0], [0, 1, np.nan]], float), np.array([[0, 1, 2]]))
+    assert np.array_equal(n, [[0, 0, 1]] * 3)                                  # NaN coordinates: the substitution
     with pytest.raises(ValueError):
         preprocess.vertex_normals(np.zeros((3, 3)), np.array([[0, 1, 3]]))
     lab = preprocess.remap_fdi_labels([0, 11, 18, 21, 28, 31, 38, 41, 48], "upper").reshape(-1)

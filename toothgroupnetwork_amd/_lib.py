@@ -6,6 +6,7 @@ If the library has not been built (``python -c "import __graft_entry__ as g; g.b
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -83,6 +84,7 @@ SIGNATURES = {
     "tgn_three_nn": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "tgn_three_interpolate": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P]),
     "tgn_take_index_error": (c_int, [_P]),
+    "tgn_clear_index_error": (c_int, [_P]),
     "tgn_square_distance": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P]),
     # section 4 (host pointers)
     "tgn_obj_count": (c_int, [ctypes.c_char_p, _P, _P]),
@@ -197,12 +199,50 @@ def take_index_error():
     return bool(lib().tgn_take_index_error(stream()))
 
 
+_check_state = threading.local()
+
+
+def _checking():
+    return INDEX_CHECK != "off" and not torch.cuda.is_current_stream_capturing()   # (a host read cannot be captured)
+
+
+def begin_index_check():
+    """In front of a checked launch: drop whatever UNCHECKED launches latched before it (HotPath, captured graphs, the
+    training path's trusted gathers, TGN_INDEX_CHECK=off sections), in stream order and without a synchronisation, so that
+    the IndexError raised afterwards belongs to this operator.  No-op inside a deferred_index_check() section."""
+    if _checking() and not getattr(_check_state, "depth", 0):
+        lib().tgn_clear_index_error(stream())
+
+
 def raise_on_index_error(what):
-    if INDEX_CHECK == "off" or torch.cuda.is_current_stream_capturing():   # (a host read cannot be captured into a HIP graph)
+    """Behind a checked launch: one 4-byte device->host copy + stream synchronisation (that is the price of the
+    reference's error behaviour; TGN_INDEX_CHECK=off drops it).  Inside deferred_index_check() the read is left to the
+    end of the section."""
+    if not _checking() or getattr(_check_state, "depth", 0):
         return
     if take_index_error():
         raise IndexError(f"{what}: index out of range for the gathered dimension "
                          "(the reference's advanced indexing raises here too, pointnet2_utils.py:56-60)")
+
+
+class deferred_index_check:
+    """`with deferred_index_check("set abstraction"):` -- ONE flag read (one synchronisation) for all the gather launches of
+    the section instead of one per launch: the fused eval path of a set-abstraction module issues up to six."""
+
+    def __init__(self, what):
+        self.what = what
+
+    def __enter__(self):
+        if not getattr(_check_state, "depth", 0):
+            begin_index_check()
+        _check_state.depth = getattr(_check_state, "depth", 0) + 1
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        _check_state.depth -= 1
+        if exc_type is None and not _check_state.depth:
+            raise_on_index_error(self.what)
+        return False
 
 
 def as_int(v):

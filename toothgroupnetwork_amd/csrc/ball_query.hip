@@ -610,6 +610,7 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
             cur = nxt;
             continue;
         }
+        wave_lds_fence();   // the bits were set by whichever lanes held the hits
         {   // base rank of every 128-index group
             unsigned c[4] = {0u, 0u, 0u, 0u};   // nquad <= 4
             unsigned tot = 0;
@@ -637,6 +638,7 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
                 }
             }
         }
+        wave_lds_fence();   // gbase and the hit list cross lanes
         if (H <= kBmHitCap) {
             for (int i = lane; i < H; i += kWave) {
                 const int v = hits[i];
@@ -652,7 +654,9 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
             const int fv = __builtin_amdgcn_readlane(first, (int)__builtin_ctzll(fm));
             for (int j = H + lane; j < K; j += kWave) put(j, fv);
         }
+        wave_lds_fence();   // every rank has been read: the bitmap can be wiped for the next query
         for (int t = 0; t < nquad; ++t) *(u32x4 *)&bm[(lane * nquad + t) * 4] = u32x4{0u, 0u, 0u, 0u};
+        wave_lds_fence();
         cur = nxt;
     }
 }

@@ -62,6 +62,15 @@ TGN_API int tgn_take_index_error(tgn_stream_t stream) {
     return h;
 }
 
+// Forget whatever earlier launches latched, in stream order (no synchronisation): a checked operator calls this in front of
+// its own launch so that a bit left by an UNCHECKED launch (a planner, a captured graph, TGN_INDEX_CHECK=off sections) is not
+// blamed on it.
+TGN_API int tgn_clear_index_error(tgn_stream_t stream) {
+    int *w = tgn::index_error_word();
+    if (!w) return TGN_OK;
+    return hipMemsetAsync(w, 0, sizeof(int), (hipStream_t)stream) == hipSuccess ? TGN_OK : TGN_ERR_LAUNCH;
+}
+
 // A planner's spacer: one wave that sleeps for about `microseconds` on `stream` (100 MHz wall clock).  HotPath uses it to
 // hold the groupings back until the FPS level-1 workgroups have read their clouds.
 namespace tgn {

@@ -217,11 +217,17 @@ TGN_API int tgn_vertex_normals(const double *vertices, long long nv, const long 
     }
     for (long long i = 0; i < nv; ++i) {
         double *n = normals + i * 3;
-        const double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-        n[0] /= len;
-        n[1] /= len;
-        n[2] /= len;
-        if (n[0] != n[0]) {   // NaN (no incident triangle, or a degenerate fan): open3d substitutes (0, 0, 1)
+        // open3d: vertex_normals_[i].normalize(); if (isnan(x)) -> (0, 0, 1).  Eigen (>= 3.3) normalises only when the squared
+        // norm is > 0, so a vertex without triangles (or a degenerate fan) KEEPS its zero sum; only NaN input reaches the
+        // substitution.  (Restated from the published sources: open3d is not installed here -- parity unpinned.)
+        const double z = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+        if (z > 0.0) {
+            const double len = sqrt(z);
+            n[0] /= len;
+            n[1] /= len;
+            n[2] /= len;
+        }
+        if (n[0] != n[0]) {
             n[0] = 0.0;
             n[1] = 0.0;
             n[2] = 1.0;

@@ -142,15 +142,19 @@ __global__ __launch_bounds__(256) void pt_softmax_aggregate_fwd_kernel(int n, in
             float mx = -INFINITY;
             for (int j = 0; j < nsample; ++j) mx = fmaxf(mx, lrow[j * g_ + g0]);
             float s = 0.0f;
-            for (int j = 0; j < nsample; ++j) s += __expf(lrow[j * g_ + g0] - mx);
+            for (int j = 0; j < nsample; ++j) s += expf(lrow[j * g_ + g0] - mx);   // expf, not __expf: the training path tracks torch.exp
             const float inv = 1.0f / s;
             for (int j = 0; j < nsample; ++j) {
-                const float w = __expf(lrow[j * g_ + g0] - mx) * inv;
+                const float w = expf(lrow[j * g_ + g0] - mx) * inv;
                 sw[j * g_ + g0] = w;
                 srow[j * g_ + g0] = w;   // kept for the backward pass
             }
         }
-        // (the same wave wrote sw: LDS operations of one wave complete in order)
+        // sw was written by other lanes of this wave: the hardware completes a wave's LDS operations in order, the fence
+        // and the wave barrier keep the COMPILER from moving the reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int ch = (int)lane; ch < c; ch += 64) {
             const int g = ch % g_;
             float acc = 0.0f;
@@ -160,6 +164,7 @@ __global__ __launch_bounds__(256) void pt_softmax_aggregate_fwd_kernel(int n, in
             }
             out[(size_t)pt * c + ch] = acc;
         }
+        __builtin_amdgcn_wave_barrier();   // the next point's weights overwrite sw
     }
 }
 
@@ -203,12 +208,16 @@ __global__ __launch_bounds__(256) void pt_softmax_aggregate_bwd_kernel(int n, in
             }
             dsm[e] = acc;
         }
-        for (int g0 = (int)lane; g0 < g_; g0 += 64) {   // (same wave wrote dsm: LDS operations complete in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // dsm crosses lanes: see the forward kernel
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int g0 = (int)lane; g0 < g_; g0 += 64) {
             float dot = 0.0f;
             for (int j = 0; j < nsample; ++j) dot += srow[j * g_ + g0] * dsm[j * g_ + g0];
             for (int j = 0; j < nsample; ++j)
                 d_logit[((size_t)pt * nsample + j) * g_ + g0] = srow[j * g_ + g0] * (dsm[j * g_ + g0] - dot);
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

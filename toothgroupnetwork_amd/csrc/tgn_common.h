@@ -113,4 +113,14 @@ __device__ __forceinline__ T idx_load(const void *p, long long i, bool is64) {
     return is64 ? (T)((const long long *)p)[i] : (T)((const int *)p)[i];
 }
 
+
+// LDS words written by some lanes of a wave and read by OTHER lanes of the same wave: the hardware completes one wave's
+// LDS operations in order, but the compiler's memory model does not know that -- a wavefront-scope release / acquire pair
+// around a wave barrier (no instructions) keeps it from moving the reads above the writes.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 }  // namespace tgn

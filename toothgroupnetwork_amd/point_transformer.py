@@ -179,7 +179,7 @@ class TransitionDown(nn.Module):
             torch.cuda.current_stream().wait_event(ev)
         else:
             n_o = self.sample_offsets(o)
-            idx, n_p = pointops.fps_with_coords(p, o, n_o)                 # blocks.py:69-70: indices and p[idx] from one kernel
+            idx, n_p = pointops.fps_with_coords(p, o, n_o, prefix=True)                 # blocks.py:69-70: indices and p[idx] from one kernel
         C1 = self.linear.out_features
         if _frozen(self, p, x) and self.nsample <= 64 and C1 % 4 == 0 and x.dtype == torch.float32:
             # the whole down-sampling step fused: (m, nsample, 3+c) is never built (blocks.py:71-73)
@@ -291,7 +291,7 @@ class PointTransformerUNet(nn.Module):
                 if td.stride == 1:
                     continue
                 n_o = td.sample_offsets(oo)
-                idx, n_p = pointops.fps_with_coords(pp, oo, n_o)
+                idx, n_p = pointops.fps_with_coords(pp, oo, n_o, prefix=True)
                 ev = torch.cuda.Event()
                 ev.record(side)
                 for t in (n_o, idx, n_p):

@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from . import _lib
+from . import _fps_prefix
 from ._fps_prefix import PrefixBook
 from ._lib import as_int, check, lib, ptr, require_cuda, stream
 
@@ -103,6 +104,7 @@ class _IndexPoints(Function):
         B, N, C = points.shape
         M = idx.numel() // B if B else 0
         out = torch.empty(tuple(idx.shape) + (C,), dtype=torch.float32, device=points.device)
+        _lib.begin_index_check()
         check(lib().tgn_gather_points(B, N, M, C, ptr(points), ptr(idx), int(idx.dtype == torch.int64), ptr(out),
                                       stream()), "gather_points")
         _lib.raise_on_index_error("index_points")
@@ -142,9 +144,10 @@ def index_points(points, idx):
 # kernel that produced new_xyz also leaves a per-cloud certificate.  A later FPS whose input has the shape of a recent
 # result is offered that result and its certificate; the kernel compares the input with the stored coordinates bit for
 # bit, per cloud, and only then writes 0..S-1 instead of iterating -- provenance by content, nothing is assumed about
-# how the tensor travelled (module round trips, index_points(xyz, fps_idx), copies).  TGN_FPS_PREFIX=0 turns it off.
+# how the tensor travelled (module round trips, index_points(xyz, fps_idx), copies).  Opt-in per call site: the
+# set-abstraction modules in eval mode ask for it, the plain operators do not (TGN_FPS_PREFIX=1 / 0 forces it on / off).
 # ---------------------------------------------------------------------------------------------
-FPS_PREFIX = os.environ.get("TGN_FPS_PREFIX", "1") != "0"
+FPS_PREFIX = _fps_prefix.FORCE     # None: opt-in per call site (the modules below); True / False: forced (TGN_FPS_PREFIX)
 _fps_book = PrefixBook()
 fps_prefix_stats = _fps_book.stats
 
@@ -156,13 +159,15 @@ def fps_prefix_clear():
 # ---------------------------------------------------------------------------------------------
 # farthest point sampling
 # ---------------------------------------------------------------------------------------------
-def _fps_dense(xyz, npoint, want_coords=False, cuda_compat=False):
+def _fps_dense(xyz, npoint, want_coords=False, cuda_compat=False, prefix=False, mode=None):
+    """mode: explicit tie-order / contraction flag bits (None: the process-wide _lib.set_fps_mode() setting)."""
     require_cuda(xyz)
     npoint = as_int(npoint)
     xyz = _f32c(xyz.detach())
     B, N, _ = xyz.shape
-    mode = _lib.fps_flags(cuda_compat)
-    use_prefix = FPS_PREFIX and not (mode & _lib.FPS_TREE_TIES)   # the tree tie order breaks the identity
+    mode = _lib.fps_flags(cuda_compat) if mode is None else int(mode)
+    # prefix: this call site chains sampling levels (FPS of an FPS result is the identity); the tree tie order breaks it
+    use_prefix = _fps_prefix.use_prefix(prefix, FPS_PREFIX) and not (mode & _lib.FPS_TREE_TIES)
     idx = torch.empty(B, npoint, dtype=torch.int64, device=xyz.device)
     new_xyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=xyz.device) if (want_coords or use_prefix) else None
     if B == 0 or npoint == 0:
@@ -192,7 +197,10 @@ def farthest_point_sample(xyz, npoint):
 
 def farthest_point_sample_np(xyz, npoint):
     """numpy in / numpy out variant with a RANDOM first sample (pointnet2_utils.py:103-118), indices bit-identical
-    to the reference's torch-CPU loop for the same torch RNG state -- ties included.
+    to the reference's torch-CPU loop for the same torch RNG state -- ties included -- for float32 input.  (float64 input:
+    the reference keeps the numpy dtype, computes the squared distances in float64 and rounds them to float32 only when
+    it stores them (:113-116); here the coordinates are rounded to float32 first, so the arg-max may differ where two
+    candidates are closer than float32 resolution.)
 
     The start is drawn with the reference's own call, torch.randint(0, N, (B,), dtype=torch.long) (:109).  The GPU
     kernel always starts at a cloud's first point, so each cloud is sampled as [p_start, p_0, ..., p_{N-1}]: the copy
@@ -205,14 +213,9 @@ def farthest_point_sample_np(xyz, npoint):
     farthest = torch.randint(0, N, (B,), dtype=torch.long)
     first = torch.gather(xyz_t, 1, farthest.view(B, 1, 1).expand(B, 1, 3))
     padded = torch.cat([first, xyz_t], dim=1).to(torch.device("cuda"))
-    prev = _lib.get_fps_mode()
-    if prev != ("first", False):        # this function IS the torch-CPU semantics, whatever mode the kernels are in
-        _lib.set_fps_mode("first", False)
-    try:
-        idx = _fps_dense(padded, npoint)[0].cpu() - 1
-    finally:
-        if prev != ("first", False):
-            _lib.set_fps_mode(*prev)
+    # this function IS the torch-CPU semantics (first-index ties, unfused distance), whatever mode the kernels are in:
+    # the flags go with the call, the process-wide mode is not touched (other threads may be sampling)
+    idx = _fps_dense(padded, npoint, mode=0)[0].cpu() - 1
     if idx.shape[1] > 0:
         idx[:, 0] = farthest
     idx.clamp_(min=0)
@@ -266,6 +269,7 @@ class _GroupPoints(Function):
         _, S, K = idx.shape
         D = 0 if points is None else points.shape[2]
         out = torch.empty(B, S, K, 3 + D, dtype=torch.float32, device=xyz.device)
+        _lib.begin_index_check()
         check(lib().tgn_group_points(B, N, S, K, D, ptr(xyz), ptr(new_xyz), ptr(points), ptr(idx),
                                      int(idx.dtype == torch.int64), int(xyz_first), ptr(out), stream()),
               "group_points")
@@ -457,6 +461,7 @@ def sa_level_max(xyz, new_xyz, points, idx, conv, bn, xyz_first):
     idx = idx.contiguous()
     out = torch.empty(B, S, C1, dtype=torch.float32, device=xyz.device)
     L = lib()
+    _lib.begin_index_check()
     if L.tgn_sa_direct_supported(K, D, C1):
         check(L.tgn_sa_direct_max(B, N, S, K, D, C1, ptr(xyz), ptr(new_xyz), ptr(points), ptr(f["Wd"]), ptr(f["b2"]), ptr(idx),
                                   int(idx.dtype == torch.int64), 1, ptr(out), stream()), "sa_direct_max")
@@ -485,6 +490,7 @@ def sa_first_layer(xyz, new_xyz, points, idx, conv, bn, xyz_first, reduce_max=Fa
     idx = idx.contiguous()
     A = sa_point_transform(xyz, points, f["Wt"])
     out = torch.empty(B, S, K, C1, dtype=torch.float32, device=xyz.device)
+    _lib.begin_index_check()
     check(lib().tgn_sa_gather_act(B, N, S, K, C1, ptr(A), ptr(new_xyz), ptr(f["Wxs"]), ptr(f["b2"]), ptr(idx),
                                   int(idx.dtype == torch.int64), 1, ptr(out), stream()), "sa_gather_act")
     _lib.raise_on_index_error("set abstraction (grouping)")
@@ -535,7 +541,7 @@ class PointNetSetAbstraction(nn.Module):
             # eval fast path: FPS (+coordinates) -> ball query -> fused first layer; `grouped` is never built
             xyz_c = _f32c(xyz)
             points_c = None if points is None else _f32c(points)
-            _, new_xyz = _fps_dense(xyz_c, self.npoint, want_coords=True)
+            _, new_xyz = _fps_dense(xyz_c, self.npoint, want_coords=True, prefix=True)
             idx = query_ball_point(self.radius, self.nsample, xyz_c, new_xyz)
             if len(self.mlp_convs) == 1:     # the whole level in the fused kernels
                 new_points = sa_level_max(xyz_c, new_xyz, points_c, idx, self.mlp_convs[0], self.mlp_bns[0], True).permute(0, 2, 1)
@@ -586,7 +592,7 @@ class PointNetSetAbstractionMsg(nn.Module):
         if xyz.requires_grad:
             new_xyz = index_points(xyz, farthest_point_sample(xyz, S))
         else:
-            _, new_xyz = _fps_dense(xyz, S, want_coords=True)
+            _, new_xyz = _fps_dense(xyz, S, want_coords=True, prefix=not self.training)
         xyz_c = _f32c(xyz)
         points_c = None if points is None else _f32c(points)
         fuse = _can_fuse(self, xyz, points)

@@ -16,6 +16,7 @@ from torch.autograd import Function
 from torch.utils.weak import WeakTensorKeyDictionary
 
 from . import _lib
+from . import _fps_prefix
 from ._fps_prefix import PrefixBook
 from ._lib import as_int, check, lib, ptr, require_cuda, stream
 
@@ -90,7 +91,7 @@ def fps_workspace(b, n_max, n_total, device):
     return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
 
 
-FPS_PREFIX = os.environ.get("TGN_FPS_PREFIX", "1") != "0"
+FPS_PREFIX = _fps_prefix.FORCE     # None: opt-in per call site (fps_with_coords(prefix=True)); True / False: forced
 _fps_book = PrefixBook()
 fps_prefix_stats = _fps_book.stats
 
@@ -99,9 +100,10 @@ def fps_prefix_clear():
     _fps_book.clear()
 
 
-def fps_with_coords(xyz, offset, new_offset, cuda_compat=False):
+def fps_with_coords(xyz, offset, new_offset, cuda_compat=False, prefix=False):
     """furthestsampling that also returns the sampled coordinates xyz[idx] straight from the kernel
-    (what blocks.py:69-70 computes with a second gather).  Returns (idx int32 (m,), new_xyz (m,3))."""
+    (what blocks.py:69-70 computes with a second gather).  Returns (idx int32 (m,), new_xyz (m,3)).
+    prefix=True: this call site chains sampling levels -- take part in the FPS-of-an-FPS-result shortcut."""
     require_cuda(xyz, offset, new_offset)
     assert xyz.is_contiguous()
     xyz = xyz.float() if xyz.dtype != torch.float32 else xyz
@@ -121,7 +123,7 @@ def fps_with_coords(xyz, offset, new_offset, cuda_compat=False):
     # n_p = p[idx] itself (blocks.py:70) and samples n_p at the next level, so provenance is established by CONTENT:
     # a previous result with the same segment layout is offered as prefix_ref and the kernel takes the shortcut for a
     # cloud only if its coordinates equal that result bit for bit.
-    use_prefix = FPS_PREFIX and not (flags & _lib.FPS_TREE_TIES)
+    use_prefix = _fps_prefix.use_prefix(prefix, FPS_PREFIX) and not (flags & _lib.FPS_TREE_TIES)
     cert_in = ref = cert_out = None
     if use_prefix:
         cert_in, ref = _fps_book.offer((tuple(off_h), xyz.shape[0], flags), xyz.device)
@@ -343,6 +345,8 @@ def queryandgroup(nsample, xyz, new_xyz, feat, idx, offset, new_offset, use_xyz=
     if own_idx:
         idx, _ = knnquery(nsample, xyz, new_xyz, offset, new_offset)  # (m, nsample)
     idx = _i32(idx).contiguous()
+    if not own_idx and use_xyz:
+        _lib.begin_index_check()
     out = _QueryGroup.apply(xyz, new_xyz, feat, idx, bool(use_xyz))
     if not own_idx and use_xyz:
         # a caller's index tensor may hold anything; the reference's fancy indexing (pointops.py:89-95) raises

@@ -40,14 +40,48 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def parse_cpulist(text):
+    """'0-3,8,10-11' (sysfs cpulist syntax) -> sorted list of CPU numbers."""
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return sorted(cpus)
+
+
+def pin_to_gpu_numa(device_index, sysfs="/sys/bus/pci/devices"):
+    """Restrict this process's host threads to the CPUs of the NUMA node its GPU hangs off (the PCI device's
+    local_cpulist): one process per GPU on an 8-GPU node otherwise lets the OBJ parser / OpenMP threads of eight ranks
+    wander over both sockets (the preprocess runner is half host time).  Best effort: returns the CPU list, or None when
+    sysfs has no answer; TGN_NUMA_PIN=0 disables it."""
+    if os.environ.get("TGN_NUMA_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        cpus = parse_cpulist(open(os.path.join(sysfs, bdf, "local_cpulist")).read())
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return allowed
+    except Exception:
+        return None
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from the torchrun environment (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).
-    Returns (rank, local_rank, world, device).  world == 1 needs no process group."""
+    Returns (rank, local_rank, world, device).  world == 1 needs no process group.  With several ranks on one node every
+    rank's host threads are pinned to its GPU's NUMA node (pin_to_gpu_numa)."""
     rank, local_rank, world = env_rank_world()
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
         device = torch.device("cuda", torch.cuda.current_device())
+        if world > 1:
+            pin_to_gpu_numa(device.index)
     else:
         device = torch.device("cpu")
     if world > 1 and not dist.is_initialized():
@@ -66,9 +100,12 @@ def gather_metrics(vec, device=None):
     """All ranks contribute a 1-D fp64 vector of equal length; every rank receives the (world, k) matrix.
     This is the only collective of a sharded run."""
     vec = torch.as_tensor(vec, dtype=torch.float64)
+    live = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if live and dist.get_backend() == "gloo":
+        device = torch.device("cpu")            # gloo ranks (CPU tests, several ranks sharing one GPU): host tensors
     if device is not None:
         vec = vec.to(device)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not live:
         return vec.reshape(1, -1)
     world = dist.get_world_size()
     out = torch.empty(world * vec.numel(), dtype=torch.float64, device=vec.device)
