@@ -288,6 +288,23 @@ int tgn_sa_direct_supported(int K, int D, int C1);
 int tgn_sa_direct_max(int B, int N, int S, int K, int D, int C1, const float *xyz, const float *new_xyz,
                       const float *points, const float *Wd, const float *b2, const void *idx, int idx_is_int64, int relu,
                       float *out, tgn_stream_t stream);
+/*
+ * tgn_sa_mlp2_max: a WHOLE set-abstraction level with a TWO-layer shared MLP (what every level of the reference networks
+ * has: pointnet_pp.py:13-15, tsg_centroid_module.py:10-12, tsg_seg_module.py:11-28), eval mode, both BatchNorms folded:
+ *   out[b,s,:] = max_k relu(W2 * relu(W1 * [x[idx]-c, f[idx]] + b1) + b2)        (pointnet2_utils.py:281-294)   (B,S,C2)
+ * in ONE kernel: neither the grouped tensor nor the (B,S,K,C1) / (B,S,K,C2) layer outputs are written.  The second layer
+ * runs on the fp32 matrix cores (exact fp32).  First layer, two forms:
+ *   commuted (A1 != NULL): A1 (B,N,C1p) = tgn_sa_point_transform of the level's points with the first layer's folded
+ *     weights; W1 = Wxs (3,C1p), the x,y,z rows of those weights; xyz / points unused (may be NULL);
+ *   direct (A1 == NULL, 3+D <= 16; tgn_sa_mlp2_direct_supported): W1 = Wd (16,C1p), rows [x, y, z, f0.., zero padding].
+ * C1p = the first layer's width padded with zero columns to a multiple of 16 (b1, W1, A1 padded alike);
+ * W2f (C1p/8, C2, 8): W2f[kb][c][i] = scale2[c] * W2[c, 8*kb + i] (zero for padded k); b2 (C2) = shift2 + scale2*bias2.
+ * nsample <= 64; idx int32 or int64, local to each cloud, out-of-range handled like tgn_group_points.
+ */
+int tgn_sa_mlp2_direct_supported(int K, int D);
+int tgn_sa_mlp2_max(int B, int N, int S, int K, int D, int C1p, int C2, const float *A1, const float *xyz,
+                    const float *points, const float *new_xyz, const float *W1, const float *b1, const void *idx,
+                    int idx_is_int64, const float *W2f, const float *b2, float *out, tgn_stream_t stream);
 /* index_points (pointnet2_utils.py:44-61): out[b,j,:] = points[b, idx[b,j], :], idx flattened to (B,M). */
 int tgn_gather_points(int B, int N, int M, int C, const float *points, const void *idx, int idx_is_int64, float *out,
                       tgn_stream_t stream);

@@ -307,6 +307,20 @@ def set_abstraction_first_layer(xyz, new_xyz, points, idx, W, bias, gamma, beta,
     return y.max(axis=2) if reduce_max else y
 
 
+def set_abstraction_mlp(xyz, new_xyz, points, idx, layers, eps=1e-5, xyz_first=True):
+    """A WHOLE set-abstraction level after sampling and ball query, eval mode, restated from the reference modules:
+    grouping (pointnet2_utils.py:162-169 / 281-285) -> [Conv2d 1x1 -> BatchNorm2d (running statistics) -> ReLU] for every
+    layer of the shared MLP (:229-233 / :286-293) -> max over the K neighbours (:236 / :294).  layers: list of
+    (W (C_out, C_in), bias, gamma, beta, mean, var).  float64 accumulation; returns (B,S,C_last)."""
+    y = group_points(xyz, new_xyz, points, idx, xyz_first).astype(np.float64)            # (B,S,K,3+D)
+    f8 = lambda a: np.asarray(a, dtype=np.float64)
+    for W, bias, gamma, beta, mean, var in layers:
+        y = y @ f8(W).T + f8(bias)
+        y = (y - f8(mean)) / np.sqrt(f8(var) + eps) * f8(gamma) + f8(beta)
+        y = np.maximum(y, 0.0)
+    return y.max(axis=2)
+
+
 def pt_attention_layer(p, x_q, x_k, x_v, idx, sd, share_planes=8, eps=1e-5):
     """PointTransformerLayer.forward after the three input projections, eval mode, restated from
     models/modules/cbl_point_transformer/blocks.py:34-43 in float64.  p (n,3), x_q/x_k/x_v (n,c), idx (n,nsample) neighbour

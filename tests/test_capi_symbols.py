@@ -43,9 +43,25 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), f"{name} declared in include/ but not exported"
 
 
+def _declared_arity():
+    out = {}
+    for h in glob.glob(os.path.join(REPO, "include", "*.h")):
+        src = open(h).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", "", src)
+        src = re.sub(r"^\s*#[^\n]*", "", src, flags=re.M)
+        for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(([^;{}()]*)\)\s*;", src):
+            args = m.group(2).strip()
+            out[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
 def test_ctypes_table_matches_header():
     from toothgroupnetwork_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared_functions()
+    arity = _declared_arity()
+    for name, (_, args) in _lib.SIGNATURES.items():     # a wrong count is a TypeError (or garbage arguments) at call time
+        assert len(args) == arity[name], (name, len(args), arity[name])
     L = _lib.lib()
     assert b"gfx950" in L.tgn_version()
     assert L.tgn_fps_resident_capacity() >= 24000  # a whole 24 000-point scan stays in registers

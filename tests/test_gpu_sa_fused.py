@@ -97,14 +97,79 @@ def test_fused_level_and_first_layer_vs_oracle(dev, oracle, N, S, K, D, C1, xyz_
             close(got.cpu().numpy(), oracle.set_abstraction_first_layer(*args, reduce_max=False), "first layer")
 
 
+def _bn_np(bn):
+    return (bn.weight.detach().cpu().numpy(), bn.bias.detach().cpu().numpy(), bn.running_mean.cpu().numpy(), bn.running_var.cpu().numpy())
+
+
+# (N, S, K, D, C1, C2): the reference networks' own levels first -- pointnet_pp.py:13-15 (sa1: direct first layer; sa2; sa3:
+# 784 is no multiple of 32), tsg_centroid / tsg_seg (:10-12 / :11-13: 39-wide rows, 196 -> padded to 208) -- then odd shapes:
+# K below 32, K between 32 and 64, a single query, widths that are no multiple of the tiles
+MLP2_SHAPES = [(6000, 1024, 32, 6, 128, 128), (6000, 1024, 64, 6, 128, 128), (1024, 512, 32, 256, 256, 512),
+               (1024, 512, 64, 256, 256, 512), (512, 256, 32, 1024, 784, 1024), (512, 256, 64, 1024, 784, 1024),
+               (3000, 1024, 32, 36, 32, 32), (512, 256, 64, 256, 196, 256), (700, 50, 7, 13, 20, 36), (640, 33, 36, 200, 72, 100),
+               (300, 1, 48, 0, 16, 4), (900, 77, 17, 61, 100, 260)]
+
+
+@pytest.mark.parametrize("N,S,K,D,C1,C2", MLP2_SHAPES)
+@pytest.mark.parametrize("xyz_first", [True, False])
+def test_two_layer_level_vs_oracle(dev, oracle, N, S, K, D, C1, C2, xyz_first):
+    """tgn_sa_mlp2_max (the whole two-layer level in one kernel, direct or commuted first layer) against the float64
+    restatement of grouping -> [conv -> BN -> ReLU] x 2 -> max on real ball-query neighbourhoods, elementwise 1e-5."""
+    from toothgroupnetwork_amd import pointnet2_utils as U, synth
+    B = 2
+    rng = np.random.default_rng(N + K + D + C2)
+    pts6 = synth.scan_batch(B, N, "arch", seed=N % 89)
+    xyz = np.ascontiguousarray(pts6[:, :, :3])
+    feat = rng.normal(size=(B, N, D)).astype(np.float32) if D else None
+    tx, tf = T(xyz, dev), (T(feat, dev) if D else None)
+    new_xyz = U.index_points(tx, U.farthest_point_sample(tx, S))
+    idx = U.query_ball_point(0.3, K, tx, new_xyz)
+    conv1, bn1 = _layer(dev, D, C1, 11, xyz_first)
+    torch.manual_seed(12)
+    conv2 = torch.nn.Conv2d(C1, C2, 1).to(dev)
+    bn2 = torch.nn.BatchNorm2d(C2).to(dev).eval()
+    with torch.no_grad():
+        bn2.running_mean.normal_(0, 0.3)
+        bn2.running_var.uniform_(0.4, 2.0)
+        bn2.weight.uniform_(0.5, 1.5)
+        bn2.bias.normal_(0, 0.2)
+    layers = [(c.weight.detach().reshape(c.out_channels, -1).cpu().numpy(), c.bias.detach().cpu().numpy()) + _bn_np(b_)
+              for c, b_ in ((conv1, bn1), (conv2, bn2))]
+    want = oracle.set_abstraction_mlp(xyz, new_xyz.cpu().numpy(), feat, idx.cpu().numpy(), layers, bn1.eps, xyz_first)
+    with torch.no_grad():
+        for index in (idx, idx.to(torch.int32)):
+            got = U.sa_level_mlp2_max(tx, new_xyz, tf, index, [conv1, conv2], [bn1, bn2], xyz_first)
+            close(got.cpu().numpy(), want, f"two-layer level ({index.dtype})")
+
+
+def test_two_layer_level_reports_a_bad_index(dev):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    torch.manual_seed(0)
+    xyz = torch.rand(1, 200, 3, device=dev)
+    feat = torch.randn(1, 200, 40, device=dev)
+    new_xyz = xyz[:, :10].contiguous()
+    idx = torch.randint(0, 200, (1, 10, 16), device=dev)
+    convs = [torch.nn.Conv2d(43, 32, 1).to(dev), torch.nn.Conv2d(32, 32, 1).to(dev)]
+    bns = [torch.nn.BatchNorm2d(32).to(dev).eval(), torch.nn.BatchNorm2d(32).to(dev).eval()]
+    with torch.no_grad():
+        U.sa_level_mlp2_max(xyz, new_xyz, feat, idx, convs, bns, True)
+        idx[0, 3, 5] = 200                                  # what an empty ball yields (pointnet2_utils.py:136-141)
+        with pytest.raises(IndexError):
+            U.sa_level_mlp2_max(xyz, new_xyz, feat, idx, convs, bns, True)
+        idx[0, 3, 5] = -1                                   # negative indices wrap like torch's indexing
+        a = U.sa_level_mlp2_max(xyz, new_xyz, feat, idx, convs, bns, True)
+        idx[0, 3, 5] = 199
+        assert torch.equal(a, U.sa_level_mlp2_max(xyz, new_xyz, feat, idx, convs, bns, True))
+
+
 def test_fused_modules_match_the_reference_modules(dev, golden_r2, monkeypatch):
     """The drop-in modules in eval mode take the fused path BY THEMSELVES at these shapes (nothing is patched; a spy only
     counts) and reproduce the reference modules' outputs (same weights) within 1e-5 elementwise."""
     from toothgroupnetwork_amd import pointnet2_utils as U
     g = golden_r2
     state = torch.load(os.path.join(GOLDEN, "module_weights_r2.pt"))
-    calls = {"level": 0, "first": 0, "group": 0}
-    real_level, real_first, real_group = U.sa_level_max, U.sa_first_layer, U.group_points
+    calls = {"level": 0, "first": 0, "mlp2": 0, "group": 0}
+    real_level, real_first, real_group, real_mlp2 = U.sa_level_max, U.sa_first_layer, U.group_points, U.sa_level_mlp2_max
 
     def spy(name, fn):
         def wrapped(*a, **k):
@@ -114,6 +179,7 @@ def test_fused_modules_match_the_reference_modules(dev, golden_r2, monkeypatch):
     monkeypatch.setattr(U, "sa_level_max", spy("level", real_level))
     monkeypatch.setattr(U, "sa_first_layer", spy("first", real_first))
     monkeypatch.setattr(U, "group_points", spy("group", real_group))
+    monkeypatch.setattr(U, "sa_level_mlp2_max", spy("mlp2", real_mlp2))
     xyz, feat, pts6 = T(g["sa_in_xyz_cf"], dev), T(g["sa_in_feat_cf"], dev), T(g["sa_in_pts6_cf"], dev)
     mods = {
         "ssg_wide": (U.PointNetSetAbstraction(128, 0.25, 32, 3 + 64, [96], False), feat),
@@ -127,8 +193,8 @@ def test_fused_modules_match_the_reference_modules(dev, golden_r2, monkeypatch):
             nx, nf = mod(xyz, f)
         assert np.array_equal(nx.cpu().numpy(), g[f"sa_{name}_xyz"]), name      # same FPS indices -> identical centres
         close(nf.cpu().numpy(), g[f"sa_{name}_feat"], name)
-    # ssg_wide, ssg_narrow and the single-layer Msg branch: whole level fused; the two-layer Msg branch: fused first layer
-    assert calls == {"level": 3, "first": 1, "group": 0}, calls
+    # ssg_wide, ssg_narrow and the single-layer Msg branch: one-layer level kernels; the two-layer Msg branch: the chained kernel
+    assert calls == {"level": 3, "first": 0, "mlp2": 1, "group": 0}, calls
 
 
 @pytest.mark.parametrize("pipeline", [False, True])

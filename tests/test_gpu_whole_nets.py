@@ -55,6 +55,11 @@ def test_seeded_fill_is_order_independent():
 def test_pointnet_pp_whole_network_matches_the_reference(dev, golden_r3, fused, monkeypatch):
     from toothgroupnetwork_amd import nets, pointnet2_utils as U
     monkeypatch.setattr(U, "FUSED_SA", fused)
+    calls = {"conv2d": 0, "group": 0, "mlp2": 0}
+    real_group, real_mlp2, real_conv = U.group_points, U.sa_level_mlp2_max, torch.nn.Conv2d.forward
+    monkeypatch.setattr(U, "group_points", lambda *a, **k: calls.__setitem__("group", calls["group"] + 1) or real_group(*a, **k))
+    monkeypatch.setattr(U, "sa_level_mlp2_max", lambda *a, **k: calls.__setitem__("mlp2", calls["mlp2"] + 1) or real_mlp2(*a, **k))
+    monkeypatch.setattr(torch.nn.Conv2d, "forward", lambda self, x: calls.__setitem__("conv2d", calls["conv2d"] + 1) or real_conv(self, x))
     net = nets.PointNetPPSeg()
     assert seeded_fill(net, 31) == golden_r3["pnpp_params"].tolist()
     net = net.to(dev).eval()
@@ -72,6 +77,9 @@ def test_pointnet_pp_whole_network_matches_the_reference(dev, golden_r3, fused, 
     print(f"\npointnet_pp whole net (fused={fused}): drop-in vs exact {worst}; reference fp32 vs exact {ref_own}")
     for n_, e in worst.items():
         assert e <= 1e-5, (n_, e)
+    # fused: every set-abstraction branch of the reference net (two-layer MLPs) is ONE chained kernel -- no torch convolution
+    # runs, no (B,S,K,.) tensor is written; unfused: the materialised path (6 groupings, 12 convolutions)
+    assert calls == ({"conv2d": 0, "group": 0, "mlp2": 6} if fused else {"conv2d": 12, "group": 6, "mlp2": 0}), calls
 
 
 @pytest.mark.gpu

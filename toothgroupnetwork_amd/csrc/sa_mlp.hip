@@ -1,0 +1,277 @@
+// sa_mlp.hip -- a WHOLE two-layer set-abstraction level in one kernel (second half):
+//
+//   out[b,s,:] = max_k relu(bn2(W2 * relu(bn1(W1 * [x[idx]-c, f[idx]] + bias1)) + bias2))      (pointnet2_utils.py:286-294)
+//
+// for the two-layer shared MLPs every set-abstraction level of the reference networks has (pointnet_pp.py:13-15,
+// tsg_centroid_module.py:10-12, tsg_seg_module.py:11-28), eval mode, BatchNorms folded.  Neither the grouped
+// (B,S,K,3+D) tensor nor the (B,S,K,C1) output of the first layer nor the (B,S,K,C2) output of the second exists
+// anywhere: a workgroup owns 128 (query, neighbour) rows -- 4 queries of 32 neighbours or 2 of 64 -- and a 128-column
+// slab of the second layer;
+//   * the first layer's rows are produced on the fly, 16 channels at a time, straight into the A fragments of the GEMM:
+//       commuted form (wide inputs): h1[r, c] = relu(A1[b, idx_r, c] + cst[q_r, c]), A1 = [f, x] * W1t per POINT
+//           (tgn_sa_point_transform, an fp32-MFMA GEMM over the N points, S*K/N times fewer flops than per row) and
+//           cst = bias - Wxs . centre per query, kept in LDS;
+//       direct form (3 + D <= 16: the first level of a network): h1[r, c] = relu(b1[c] + sum_j g_r[j] * Wd[j, c]) from the
+//           gathered row g_r = [x - c, f] held in registers (the weights of 8 channels are wave-uniform: scalar loads);
+//   * the second layer runs on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains: the 1e-5 contract holds): 128 x 128 x 16
+//     tiles, 2 x 2 MFMA tiles per wave, fragments in LDS in the layout the MFMA operands want ([k parity][row][k-step]: a
+//     lane fetches its eight k-steps of a tile with two ds_read_b128, producers store two ds_write_b128), two tile
+//     buffers, ONE barrier per 16-wide K tile, the next tile's gathers in flight underneath;
+//   * the max over a query's neighbours is taken on the accumulators (bias and ReLU commute with it) and (B,S,C2) is all
+//     that is written.
+// Rows past K (K < 32 or 32 < K < 64) repeat neighbour 0, which a max does not see.
+#include "tgn_common.h"
+
+namespace tgn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMlpMT = 128, kMlpNT = 128, kMlpKT = 16;
+constexpr int kFS = 12;                        // fragment row stride in floats: 8 k-steps + 4 pad (b128 conflict-free)
+constexpr int kFrag = 2 * 128 * kFS;           // one operand tile [k parity][row][k-step]
+
+template <typename IdxT, bool DIRECT>
+__global__ __launch_bounds__(256, 2) void sa_mlp2_max_kernel(long long Q, int N, int S, int K, int D, int C1p, int C2,
+                                                              const float *__restrict__ A1,       // commuted: (B,N,C1p)
+                                                              const float *__restrict__ xyz,      // direct: (B,N,3)
+                                                              const float *__restrict__ points,   // direct: (B,N,D)
+                                                              const float *__restrict__ new_xyz,  // (B,S,3)
+                                                              const float *__restrict__ W1,       // commuted: Wxs (3,C1p); direct: Wd (16,C1p)
+                                                              const float *__restrict__ b1,       // (C1p)
+                                                              const IdxT *__restrict__ idx,       // (B,S,K)
+                                                              const float *__restrict__ W2f,      // (C1p/8, C2, 8)
+                                                              const float *__restrict__ b2,       // (C2)
+                                                              float *__restrict__ out,            // (B,S,C2)
+                                                              int *__restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *FA = smem, *FB = smem + 2 * kFrag, *cst = smem + 4 * kFrag;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int kshift = K > 32 ? 6 : 5, Kp = 1 << kshift, QPT = kMlpMT >> kshift;
+    const unsigned ntiles = ((unsigned)C2 + kMlpNT - 1) / kMlpNT;
+    const long long mtiles = (Q + QPT - 1) / QPT;
+    // XCD-contiguous item ranges, column tile fastest: the blocks that gather the same rows run next to each other on one L2
+    const unsigned nb = gridDim.x;
+    const long long item = (long long)(blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
+    const long long mt = item / ntiles;
+    if (mt >= mtiles) return;
+    const int col0 = (int)(item - mt * ntiles) * kMlpNT;
+    const long long q0 = mt * QPT;
+
+    // ---- producer roles.  A: thread (row ar, k half ah) makes 8 consecutive channels of one (query, neighbour) row per K tile;
+    //      B: thread (column bc, k half bh) fetches 8 consecutive k of one column of W2 (32 contiguous bytes of W2f)
+    const int ar = tid & 127;
+    const int ah = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int ql = ar >> kshift;
+    long long q = q0 + ql;
+    if (q >= Q) q = Q - 1;
+    const int b = (int)(q / S);
+    int kk = ar & (Kp - 1);
+    if (kk >= K) kk = 0;
+    long long v = (long long)idx[q * K + kk];
+    if (v < 0) v += N;
+    bool bad = false;
+    if (v < 0 || v >= N) {
+        bad = true;
+        v = 0;
+    }
+    if (err && col0 == 0 && bad) atomicOr(err, 1);
+    const float *__restrict__ arow = A1 + ((size_t)b * N + (size_t)v) * C1p + ah * 8;
+    float g[16];
+    if (DIRECT) {
+        const float *__restrict__ px = xyz + ((size_t)b * N + (size_t)v) * 3;
+        const float *__restrict__ pf = points + ((size_t)b * N + (size_t)v) * D;
+        g[0] = px[0] - new_xyz[q * 3 + 0];
+        g[1] = px[1] - new_xyz[q * 3 + 1];
+        g[2] = px[2] - new_xyz[q * 3 + 2];
+#pragma unroll
+        for (int j = 3; j < 16; ++j) g[j] = j - 3 < D ? pf[j - 3] : 0.0f;
+    } else {
+        for (int l = 0; l < QPT; ++l) {   // cst[l][c] = b1[c] - Wxs[:,c] . centre of query l
+            long long qq = q0 + l;
+            if (qq >= Q) qq = Q - 1;
+            const float cx = new_xyz[qq * 3 + 0], cy = new_xyz[qq * 3 + 1], cz = new_xyz[qq * 3 + 2];
+            for (int c = tid; c < C1p; c += 256)
+                cst[l * C1p + c] = b1[c] - ((W1[c] * cx + W1[C1p + c] * cy) + W1[2 * C1p + c] * cz);
+        }
+    }
+    const int bc = tid & 127, bh = tid >> 7;
+    const bool bok = col0 + bc < C2;
+    const float *__restrict__ brow = W2f + ((size_t)bh * C2 + (size_t)(bok ? col0 + bc : 0)) * 8;
+    const size_t bstep = (size_t)2 * C2 * 8;   // one K tile = two k-blocks of 8
+
+    f32x4 ra0, ra1, rb0 = {0.f, 0.f, 0.f, 0.f}, rb1 = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int t) {
+        if (!DIRECT) {
+            ra0 = *(const f32x4 *)(arow + t * kMlpKT);
+            ra1 = *(const f32x4 *)(arow + t * kMlpKT + 4);
+        }
+        if (bok) {
+            rb0 = *(const f32x4 *)(brow + (size_t)t * bstep);
+            rb1 = *(const f32x4 *)(brow + (size_t)t * bstep + 4);
+        }
+    };
+    auto stage = [&](int t, int buf) {
+        float h[8];
+        if (DIRECT) {
+            const float *__restrict__ wd = W1 + t * kMlpKT + ah * 8;   // wave-uniform: scalar loads
+            const float *__restrict__ bb = b1 + t * kMlpKT + ah * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) h[i] = bb[i];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j < 3 + D) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) h[i] = __builtin_fmaf(g[j], wd[(size_t)j * C1p + i], h[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) h[i] = fmaxf(h[i], 0.0f);
+        } else {
+            const float *cs = cst + ql * C1p + t * kMlpKT + ah * 8;
+            const f32x4 c0 = *(const f32x4 *)cs, c1 = *(const f32x4 *)(cs + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                h[i] = fmaxf(ra0[i] + c0[i], 0.0f);
+                h[4 + i] = fmaxf(ra1[i] + c1[i], 0.0f);
+            }
+        }
+        // channel 8*ah + i of the tile is k-step 4*ah + (i >> 1), parity i & 1
+        float *fa = FA + buf * kFrag + ar * kFS + ah * 4;
+        *(f32x4 *)fa = f32x4{h[0], h[2], h[4], h[6]};
+        *(f32x4 *)(fa + 128 * kFS) = f32x4{h[1], h[3], h[5], h[7]};
+        float *fb = FB + buf * kFrag + bc * kFS + bh * 4;
+        *(f32x4 *)fb = f32x4{rb0[0], rb0[2], rb1[0], rb1[2]};
+        *(f32x4 *)(fb + 128 * kFS) = f32x4{rb0[1], rb0[3], rb1[1], rb1[3]};
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    auto compute = [&](int buf) {
+        const float *fa = FA + buf * kFrag + (hi * 128 + wm * 64 + lo) * kFS;
+        const float *fb = FB + buf * kFrag + (hi * 128 + wn * 64 + lo) * kFS;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const f32x4 a0 = *(const f32x4 *)(fa + half * 4), a1 = *(const f32x4 *)(fa + 32 * kFS + half * 4);
+            const f32x4 w0 = *(const f32x4 *)(fb + half * 4), w1 = *(const f32x4 *)(fb + 32 * kFS + half * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], w0[s], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], w1[s], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], w0[s], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], w1[s], acc[1][1], 0, 0, 0);
+            }
+        }
+    };
+
+    const int T = C1p / kMlpKT;
+    fetch(0);
+    __syncthreads();   // cst is complete
+    stage(0, 0);
+    if (T > 1) fetch(1);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        compute(t & 1);
+        if (t + 1 < T) stage(t + 1, (t + 1) & 1);   // the other buffer: last read before the barrier that ended tile t-1
+        if (t + 2 < T) fetch(t + 2);
+        __syncthreads();
+    }
+
+    // ---- max over the rows of a query.  Accumulator register r of lane l is row (r & 3) + 8 (r >> 2) + 4 hi, column lo of its tile.
+    float cm[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float m = acc[i][j][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
+            cm[i][j] = fmaxf(m, __shfl_xor(m, 32));
+        }
+    if (hi == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + wn * 64 + j * 32 + lo;
+            if (col >= C2) continue;
+            const float bias = b2[col];
+            if (kshift == 6) {   // 64 rows = one query
+                const long long qq = q0 + wm;
+                if (qq < Q) out[(size_t)qq * C2 + col] = fmaxf(fmaxf(cm[0][j], cm[1][j]) + bias, 0.0f);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const long long qq = q0 + wm * 2 + i;
+                    if (qq < Q) out[(size_t)qq * C2 + col] = fmaxf(cm[i][j] + bias, 0.0f);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace tgn
+
+using namespace tgn;
+
+// 1 if tgn_sa_mlp2_max takes the direct form for this first layer (the caller then passes xyz / points / Wd, no A1)
+TGN_API int tgn_sa_mlp2_direct_supported(int K, int D) { return (D >= 0 && 3 + D <= 16 && K >= 1 && K <= 64) ? 1 : 0; }
+
+TGN_API int tgn_sa_mlp2_max(int B, int N, int S, int K, int D, int C1p, int C2, const float *A1, const float *xyz,
+                            const float *points, const float *new_xyz, const float *W1, const float *b1, const void *idx,
+                            int idx_is_int64, const float *W2f, const float *b2, float *out, tgn_stream_t stream) {
+    const long long Q = (long long)B * S;
+    if (Q <= 0 || C2 <= 0) return TGN_OK;
+    const bool direct = A1 == nullptr;
+    if (!new_xyz || !W1 || !b1 || !idx || !W2f || !b2 || !out || (direct && (!xyz || (D > 0 && !points)))) {
+        set_error("tgn_sa_mlp2_max: null pointer");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    if (K < 1 || K > 64 || C1p < 16 || (C1p & 15) || N < 1 || (direct && !tgn_sa_mlp2_direct_supported(K, D)) ||
+        (((uintptr_t)A1 | (uintptr_t)W2f | (uintptr_t)W1 | (uintptr_t)b1) & 15)) {
+        set_error("tgn_sa_mlp2_max: needs 1 <= nsample <= 64, a first-layer width padded to a multiple of 16, 16-byte aligned "
+                  "operands, and 3+D <= 16 for the direct form");
+        return TGN_ERR_UNSUPPORTED;
+    }
+    const int qpt = K > 32 ? 2 : 4;
+    const size_t lds = (size_t)(4 * kFrag + (direct ? 0 : qpt * C1p)) * sizeof(float);
+    if (lds > 80 * 1024) {   // two workgroups per CU
+        set_error("tgn_sa_mlp2_max: first-layer width %d needs %zu bytes of LDS per workgroup (limit 80 KiB)", C1p, lds);
+        return TGN_ERR_UNSUPPORTED;
+    }
+    const long long mtiles = (Q + qpt - 1) / qpt, ntiles = (C2 + kMlpNT - 1) / kMlpNT;
+    const long long blocks = (mtiles * ntiles + 7) / 8 * 8;
+    if (blocks > 0x7FFFFFFFLL) {
+        set_error("tgn_sa_mlp2_max: too many tiles");
+        return TGN_ERR_UNSUPPORTED;
+    }
+    int *err = index_error_word();
+    hipStream_t st = (hipStream_t)stream;
+    if (direct && !points) points = xyz;   // D == 0: never read
+#define TGN_MLP2(IT, DIR)                                                                                                 \
+    if (lds > 48 * 1024)                                                                                                  \
+        (void)hipFuncSetAttribute((const void *)sa_mlp2_max_kernel<IT, DIR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  80 * 1024);                                                                             \
+    hipLaunchKernelGGL((sa_mlp2_max_kernel<IT, DIR>), dim3((unsigned)blocks), dim3(256), lds, st, Q, N, S, K, D, C1p, C2, \
+                       A1, xyz, points, new_xyz, W1, b1, (const IT *)idx, W2f, b2, out, err)
+    if (idx_is_int64) {
+        if (direct) {
+            TGN_MLP2(long long, true);
+        } else {
+            TGN_MLP2(long long, false);
+        }
+    } else {
+        if (direct) {
+            TGN_MLP2(int, true);
+        } else {
+            TGN_MLP2(int, false);
+        }
+    }
+#undef TGN_MLP2
+    return check_launch("sa_mlp2_max_kernel");
+}

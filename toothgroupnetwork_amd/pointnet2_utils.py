@@ -497,6 +497,81 @@ def sa_first_layer(xyz, new_xyz, points, idx, conv, bn, xyz_first, reduce_max=Fa
     return out
 
 
+def fold_second_layer(conv, bn, C1p):
+    """The second Conv2d(1x1) + eval-mode BatchNorm2d of a shared MLP as the operands of tgn_sa_mlp2_max:
+      W2f (C1p/8, C2, 8): W2f[kb, c, i] = scale[c] * W[c, 8*kb + i], zero for the padded input channels
+      b2  (C2,)          = shift + scale * bias"""
+    C2, C1 = conv.out_channels, conv.in_channels
+    W = conv.weight.detach().reshape(C2, C1).float()
+    bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(C2, device=W.device)
+    scale = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).float()
+    shift = (bn.bias.detach() - bn.running_mean * scale).float()
+    Wp = W.new_zeros(C2, C1p)
+    Wp[:, :C1] = W * scale[:, None]
+    W2f = Wp.view(C2, C1p // 8, 8).permute(1, 0, 2).contiguous()
+    return W2f, (shift + scale * bias).contiguous()
+
+
+def _pad_cols(t, C1p):
+    if t.shape[-1] == C1p:
+        return t.contiguous()
+    out = t.new_zeros(t.shape[:-1] + (C1p,))
+    out[..., :t.shape[-1]] = t
+    return out
+
+
+def sa_level_mlp2_max(xyz, new_xyz, points, idx, convs, bns, xyz_first):
+    """A whole set-abstraction level with a TWO-layer shared MLP after sampling and ball query:
+        max_k relu(bn2(conv2(relu(bn1(conv1([xyz[idx]-new_xyz, points[idx]]))))))  ->  (B,S,C2)
+    (pointnet2_utils.py:162-169 + 229-236, or 281-294 for Msg) in ONE kernel after the per-point transform of the first
+    layer (wide inputs) or with the first layer computed from the gathered rows (3+D <= 16): nothing of size S*K is
+    written, no torch convolution runs (tgn_sa_mlp2_max; the second layer on the fp32 matrix cores)."""
+    B, N, _ = xyz.shape
+    _, S, K = idx.shape
+    D = 0 if points is None else points.shape[2]
+    f = fold_first_layer(convs[0], bns[0], D, xyz_first)
+    C1 = f["C1"]
+    C1p = (C1 + 15) // 16 * 16
+    W2f, b2 = fold_second_layer(convs[1], bns[1], C1p)
+    C2 = b2.shape[0]
+    idx = idx.contiguous()
+    out = torch.empty(B, S, C2, dtype=torch.float32, device=xyz.device)
+    L = lib()
+    b1 = _pad_cols(f["b2"], C1p)
+    if L.tgn_sa_mlp2_direct_supported(K, D):
+        A1, W1 = None, _pad_cols(f["Wd"], C1p)                       # (16, C1p): rows [x, y, z, features..., 0]
+    else:
+        A1 = sa_point_transform(xyz, points, _pad_cols(f["Wt"], C1p))    # (B, N, C1p)
+        W1 = _pad_cols(f["Wxs"], C1p)
+    _lib.begin_index_check()
+    check(L.tgn_sa_mlp2_max(B, N, S, K, D, C1p, C2, ptr(A1), ptr(xyz), ptr(points), ptr(new_xyz), ptr(W1), ptr(b1), ptr(idx),
+                            int(idx.dtype == torch.int64), ptr(W2f), ptr(b2), ptr(out), stream()), "sa_mlp2_max")
+    _lib.raise_on_index_error("set abstraction (grouping)")
+    return out
+
+
+def _mlp2_shape_ok(K, C1):
+    """tgn_sa_mlp2_max keeps the per-query constants of its 4 (K <= 32) or 2 queries in LDS next to the tile buffers."""
+    return 1 <= K <= 64 and (4 if K <= 32 else 2) * ((C1 + 15) // 16 * 16) <= 8192
+
+
+def _fused_level(xyz_c, new_xyz, points_c, idx, convs, bns, xyz_first, N, S, K):
+    """The fused eval-mode forms of one (radius, nsample) branch, or None when the shared MLP / shape has none:
+    one layer -> sa_level_max; two layers (every level of the reference networks) -> sa_level_mlp2_max; more -> fused first
+    layer (where it is cheaper than grouping) + the remaining layers in torch.  Returns (B, C', S)."""
+    n = len(convs)
+    if n == 0 or not _fused_shape_ok(K, convs[0].out_channels):
+        return None
+    if n == 1:
+        return sa_level_max(xyz_c, new_xyz, points_c, idx, convs[0], bns[0], xyz_first).permute(0, 2, 1)
+    if n == 2 and _mlp2_shape_ok(K, convs[0].out_channels):
+        return sa_level_mlp2_max(xyz_c, new_xyz, points_c, idx, convs, bns, xyz_first).permute(0, 2, 1)
+    if _fuse_pays(N, S, K, 3 + (0 if points_c is None else points_c.shape[2]), convs[0].out_channels):
+        y = sa_first_layer(xyz_c, new_xyz, points_c, idx, convs[0], bns[0], xyz_first=xyz_first)
+        return _mlp_tail_and_max(y, convs, bns, 1)
+    return None
+
+
 def _fused_shape_ok(K, C1):
     return K <= 64 and C1 % 4 == 0
 
@@ -533,21 +608,17 @@ class PointNetSetAbstraction(nn.Module):
         xyz = xyz.permute(0, 2, 1)
         if points is not None:
             points = points.permute(0, 2, 1)
-        if (not self.group_all and len(self.mlp_convs) > 0 and _can_fuse(self, xyz, points)
-                and _fused_shape_ok(self.nsample, self.mlp_convs[0].out_channels)
-                and (len(self.mlp_convs) == 1 or
-                     _fuse_pays(xyz.shape[1], self.npoint, self.nsample, 3 + (0 if points is None else points.shape[2]),
-                                self.mlp_convs[0].out_channels))):
-            # eval fast path: FPS (+coordinates) -> ball query -> fused first layer; `grouped` is never built
+        if not self.group_all and len(self.mlp_convs) > 0 and _can_fuse(self, xyz, points):
+            # eval fast path: FPS (+coordinates) -> ball query -> fused shared MLP + max; `grouped` is never built
             xyz_c = _f32c(xyz)
             points_c = None if points is None else _f32c(points)
             _, new_xyz = _fps_dense(xyz_c, self.npoint, want_coords=True, prefix=True)
             idx = query_ball_point(self.radius, self.nsample, xyz_c, new_xyz)
-            if len(self.mlp_convs) == 1:     # the whole level in the fused kernels
-                new_points = sa_level_max(xyz_c, new_xyz, points_c, idx, self.mlp_convs[0], self.mlp_bns[0], True).permute(0, 2, 1)
-            else:
-                y = sa_first_layer(xyz_c, new_xyz, points_c, idx, self.mlp_convs[0], self.mlp_bns[0], xyz_first=True)
-                new_points = _mlp_tail_and_max(y, self.mlp_convs, self.mlp_bns, 1)
+            new_points = _fused_level(xyz_c, new_xyz, points_c, idx, self.mlp_convs, self.mlp_bns, True, xyz_c.shape[1],
+                                      self.npoint, self.nsample)
+            if new_points is None:      # no fused form for this MLP / shape: group, then the reference's stack
+                new_points = _mlp_tail_and_max(group_points(xyz_c, new_xyz, points_c, idx, xyz_first=True), self.mlp_convs,
+                                               self.mlp_bns, 0)
             return new_xyz.permute(0, 2, 1), new_points
         if self.group_all:
             new_xyz, new_points = sample_and_group_all(xyz, points)
@@ -597,28 +668,16 @@ class PointNetSetAbstractionMsg(nn.Module):
         points_c = None if points is None else _f32c(points)
         fuse = _can_fuse(self, xyz, points)
         new_points_list = []
-        for i, radius in enumerate(self.radius_list):
-            K = self.nsample_list[i]
-            group_idx = query_ball_point(radius, K, xyz_c, new_xyz)
-            if (fuse and _fused_shape_ok(K, self.conv_blocks[i][0].out_channels)
-                    and (len(self.conv_blocks[i]) == 1 or
-                         _fuse_pays(xyz_c.shape[1], S, K, 3 + (0 if points_c is None else points_c.shape[2]),
-                                    self.conv_blocks[i][0].out_channels))):
+        with _lib.deferred_index_check("set abstraction (grouping)"):      # one flag read for all branches
+            for i, radius in enumerate(self.radius_list):
+                K = self.nsample_list[i]
+                group_idx = query_ball_point(radius, K, xyz_c, new_xyz)
                 convs, bns = self.conv_blocks[i], self.bn_blocks[i]
-                if len(convs) == 1:
-                    new_points_list.append(sa_level_max(xyz_c, new_xyz, points_c, group_idx, convs[0], bns[0], False).permute(0, 2, 1))
-                else:
-                    y = sa_first_layer(xyz_c, new_xyz, points_c, group_idx, convs[0], bns[0], xyz_first=False)
-                    new_points_list.append(_mlp_tail_and_max(y, convs, bns, 1))
-                continue
-            grouped_points = group_points(xyz_c, new_xyz, points_c, group_idx, xyz_first=False)  # [feat, rel_xyz] (:285)
-            grouped_points = grouped_points.permute(0, 3, 2, 1)  # [B, D, K, S]
-            for j in range(len(self.conv_blocks[i])):
-                conv = self.conv_blocks[i][j]
-                bn = self.bn_blocks[i][j]
-                grouped_points = F.relu(bn(conv(grouped_points)))
-            new_points = torch.max(grouped_points, 2)[0]  # [B, D', S]
-            new_points_list.append(new_points)
+                new_points = _fused_level(xyz_c, new_xyz, points_c, group_idx, convs, bns, False, xyz_c.shape[1], S, K) if fuse else None
+                if new_points is None:
+                    grouped_points = group_points(xyz_c, new_xyz, points_c, group_idx, xyz_first=False)  # [feat, rel_xyz] (:285)
+                    new_points = _mlp_tail_and_max(grouped_points, convs, bns, 0)                        # (:286-294)
+                new_points_list.append(new_points)
         new_xyz = new_xyz.permute(0, 2, 1)
         new_points_concat = torch.cat(new_points_list, dim=1)
         return new_xyz, new_points_concat
