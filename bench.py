@@ -94,24 +94,9 @@ def main():
                     "(exact, certificate checked on the device) instead of iterating; reported separately, never the headline")
     ap.add_argument("--shape", default="A", choices=["A", "B"], help="A: the headline configuration (BASELINE.json config 2); "
                     "B: what the reference net instantiates (multi-scale grouping, SURVEY.md 8) -- not the headline")
-    ilist = lambda s: [int(v) for v in str(s).split(",")]
-    ap.add_argument("--group-impl", type=ilist, default=[0], help="grouping kernel, one value or one per level: 0 choose, 1 = 4-B stores, "
-                    "2 = 16-B stores through LDS, 3 = LDS-DMA ring, 7 = row pieces into an LDS image")
-    ap.add_argument("--group-policy", type=ilist, default=[-1], help="cache policy of the 16-B grouping stores (0 plain, 2 nt, 16 sc1; -1 default)")
-    ap.add_argument("--group-max-blocks", type=ilist, default=[-1], help="grid bound of the grouping kernel (-1: 256 = one wave per SIMD when pipelined, else none)")
-    ap.add_argument("--fused", type=int, default=0, help="1: every level is a fused set-abstraction level (single-layer shared MLP "
-                    "[128,512,1024], eval-mode BatchNorm folded): the grouped tensor is never written -- a second, non-headline line")
-    ap.add_argument("--ball-stream", type=int, default=-1, help="-1: default (2 = phased: ball queries on a third stream beside FPS levels "
-                    "2-3, fenced off from the next step's FPS level 1); 0: in line on the FPS stream; 1: third stream, free-running")
-    ap.add_argument("--ball-split", type=int, default=-1, help="phased schedule: where the ball queries of levels 2-3 run (hotpath.py; -1 = default: the last level in front of the groupings)")
-    ap.add_argument("--group-delay-us", type=int, default=-1, help="gated schedule: hold the groupings back by this long behind the start of "
-                    "FPS level 1 (-1: default, ~100 us at 24 000 points: most of the FPS set-up)")
-    ap.add_argument("--group-order", type=ilist, default=None, help="gated schedule: order of the grouping launches, e.g. 2,1,0")
-    ap.add_argument("--grid-stream", type=int, default=0, help="phased schedule: the early level-1 grid on a stream of its own (experiment)")
-    ap.add_argument("--low-valu", type=int, default=1, help="phased schedule: FPS level 2 on the bucket-skipping kernel (TGN_FPS_LOW_VALU)")
-    ap.add_argument("--early-grid", type=int, default=-1, help="phased schedule: build the level-1 ball-query grid ahead of the fence (-1 default on)")
-    ap.add_argument("--group-gate", type=int, default=-1, help="1: groupings of a step wait for its last ball query, i.e. run beside the next "
-                    "step's FPS level 1 (-1: default on when pipelined)")
+    ap.add_argument("--fused", type=int, default=0, help="1: every level is a fused set-abstraction level with a two-layer shared MLP "
+                    "([64,128], [256,512], [512,1024]; eval-mode BatchNorm folded): neither the grouped tensor nor a layer output of "
+                    "size S*K is written -- a second, non-headline line bound by the fp32 matrix cores")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL; gloo lets several ranks share "
                     "one GPU, e.g. to exercise the N > 1 branch on a one-GPU box)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra with_fps_prefix_identity measurement (profiling runs)")
@@ -126,18 +111,11 @@ def main():
     B = args.batch
     shape = hotpath.SHAPE_A if args.shape == "A" else hotpath.SHAPE_B
     xyz, feats, scans = make_inputs(B, device, seed=100 + rank, shape=shape)
-    one = lambda v: v[0] if len(v) == 1 else v
-    mb = one(args.group_max_blocks)
-    gopts = dict(group_impl=one(args.group_impl), group_policy=one(args.group_policy),
-                 group_max_blocks=None if mb == -1 else mb, fused=bool(args.fused),
-                 ball_stream=None if args.ball_stream < 0 else args.ball_stream,
-                 group_gate=None if args.group_gate < 0 else bool(args.group_gate),
-                 early_grid=None if args.early_grid < 0 else bool(args.early_grid), ball_split=None if args.ball_split < 0 else int(args.ball_split), grid_stream=bool(args.grid_stream),
-                 low_valu=bool(args.low_valu), group_order=args.group_order, group_delay_us=None if args.group_delay_us < 0 else args.group_delay_us)
+    gopts = dict(fused=bool(args.fused))
     if args.fused and args.shape != "A":
         raise SystemExit("--fused is defined for shape A (single-scale levels)")
     hp = hotpath.HotPath(B, device, shape=shape, pipeline=bool(args.pipeline), fps_prefix=bool(args.fps_prefix), **gopts)
-    for _ in range(max(args.warmup, 0)):
+    for _ in range(max(args.warmup, 1)):                     # (the first run also measures the schedule's plan, hotpath.plan_schedule)
         hp.run(xyz, feats, inputs_on_current_stream=False)   # the synthetic scans are resident before any step
     torch.cuda.synchronize()
     if not args.no_kernel_timing:
@@ -173,9 +151,9 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": ("shape_A FUSED (NOT the headline configuration): 24000-pt scans, npoint=[4096,1024,256], nsample=32, "
-                                "radii=[0.05,0.1,0.2]; FPS + ball query + fused set-abstraction level (gather, centre, 1x1 conv "
-                                "[9->128, 131->512, 515->1024] on the fp32 matrix cores, folded BatchNorm, ReLU, max over K); "
-                                "the grouped tensor is never written, level l feeds level l+1") if args.fused else
+                                "radii=[0.05,0.1,0.2]; FPS + ball query + fused set-abstraction level (gather, centre, two-layer shared "
+                                "MLP [9->64->128, 131->256->512, 515->512->1024] on the fp32 matrix cores, folded BatchNorms, ReLUs, max "
+                                "over K); no grouped tensor and no layer output of size S*K is written, level l feeds level l+1") if args.fused else
                                ("shape_A: 24000-pt scans, npoint=[4096,1024,256], nsample=32, radii=[0.05,0.1,0.2], "
                                 "D=[6,128,512]; FPS+ball_query+group forward, grouped tensors materialised") if args.shape == "A" else
                                ("shape_B (NOT the headline configuration): 24000-pt scans, npoint=[1024,512,256], multi-scale "
@@ -216,17 +194,20 @@ def main():
                                                "it (~55 VALU instructions per wave and iteration instead of ~420, "
                                                "profiles/r02_pmc_sq_counters.txt) and is bound by the dependency chain of one "
                                                "iteration in the wave that holds the new sample, so this is not a utilisation figure"}
-        # HBM bytes per launch from the PMC passes committed under profiles/ (tools/gpu_pmc.sh; same workload)
+        # HBM bytes per launch: NOT measured in this run -- read from the PMC passes committed under profiles/ (tools/gpu_pmc.sh,
+        # separate rocprofv3 --pmc runs of the same workload; labelled `traffic_source`)
         pmc = {}
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(REPO, "profiles", name)))
+                pmc_name = name
                 break
             except Exception:
                 pass
         pmc_ok = B == 256 and args.shape == "A" and not args.fused
         if dom in pmc and pmc_ok:
             out["roofline"]["traffic"] = pmc[dom]["fetch"] + pmc[dom]["write"]
+            out["roofline"]["traffic_source"] = f"profiles/{pmc_name} (committed PMC passes of the same workload, not this run)"
         # the HBM-bound kernel of the path, for reference next to the (latency-bound) dominant one
         gk = max((k for k in avg if k.startswith("group")), key=lambda k: avg[k])
         gl = int(gk.split("_l")[1]) - 1
@@ -236,18 +217,23 @@ def main():
                                  "traffic": (pmc[gk]["fetch"] + pmc[gk]["write"]) if gk in pmc and pmc_ok else None,
                                  "algorithmic_bytes_per_launch": galgo, "avg_launch_ms": avg[gk]}
     if args.fused and rank == 0 and not args.no_kernel_timing:
-        # matrix-core side of the fused levels: flops of the per-point transforms / direct contractions per step
+        # the fused levels are bound by the fp32 matrix cores: flops of the first layers (per POINT where the transform commutes
+        # with the gather, per gathered row in the direct form) and of the second layers (per gathered row), against 157.3 TFLOP/s
         fl = 0
         Nl = shape["n"]
-        for S, K, D, C1 in zip(shape["npoint"], shape["nsample"], shape["d"], shape["c_out"]):
+        for S, K, D, widths in zip(shape["npoint"], shape["nsample"], shape["d"], shape["mlp"]):
             direct = (3 + D) <= 16
-            fl += 2 * (S * K if direct else Nl) * (3 + D) * C1
+            fl += 2 * (S * K if direct else Nl) * (3 + D) * widths[0]
+            if len(widths) == 2:
+                fl += 2 * S * K * widths[0] * widths[1]
             Nl = S
         sa_ms = sum(v for k, v in avg.items() if k.startswith("group"))
-        out["fused_levels"] = {"flops_per_mesh": fl, "sa_kernels_ms_per_step": sa_ms,
-                               "achieved_TFLOPs_fp32": fl * B / (sa_ms * 1e-3) / 1e12, "peak_TFLOPs_fp32_mfma": 157.3,
-                               "note": "set-abstraction kernels (per-point transform + gather-max, or the direct kernel) are timed under the "
-                                       "group_l* keys; fp32 MFMA = exact fp32, 1/16 of the bf16 rate"}
+        tf = fl * B / (sa_ms * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "set-abstraction kernels (sa_mlp2_max + sa_point_transform)", "bound": "mfma", "achieved": tf,
+                           "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None,
+                           "algorithmic_flops_per_launch": fl * B, "avg_launch_ms": sa_ms,
+                           "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32) = exact fp32, 1/16 of the bf16 rate; timed under the group_l* keys"}
+        out.pop("roofline_group", None)
     if world == 1 and not args.fps_prefix and not args.no_alt and not args.fused:
         # the same steps with levels 2 and 3 answered by the FPS-of-an-FPS-result identity (exact):
         # reported next to the headline, never as the headline

@@ -39,9 +39,9 @@ def test_fps_and_group_kernels_can_share_a_cu():
     # (dynamic LDS: 2 images of 32 + R*C floats + 512 floats of set-up planes, R*C <= 2176 -- group.hip launcher)
     rows_lds = (2 * (32 + 2176) + 64 * 3 + 64 * 5) * 4
     # (store policy 2 = nt is what the launcher picks by default, 16 = sc1)
-    for name in ("tgn::group_points_rows_kernel<int, 2, 0, 4>", "tgn::group_points_rows_kernel<long long, 2, 0, 4>",
-                 "tgn::group_points_rows_kernel<int, 2, 0, 1>", "tgn::group_points_rows_kernel<int, 16, 0, 4>",
-                 "tgn::group_points_rows_kernel<long long, 16, 0, 4>", "tgn::group_points_rows_kernel<int, 16, 0, 1>"):
+    for name in ("tgn::group_points_rows_kernel<int, 2, 4>", "tgn::group_points_rows_kernel<long long, 2, 4>",
+                 "tgn::group_points_rows_kernel<int, 2, 1>", "tgn::group_points_rows_kernel<int, 16, 4>",
+                 "tgn::group_points_rows_kernel<long long, 16, 4>", "tgn::group_points_rows_kernel<int, 16, 1>"):
         gv, gs, _ = g[name]
         assert gs == 0 and gv <= 48, f"{name} uses {gv} VGPRs (> 48: does not fit beside the FPS workgroup)"
     assert lds + 4 * rows_lds <= 160 * 1024

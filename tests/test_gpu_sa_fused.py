@@ -198,11 +198,12 @@ def test_fused_modules_match_the_reference_modules(dev, golden_r2, monkeypatch):
 
 
 @pytest.mark.parametrize("pipeline", [False, True])
-def test_hotpath_fused_levels_vs_oracle(dev, oracle, pipeline):
-    """bench.py --fused: three chained fused levels (level l's output is level l+1's feature input) against the oracle
-    chain FPS -> ball query -> float64 layer, level by level, on every scan of a small batch."""
+@pytest.mark.parametrize("mlp", [[[64], [96], [160]], [[48, 64], [80, 96], [100, 160]]])
+def test_hotpath_fused_levels_vs_oracle(dev, oracle, pipeline, mlp):
+    """bench.py --fused: three chained fused levels (level l's output is level l+1's feature input), one- and two-layer
+    shared MLPs, against the oracle chain FPS -> ball query -> float64 MLP + max, level by level, on every scan."""
     from toothgroupnetwork_amd import hotpath, synth
-    shape = dict(n=3000, npoint=[512, 128, 32], radius=[0.15, 0.3, 0.6], nsample=[32, 32, 16], d=[6, 64, 96], c_out=[64, 96, 160])
+    shape = dict(n=3000, npoint=[512, 128, 32], radius=[0.15, 0.3, 0.6], nsample=[32, 32, 16], d=[6, mlp[0][-1], mlp[1][-1]], mlp=mlp)
     B = 3
     scans = synth.scan_batch(B, 3000, "arch", 41)
     pts = T(scans, dev)
@@ -213,15 +214,13 @@ def test_hotpath_fused_levels_vs_oracle(dev, oracle, pipeline):
     torch.cuda.synchronize()
     cur, feat = scans[:, :, :3].copy(), scans
     for li, lv in enumerate(levels):
-        S, K, D, C1 = lv["S"], lv["K"], lv["D"], lv["C1"]
+        S, K = lv["S"], lv["K"]
         fidx = oracle.farthest_point_sample(cur, S)
         assert np.array_equal(lv["fps_idx"].cpu().numpy(), fidx)
         new_xyz = oracle.index_points(cur, fidx)
         gidx = oracle.query_ball_point(shape["radius"][li], K, cur, new_xyz)
         assert np.array_equal(lv["group_idx"].cpu().numpy(), gidx)
-        Wt = lv["Wt"].cpu().numpy()                                   # rows [features..., x, y, z]
-        W = np.concatenate([Wt[D:], Wt[:D]], 0).T                     # (C1, 3+D) in [xyz, features] order
-        want = oracle.set_abstraction_first_layer(cur, new_xyz, feat, gidx, W, lv["b2"].cpu().numpy(), np.ones(C1), np.zeros(C1),
-                                                  np.zeros(C1), np.full(C1, 1.0 - 1e-5), 1e-5, True, reduce_max=True)
+        layers = [(W, b, np.ones(len(b)), np.zeros(len(b)), np.zeros(len(b)), np.full(len(b), 1.0 - 1e-5)) for W, b in lv["layers"]]
+        want = oracle.set_abstraction_mlp(cur, new_xyz, feat, gidx, layers, 1e-5, True)   # (identity BatchNorm)
         close(lv["out"].cpu().numpy(), want, f"level {li + 1}")
         cur, feat = new_xyz, lv["out"].cpu().numpy()                  # the GPU's own fp32 output feeds the next level in both chains

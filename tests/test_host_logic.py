@@ -162,15 +162,16 @@ def test_known_offsets_spare_the_device_to_host_copy():
         assert P.offsets_host(r) == [[7]]
 
 
-def test_default_placement_of_the_last_ball_query():
-    """hotpath.default_ball_split: the last level's query moves in front of the groupings only where those leave room beside
-    the FPS level-1 launch -- the headline shape at a full batch (measured: 4.69 -> 4.62 ms per step), not the
-    multi-scale shape whose groupings take ten times the FPS launch (measured: 2 % slower)."""
+def test_the_phased_plan_follows_its_measurements():
+    """hotpath.plan_schedule: the last level's query moves in front of the groupings only where those leave room beside
+    the FPS level-1 launch -- the headline shape at a full batch (measured: FPS level 1 3.33 ms, groupings 2.95 ms;
+    4.69 -> 4.62 ms per step), not the multi-scale shape whose groupings take ten times the FPS launch (measured: 2 %
+    slower); the spacer follows the FPS set-up time."""
     from toothgroupnetwork_amd import hotpath as H
 
-    assert H.default_ball_split(H.SHAPE_A, 256) == 4
-    assert H.default_ball_split(H.SHAPE_A, 16) == 4
-    assert H.default_ball_split(H.SHAPE_B, 256) == 0
-    one_level = dict(H.SHAPE_A, npoint=H.SHAPE_A["npoint"][:1], radius=H.SHAPE_A["radius"][:1],
-                     nsample=H.SHAPE_A["nsample"][:1], d=H.SHAPE_A["d"][:1])
-    assert H.default_ball_split(one_level, 256) == 0
+    a = H.plan_schedule(3.33, 2.95, 0.17, 3)
+    assert a["last_query_early"] and 90 <= a["spacer_us"] <= 110
+    assert not H.plan_schedule(0.9, 9.0, 0.17, 3)["last_query_early"]          # Shape B
+    assert not H.plan_schedule(3.33, 3.2, 0.17, 3)["last_query_early"]         # no room left
+    assert not H.plan_schedule(3.33, 0.1, 0.17, 1)["last_query_early"]         # a single level has nothing to move
+    assert H.plan_schedule(1.0, 0.5, 0.0, 2)["spacer_us"] == 0 and H.plan_schedule(9.0, 0.5, 2.0, 2)["spacer_us"] == 300

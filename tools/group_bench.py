@@ -22,15 +22,9 @@ levels = hp.run(xyz, feats)
 torch.cuda.synchronize()
 _, per_level = hotpath.algorithmic_bytes(**hotpath.SHAPE_A)
 variants = ([(1, -1, 0)] + [(2, p, mb) for p in (2, 16) for mb in (0, 1024, 512)]
-            + [(i, p, mb) for i in (3, 4) for p in (16, 0, 2) for mb in (0, 1024, 512, 256)])
-if len(sys.argv) > 1 and sys.argv[1] == "rows":
-    variants = [(7, p, mb) for p in (0, 2) for mb in (0, 1024, 256)] + [(i, 16, mb) for i in (7, 8, 9) for mb in (0, 1024, 256)]
-if len(sys.argv) > 1 and sys.argv[1] == "pairs":   # level 1: the pairs kernel (impl 10) against v1 / v2, per grid bound
+            + [(7, p, mb) for p in (0, 2, 16) for mb in (0, 1024, 256)])
+if len(sys.argv) > 1 and sys.argv[1] == "pairs":   # level 1: the pairs kernel (impl 10) against the per-element / staged kernels
     variants = [(1, -1, 0), (2, 16, 0)] + [(10, p, mb) for p in (16, 0, 2) for mb in (0, 2048, 1024, 512, 256)]
-if len(sys.argv) > 1 and sys.argv[1] == "dbg":
-    variants = [(i, 16, mb) for i in (3, 5, 6) for mb in (0, 1024, 512, 256)]
-if len(sys.argv) > 1 and sys.argv[1] == "quick":
-    variants = [(1, -1, 0), (2, 16, 0), (3, 16, 0), (3, 16, 1024), (3, 16, 512), (3, 16, 256), (3, 0, 512), (3, 2, 512)]
 print(f"{'impl':>4} {'pol':>3} {'maxb':>5} | " + " | ".join(f"L{i + 1} ms   GB/s" for i in range(3)))
 for impl, pol, mb in variants:
     row = []

@@ -238,17 +238,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(24))) void grou
     }
 }
 
-// ---- v3 (wide rows): the same walk with the gathers landing DIRECTLY in LDS ----------------------------------
-// `buffer_load_dword ... lds` (LDS-DMA) writes lane l's dword to LDS[M0 + 4*l]: exactly the staging layout, so the
-// gathered data never occupies a VGPR and the number of gathers in flight is bounded by LDS, not by registers: a ring
-// of NBUF 1-KiB slots per wave keeps NBUF-1 steps (4 gathers each) in flight.  With that much in flight per wave a
-// handful of waves per CU saturates the store stream, which is what lets the launcher keep the number of queries an
-// XCD works on at a time -- and with it the set of feature rows that must stay in its L2 -- small.
-// hipcc does not order a ds_read behind a pending LDS-DMA (MI355X_MICROARCH.md): the waits are explicit.  On gfx9 the
-// vector-memory operations of a wave retire in issue order on ONE counter, loads and stores alike, so "step t has
-// landed" == "at most (operations issued after step t's gathers) outstanding" = 4 per later step in flight + 1 per
-// store issued since; EXACT = false leaves the stores out of the count (never less safe, waits for their
-// acknowledgements too).
+// ---- explicit vmcnt waits.  hipcc does not order a ds_read behind a pending LDS-DMA (MI355X_MICROARCH.md): the waits are
+// written by hand.  On gfx9 the vector-memory operations of a wave retire in issue order on ONE counter, loads and stores
+// alike, so "X has landed" == "at most (operations issued after X) outstanding".
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
@@ -301,121 +293,8 @@ __device__ __forceinline__ void wait_vmcnt_any(unsigned n) {   // wave-uniform n
     else wait_vmcnt_dyn(n);
 }
 
-// DBG (tools/group_bench.py only): 1 = no gathers, 2 = no stores -- which side bounds a wave?
-template <typename IdxT, int POLICY, int NBUF, bool EXACT, int DBG = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(24))) void group_points_ring_kernel(
-    long long queries, long long q_per_xcd, int N, int S, int K, int D, unsigned magicC,
-    const float *__restrict__ xyz, const float *__restrict__ new_xyz, const float *__restrict__ points,
-    const IdxT *__restrict__ idx, int xyz_first, float *__restrict__ out, int *__restrict__ err) {
-    static_assert(NBUF >= 2 && NBUF <= 4, "ring depth");
-    __shared__ float srel[4][64 * 3];                                        // per neighbour: centred coordinates
-    __shared__ __attribute__((aligned(16))) float ring[4][NBUF][256];        // NBUF 1-KiB steps of the output, per wave
-    const unsigned lane = threadIdx.x & (kWave - 1);
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const unsigned C = 3u + (unsigned)D;
-    const unsigned xo = xyz_first ? 0u : (unsigned)D;
-    const unsigned fo = xyz_first ? 3u : 0u;
-    const unsigned total = (unsigned)K * C;
-    const unsigned units = total >> 2;
-    const unsigned nsteps = (units + 63u) >> 6;
-    const unsigned lane4 = lane * 4u;
-    const unsigned x = blockIdx.x & 7u, j = blockIdx.x >> 3, nbx = gridDim.x >> 3;
-    long long q1 = (long long)(x + 1) * q_per_xcd;
-    if (q1 > queries) q1 = queries;
-    for (long long q = (long long)x * q_per_xcd + (long long)j * 4 + wv; q < q1; q += (long long)nbx * 4) {
-        const int b = (int)(q / S);
-        const float cq0 = new_xyz[q * 3 + 0], cq1 = new_xyz[q * 3 + 1], cq2 = new_xyz[q * 3 + 2];
-        const __amdgpu_buffer_rsrc_t rs_xyz = make_rsrc(xyz + (size_t)b * N * 3, (unsigned)N * 12u);
-        const __amdgpu_buffer_rsrc_t rs_idx = make_rsrc(idx + q * K, (unsigned)K * (unsigned)sizeof(IdxT));
-        bool bad = false;
-        unsigned r0 = 0;  // lane k: feature-row offset of neighbour k
-        if (lane < (unsigned)K) {
-            IdxT raw;
-            if constexpr (sizeof(IdxT) == 8) {
-                const auto t = __builtin_amdgcn_raw_buffer_load_b64(rs_idx, lane * 8u, 0, 0);
-                raw = (IdxT)(((unsigned long long)t[1] << 32) | t[0]);
-            } else {
-                raw = (IdxT)__builtin_amdgcn_raw_buffer_load_b32(rs_idx, lane * 4u, 0, 0);
-            }
-            const unsigned v = checked_index(raw, N, bad);
-            r0 = v * (unsigned)D;
-            const float px = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_xyz, v * 12u, 0, 0));
-            const float py = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_xyz, v * 12u + 4u, 0, 0));
-            const float pz = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_xyz, v * 12u + 8u, 0, 0));
-            srel[wv][lane * 3 + 0] = px - cq0;
-            srel[wv][lane * 3 + 1] = py - cq1;
-            srel[wv][lane * 3 + 2] = pz - cq2;
-        }
-        if (err && __any(bad) && lane == 0) atomicOr(err, 1);
-        const __amdgpu_buffer_rsrc_t rs_pts = make_rsrc(points + (size_t)b * N * D, (unsigned)N * (unsigned)D * 4u);
-        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(out + (size_t)q * total, total * 4u);
-        // everything above has been consumed (r0 and the tables depend on it): the counter is at zero from here on
-        unsigned ki = 0, ci = 0;  // SGPRs: row / first channel of the next sub-step to ISSUE
-        unsigned kc = 0, cc = 0;  // ... and of the next sub-step to CONSUME
-        auto issue = [&](unsigned step) {
-            float *slot = ring[wv][step % NBUF];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                // 64 consecutive output floats, first one in row ki at channel ci.  Past the end of the query the
-                // cursor runs on (garbage rows, still inside the scan's feature block; those lanes are never stored).
-                const unsigned rowA = (unsigned)__builtin_amdgcn_readlane((int)r0, (int)(ki & 63u));
-                const unsigned sA = (rowA + ci - fo) * 4u;
-                unsigned voff = lane4, soff = sA;
-                if (!(ci >= fo && ci + 64u <= fo + (unsigned)D)) {
-                    // lanes >= C - ci belong to row ki + 1, channel ci + lane - C.  The hardware range-checks voff
-                    // only; a coordinate lane's offset may come out "negative": it reads 0 and is patched on arrival.
-                    const unsigned rowB = (unsigned)__builtin_amdgcn_readlane((int)r0, (int)((ki + 1u) & 63u));
-                    const unsigned sB = (rowB + ci - C - fo) * 4u;
-                    voff = lane4 + (lane >= C - ci ? sB : sA);
-                    soff = 0;
-                }
-                if (!(DBG & 1))
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pts, (__attribute__((address_space(3))) void *)(slot + s * 64),
-                                                             4, voff, soff, 0, 0);
-                ci += 64u;
-                if (ci >= C) {
-                    ci -= C;
-                    ++ki;
-                }
-            }
-        };
-        const unsigned pre = nsteps < (unsigned)(NBUF - 1) ? nsteps : (unsigned)(NBUF - 1);
-        for (unsigned t = 0; t < pre; ++t) issue(t);
-#pragma unroll 1
-        for (unsigned t = 0; t < nsteps; ++t) {
-            if (t + (unsigned)(NBUF - 1) < nsteps) issue(t + (unsigned)(NBUF - 1));
-            // gathers of step t have landed <=> no more than (ops issued after them) are outstanding
-            const unsigned ahead = nsteps - 1u - t < (unsigned)(NBUF - 1) ? nsteps - 1u - t : (unsigned)(NBUF - 1);
-            const unsigned stores_since = t < (unsigned)(NBUF - 1) ? t : (unsigned)(NBUF - 1);
-            if (!DBG) wait_vmcnt_dyn(4u * ahead + (EXACT ? stores_since : 0u));
-            if (DBG == 2) wait_vmcnt_dyn(4u * ahead);
-            float *slot = ring[wv][t % NBUF];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (!(cc >= fo && cc + 64u <= fo + (unsigned)D)) {  // wave-uniform: the sub-step holds a coordinate triple
-                    const bool wrap = lane >= C - cc;
-                    const unsigned cx = cc + lane - (wrap ? C : 0u) - xo;
-                    const unsigned k = kc + (wrap ? 1u : 0u);
-                    if (cx < 3u && k < (unsigned)K) slot[s * 64 + lane] = srel[wv][k * 3u + cx];
-                }
-                cc += 64u;
-                if (cc >= C) {
-                    cc -= C;
-                    ++kc;
-                }
-            }
-            const f32x4 w = *(const f32x4 *)&slot[lane * 4];
-            const unsigned u = t * 64u + lane;
-            if (u < units && (!(DBG & 2) || w[0] == 123.456f))
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, w),
-                                                       rs_out, u * 16u, 0, POLICY);
-        }
-        // the next query's set-up loads are waited for by the compiler (vmcnt(0)): the ring is drained by then
-    }
-}
-
 // ---- v5 (wide rows): row pieces straight into an LDS image of the output, ONE wave per workgroup --------------------
-// Measured in round 2 (profiles/r02_group_*.txt, r02_gather_bench.txt): with its stores removed the ring kernel above
+// Measured in round 2 (profiles/r02_group_*.txt, r02_gather_bench.txt): with their stores removed the round-1 style kernels
 // still needs 1.3-1.9 ms for 4.3 GB, while a bare LDS-DMA gather loop reaches 6-7 TB/s from HBM with only 4-8 waves
 // per CU -- the grouping kernels were bound by their own instruction streams (~170 mostly scalar, mostly dependent
 // instructions per KiB: the scalar unit of a CU saturates at full occupancy, a lone wave crawls at low occupancy), not
@@ -433,12 +312,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(24))) void grou
 //     are fetched underneath the current query, so a wave never sits through their two dependent round trips.
 // The vector-memory operations of a wave retire in issue order on one counter (gfx9), loads and stores alike, so
 // "X has landed" is "at most (operations issued after X) outstanding" -- acknowledgements of stores are never waited
-// for.  DBG (tools/group_bench.py only): 1 = no gathers, 2 = no stores.
+// for.
 // W = dwords per lane of a feature-row piece: 4 (`buffer_load_dwordx4 ... lds`, gfx950: 1 KiB per instruction; it takes
 // LDS destinations and sources that are only 4-byte aligned -- tools/dma_test/lds_dma_align.hip) when D % 4 == 0, else 1.
 // A level-2 row (128 floats) is ONE instruction instead of three, a level-3 row two instead of nine: the kernel was bound
 // by the issue cost of its LDS-DMA instructions (~60-180 cycles each), not by bytes in flight.
-template <typename IdxT, int POLICY, int DBG = 0, int W = 1>
+template <typename IdxT, int POLICY, int W = 1>
 __global__ __launch_bounds__(64) void group_points_rows_kernel(
     long long queries, long long q_per_xcd, int N, int S, int K, int D, int R, const float *__restrict__ xyz,
     const float *__restrict__ new_xyz, const float *__restrict__ points, const IdxT *__restrict__ idx, int xyz_first,
@@ -525,7 +404,6 @@ __global__ __launch_bounds__(64) void group_points_rows_kernel(
             const unsigned k0 = ib * (unsigned)R;
             float *img = lds_img + (ib & 1u) * IMG + (k0 * C & 31u);
             const unsigned rows = (unsigned)K - k0 < (unsigned)R ? (unsigned)K - k0 : (unsigned)R;
-            if (DBG & 1) return rows;
             auto piece = [&](float *dst, unsigned soff, unsigned p) {   // (the size operand must be a literal)
                 if constexpr (W == 4)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pts, (__attribute__((address_space(3))) void *)(dst + p * FP), 16,
@@ -575,16 +453,14 @@ __global__ __launch_bounds__(64) void group_points_rows_kernel(
             const unsigned rows = rows_next;
             const bool last = ib + 1u == nb;
             const unsigned idx_ops = (ib == 0 && has_next) ? NIDX : 0u;   // issued after image 0's pieces
-            if (DBG & 1) {
-                if (!last) rows_next = issue(ib + 1u);
-            } else if (overlap && !last) {
+            if (overlap && !last) {
                 rows_next = issue(ib + 1u);
                 // image ib has landed <=> at most [what was issued after its pieces] is outstanding
-                wait_vmcnt_any(rows_next * pieces + idx_ops + ((DBG & 2) ? 0u : prev_stores));
+                wait_vmcnt_any(rows_next * pieces + idx_ops + prev_stores);
             } else if (last && has_next && ib == 0) {
                 wait_vmcnt<0>();           // single-image queries: the index row of the next query must be in as well
             } else {
-                wait_vmcnt_any(overlap && !(DBG & 2) ? prev_stores : 0u);   // nothing was issued after image ib but those stores
+                wait_vmcnt_any(overlap ? prev_stores : 0u);   // nothing was issued after image ib but those stores
             }
             if (last && has_next) {
                 // everything issued before this query's last image has landed, the next query's index row included:
@@ -607,13 +483,12 @@ __global__ __launch_bounds__(64) void group_points_rows_kernel(
             for (unsigned u = lane, u0 = 0; u0 < units; u += 64u, u0 += 64u, ++nst) {
                 if (u < units) {
                     const f32x4 w = *(const f32x4 *)&buf[u * 4u];
-                    if (!(DBG & 2) || w[0] == 123.456f)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, w),
-                                                               rs_out, ((a0 >> 2) + u) * 16u, 0, POLICY);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, w),
+                                                           rs_out, ((a0 >> 2) + u) * 16u, 0, POLICY);
                 }
             }
-            prev_stores = (DBG & 2) ? 0u : nst;
-            if (!(DBG & 1) && !overlap && !last) rows_next = issue(ib + 1u);
+            prev_stores = nst;
+            if (!overlap && !last) rows_next = issue(ib + 1u);
         }
         if (!has_next) break;
         tail_stores = prev_stores;
@@ -757,20 +632,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void grou
     if (err && __any(bad) && lane == 0) atomicOr(err, 1);
 }
 
-static int env_int(const char *name, int dflt) {
-    const char *s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
-}
 
 }  // namespace tgn
 
 using namespace tgn;
 
-// impl: 0 = choose, 1 = v1 (4-B stores), 2 = v2 (16-B stores), 3 = v3 (16-B stores, gathers straight into an LDS ring),
-// 4 = v3 with conservative wait counts, 5/6 = v3 debug variants (no gathers / no stores: timing only),
-// 7 = v5 (row pieces into an LDS image, one wave per workgroup; max_blocks counts 4 waves as one block).  store_policy: cache-policy bits of the v2 output
-// stores (0 plain, 2 nt, 16 sc1, 17 sc0|sc1, 18 sc1|nt), -1 = default.  max_blocks: upper bound on the v2 grid
-// (0 = no bound): a caller that overlaps the grouping with a register-hungry kernel keeps CUs free this way.
+// impl: 0 = choose, 1 = the per-element kernel (any shape), 2 = 16-B stores through an LDS staging line (24 VGPRs: two waves
+// per SIMD beside a register-hungry kernel), 7 = row pieces into an LDS image (rows of >= 64 floats, one wave per workgroup;
+// max_blocks counts 4 of its waves as one block), 10 = pairs kernel (rows of 3 / 6 / 9 floats).  A kernel that does not take
+// the shape falls back to the next one down.  store_policy: cache-policy bits of the 16-B output stores (0 plain, 2 nt, 16 sc1,
+// 17 sc0|sc1, 18 sc1|nt), -1 = per-kernel default.  max_blocks: upper bound on the grid (0 = none): a caller that overlaps the
+// grouping with a register-hungry kernel keeps it to what is resident beside that kernel.
 TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *xyz, const float *new_xyz,
                                 const float *points, const void *idx, int idx_is_int64, int xyz_first, float *out,
                                 int impl, int store_policy, int max_blocks, tgn_stream_t stream) {
@@ -786,22 +658,19 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
         set_error("tgn_group_points: nsample %d / channels %d out of the supported range", K, 3 + D);
         return TGN_ERR_UNSUPPORTED;
     }
-    static const int env_impl = env_int("TGN_GROUP_IMPL", 0);
-    static const int env_policy = env_int("TGN_GROUP_POLICY", -1);   // -1: per kernel, below
-    static const int env_blocks = env_int("TGN_GROUP_MAX_BLOCKS", 0);
-    const bool exact = impl != 4;   // impl 4: the ring kernel with the conservative wait counts (stores not counted)
-    if (impl == 4) impl = 3;
-    if (impl <= 0) impl = env_impl;
-    if (store_policy < 0) store_policy = env_policy;
-    if (max_blocks <= 0) max_blocks = env_blocks;
+    if (impl != 0 && impl != 1 && impl != 2 && impl != 7 && impl != 10) {
+        set_error("tgn_group_points_ex: impl %d (0 choose, 1 per element, 2 staged 16-B stores, 7 row pieces, 10 pairs)", impl);
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    if (max_blocks < 0) max_blocks = 0;
     int *err = index_error_word();
     const int C = 3 + D;
     const unsigned magicC = (unsigned)((0x100000000ULL + C - 1) / C);
     const float *pts = points ? points : xyz;
     hipStream_t st = (hipStream_t)stream;
     const bool v2_ok = ((long long)K * C) % 4 == 0 && ((uintptr_t)out & 15) == 0 && (long long)N * (D > 0 ? D : 1) < (1LL << 30);
-    const bool ring_ok = v2_ok && C >= 64 && K <= 64 && (long long)N * D * 4 >= 256;
-    // narrow rows (level 1): one lane per (query, neighbour) pair, rows assembled in an LDS image (impl 10)
+    const bool rows_ok = v2_ok && C >= 64 && K <= 64 && (long long)N * D * 4 >= 256 && K % 4 == 0 && queries < (1LL << 31);
+    // narrow rows (level 1): one lane per (query, neighbour) pair, rows assembled in an LDS image
     {
         const long long pairs_per_scan = (long long)S * K;
         const bool pairs_ok = (D == 0 || D == 3 || D == 6) && (K & (K - 1)) == 0 && pairs_per_scan % 64 == 0 &&
@@ -843,13 +712,11 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
             return check_launch("group_points_pairs_kernel");
         }
     }
-    if ((impl == 5 || impl == 6 || impl == 8 || impl == 9) && store_policy < 0) store_policy = 16;
-    if ((impl == 5 || impl == 6 || impl == 8 || impl == 9) && !(ring_ok && store_policy == 16)) impl = 3;   // debug variants: sc1 only
-    if (impl >= 3 && !ring_ok) impl = 2;
-    if (impl == 2 && !v2_ok) impl = 1;
     // default: the row-piece kernel for wide rows (a bounded grid means "runs beside something that owns most of every
     // CU" -- the FPS level-1 workgroups, which leave one <= 48-VGPR wave per SIMD and ~95 KiB of LDS: 4 of its waves fit)
-    if (impl == 0) impl = (ring_ok && K % 4 == 0 && queries < (1LL << 31)) ? 7 : v2_ok ? 2 : 1;
+    if (impl == 0) impl = rows_ok ? 7 : v2_ok ? 2 : 1;
+    if (impl == 7 && !rows_ok) impl = 2;
+    if (impl == 2 && !v2_ok) impl = 1;
     if (impl == 1) {
         long long blocks = ((queries + 3) / 4 + 7) / 8 * 8;  // one query per wave, grid a multiple of the 8 XCDs
         if (blocks > (1LL << 30)) blocks = 1LL << 30;
@@ -861,18 +728,15 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
                                magicC, xyz, new_xyz, pts, (const int *)idx, xyz_first, out, err);
         return check_launch("group_points_kernel");
     }
-    if (impl >= 7 && !(ring_ok && K % 4 == 0 && queries < (1LL << 31))) impl = 3;
-    if (impl >= 7) {
+    if (impl == 7) {
         if (store_policy < 0) store_policy = 2;   // nt, see the pairs kernel above
-        // v5: one wave per workgroup; R rows per LDS image (multiple of 4, about 8 KiB, at most 20 rows)
-        static const int env_img = env_int("TGN_GROUP_IMAGE_FLOATS", 2176);   // floats per LDS image (experiments)
-        int R = (int)(env_img / C) / 4 * 4;
+        // one wave per workgroup; R rows per LDS image (multiple of 4, about 8 KiB, at most 20 rows)
+        int R = (int)(2176 / C) / 4 * 4;
         if (R < 4) R = 4;
         if (R > 20) R = 20;
         if (R > K) R = K;
         const size_t lds = (size_t)(2 * (32 + R * C) + 64 * 3 + 64 * 5) * sizeof(float);
-        static const int env_wide = env_int("TGN_GROUP_WIDE_DMA", 1);
-        const bool wide_dma = env_wide && D % 4 == 0;   // 16-byte LDS-DMA pieces
+        const bool wide_dma = D % 4 == 0;   // 16-byte LDS-DMA pieces
         long long qx = B >= 8 ? (long long)((B + 7) / 8) * S : (queries + 7) / 8;
         long long nb = qx;                       // workgroups (= waves) per XCD
         long long per_cu = (long long)(160 * 1024) / (long long)lds;   // resident workgroups per CU (LDS-bound)
@@ -883,8 +747,7 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
         if (nb > capw) nb = capw;
 #define TGN_GROUP_ROWS(IT, POL)                                                                                       \
     do {                                                                                                              \
-        auto kfn = impl == 8 ? group_points_rows_kernel<IT, POL, 1> : impl == 9 ? group_points_rows_kernel<IT, POL, 2> \
-                   : (wide_dma ? group_points_rows_kernel<IT, POL, 0, 4> : group_points_rows_kernel<IT, POL, 0>);    \
+        auto kfn = wide_dma ? group_points_rows_kernel<IT, POL, 4> : group_points_rows_kernel<IT, POL, 1>;            \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, dim3((unsigned)(nb * 8)), dim3(64), lds, st, queries, qx, N, S, K, D, R, xyz, new_xyz, pts, \
                            (const IT *)idx, xyz_first, out, err);                                                     \
@@ -897,7 +760,7 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
 #undef TGN_GROUP_ROWS
         return check_launch("group_points_rows_kernel");
     }
-    // v2: per-XCD query ranges (whole scans when B >= 8), at most 8 blocks per CU resident
+    // staged 16-B stores: per-XCD query ranges (whole scans when B >= 8), at most 8 blocks per CU resident
     long long q_per_xcd = B >= 8 ? (long long)((B + 7) / 8) * S : ((queries + 7) / 8 + 3) / 4 * 4;
     long long nbx = (q_per_xcd + 3) / 4;
     long long cap = 256;  // 32 CUs x 8 blocks per XCD
@@ -906,26 +769,14 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
     const dim3 grid((unsigned)(nbx * 8));
 #define TGN_GROUP_V2(IT, POL)                                                                                            \
     do {                                                                                                                 \
-        if (impl == 5)                                                                                                   \
-            hipLaunchKernelGGL((group_points_ring_kernel<IT, POL, 4, true, 1>), grid, dim3(256), 0, st, queries,         \
-                               q_per_xcd, N, S, K, D, magicC, xyz, new_xyz, pts, (const IT *)idx, xyz_first, out, err);  \
-        else if (impl == 6)                                                                                              \
-            hipLaunchKernelGGL((group_points_ring_kernel<IT, POL, 4, true, 2>), grid, dim3(256), 0, st, queries,         \
-                               q_per_xcd, N, S, K, D, magicC, xyz, new_xyz, pts, (const IT *)idx, xyz_first, out, err);  \
-        else if (impl == 3 && exact)                                                                                     \
-            hipLaunchKernelGGL((group_points_ring_kernel<IT, POL, 4, true>), grid, dim3(256), 0, st, queries, q_per_xcd, \
-                               N, S, K, D, magicC, xyz, new_xyz, pts, (const IT *)idx, xyz_first, out, err);             \
-        else if (impl == 3)                                                                                              \
-            hipLaunchKernelGGL((group_points_ring_kernel<IT, POL, 4, false>), grid, dim3(256), 0, st, queries,           \
-                               q_per_xcd, N, S, K, D, magicC, xyz, new_xyz, pts, (const IT *)idx, xyz_first, out, err);  \
-        else if (C >= 64 && K <= 64)                                                                                     \
+        if (C >= 64 && K <= 64)                                                                                          \
             hipLaunchKernelGGL((group_points_v2_kernel<IT, POL, true>), grid, dim3(256), 0, st, queries, q_per_xcd, N,   \
                                S, K, D, magicC, xyz, new_xyz, pts, (const IT *)idx, xyz_first, out, err);                \
         else                                                                                                             \
             hipLaunchKernelGGL((group_points_v2_kernel<IT, POL, false>), grid, dim3(256), 0, st, queries, q_per_xcd, N,  \
                                S, K, D, magicC, xyz, new_xyz, pts, (const IT *)idx, xyz_first, out, err);                \
     } while (0)
-    if (store_policy < 0) store_policy = 16;   // v2 / ring kernels: write-through (profiles/r01_store_bench.txt)
+    if (store_policy < 0) store_policy = 16;   // write-through (profiles/r01_store_bench.txt)
 #define TGN_GROUP_V2_POL(IT)                                   \
     switch (store_policy) {                                    \
         case 0: TGN_GROUP_V2(IT, 0); break;                    \
