@@ -74,10 +74,8 @@ constexpr int next_pow2(int v) {
     return p;
 }
 
-// HAND: how the block arg-max is handed over.  false: one LDS record per wave and ONE s_barrier per iteration, after which every
-// wave reduces the NW records.  true: tagged records and no barrier -- see "flag hand-off" in the loop.
-template <int NT, int P, int MODE, bool DBG, int CB, bool HAND>
-__device__ __forceinline__ void fps_bucket_body(const FpsArgs &a) {
+template <int NT, int P, int MODE, bool DBG = false, int CB = 4>
+__global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
     constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0, CERT = (MODE & kFpsModeCert) != 0;
     constexpr int NW = NT / kWave;
     constexpr int CAP = NT * P;
@@ -97,13 +95,6 @@ __device__ __forceinline__ void fps_bucket_body(const FpsArgs &a) {
     __shared__ float red[6][NW];
     __shared__ int wave_tot[NW];
     __shared__ float4 rec[2][NW][2];  // per wave: {value, tie key} and {x, y, z} of its candidate
-    constexpr int kHandWords = 96;    // HAND, per iteration parity: {value, key, tag, -} of wave w at word 4w, {x, y, z} at 34 + 4w; M at 72 / 78
-    __shared__ unsigned hrec_s[HAND ? 2 * kHandWords : 1];
-    // plain LDS words (a generic pointer would make these flat_load / flat_store; `volatile` makes the compiler wait for every
-    // single access -- 6 + 4 exposed LDS round trips per iteration); order and re-reading are pinned with compiler barriers
-    typedef __attribute__((address_space(3))) unsigned lds_word;
-#define TGN_CBAR() asm volatile("" ::: "memory")
-    lds_word *hrec = (lds_word *)hrec_s;
     float4 *outbuf = (float4 *)cells;                                  // [NT]: results of the current chunk of NT iterations
     float (*bmeta)[NW][P] = (float (*)[NW][P])(cells + NT * 4);        // [4][NW][P]: per bucket x, y, z, tie key of its arg-max
     static_assert(kCellWords % NT == 0, "prefix scan: whole words per thread");
@@ -269,13 +260,6 @@ __device__ __forceinline__ void fps_bucket_body(const FpsArgs &a) {
     // coalesced: the per-iteration global store sequence of one lane was ~20 instructions on the critical wave.
     if (tid == 0) outbuf[0] = make_float4(__int_as_float(0), qx, qy, qz);  // row 0: sampling_cuda_kernel.cu:39
 
-    if (HAND && ((a.flags >> 20) & 2)) __builtin_amdgcn_s_setprio(2);
-    if (HAND) {   // tags start at 0: no iteration j >= 1 matches
-        if (tid < 2 * kHandWords) hrec[tid] = 0u;
-        __syncthreads();
-    }
-    int wprev = -1;   // HAND: the wave that won the previous iteration (it holds the new sample: everybody waits for it)
-    const int hvar = HAND ? ((a.flags >> 20) & 15) : 0;   // experiment bits: 1 s_sleep in the polls, 2 low issue priority while polling
     // cached wave candidate (wave-uniform): value, tie key, coordinates
     float wm = -1.0f, wx = 0.0f, wy = 0.0f, wz = 0.0f;
     unsigned wkey = 0, pub_bits = 0u, pub_key = 0xFFFFFFFFu;
@@ -409,163 +393,6 @@ __device__ __forceinline__ void fps_bucket_body(const FpsArgs &a) {
             qx = wx;
             qy = wy;
             qz = wz;
-        } else if constexpr (HAND) {
-            // ---- flag hand-off.  93 % of the iterations everybody waits for ONE wave -- the previous winner's, which holds the
-            // new sample, refreshes its bucket and searches for its next candidate -- and with a barrier the reduction over the
-            // NW records only starts when that wave arrives.  Here every record carries the iteration number as a tag, stored
-            // last (the LDS operations of a wave complete in order), and nobody waits at a barrier:
-            //   * the other NW-1 waves publish, poll until all NW-1 of THEIR records are in and reduce those to M while the late
-            //     wave is still working; one of them parks M in LDS; then they poll the late wave's record alone and finish with
-            //     one scalar comparison M <-> late record;
-            //   * the late wave publishes, reads M (there long since) and does the same comparison.
-            // Records are double-buffered by iteration parity: a wave can only be one hand-off ahead of another (it needs
-            // everybody's records of iteration j+1 to finish j+1), so parity j is rewritten at j+2, after all reads of j.
-            // A record is two word triples, {value, key, tag} and {x, y, z}; a poll reads both with the same three ds_read_b32
-            // (lane l < 8: the first triple of wave l, lane 8 + l: the second), placed on 16 different banks so that each read
-            // is ONE pass of the LDS; the tag word is read first: a tag that matches vouches for the z read in the same pass and
-            // for everything read after it.
-            static_assert(NW == 8, "flag hand-off: 8-wave kernels");
-            lds_word *hp_ = hrec + ((unsigned)j & 1u) * kHandWords;
-            {
-                lds_word *w1 = hp_ + 4 * wave, *w0 = hp_ + 34 + 4 * wave;
-                w0[0] = __float_as_uint(wx);
-                w0[1] = __float_as_uint(wy);
-                w0[2] = __float_as_uint(wz);
-                w1[0] = pub_bits;
-                w1[1] = pub_key;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                TGN_CBAR();
-                w1[2] = (unsigned)j;
-                TGN_CBAR();
-            }
-            unsigned f_bits, f_key, f_x, f_y, f_z;   // the block's winner (wave-uniform)
-            int f_wave;
-            auto better = [](unsigned av, unsigned ak, unsigned bv, unsigned bk) { return av > bv || (av == bv && ak < bk); };
-            unsigned spins = 0;
-            // (the lane-dependent LDS offsets are re-derived from the lane number every iteration: hoisted out of the loop they
-            // would each pin a VGPR for the whole kernel, and the kernel must stay within the 232 of the barrier variant)
-            unsigned ln_ = (unsigned)lane;
-            asm volatile("" : "+v"(ln_));
-            const unsigned li = ln_ & 15u;
-            if (wave == wprev) {
-                // M: {value, key, tag, wave} at words 72.., {x, y, z} at words 78.. of the parity block; even lanes read the first
-                lds_word *mp = hp_ + 72 + (li & 1u) * 6;
-                unsigned a_, b_, c_, m_w;
-                do {
-                    TGN_CBAR();
-                    c_ = mp[2];   // the tag FIRST: what is read behind a matching tag was stored in front of it
-                    TGN_CBAR();
-                    a_ = mp[0];
-                    b_ = mp[1];
-                    m_w = hp_[75];
-                    asm volatile("" ::"v"(a_), "v"(b_), "v"(c_), "v"(m_w));   // all four requested in EVERY poll: one LDS round trip, not two
-                    if (++spins > (1u << 20)) __builtin_trap();
-                } while (__builtin_amdgcn_readlane((int)c_, 0) != j);
-                const unsigned m_bits = (unsigned)__builtin_amdgcn_readlane((int)a_, 0), m_key = (unsigned)__builtin_amdgcn_readlane((int)b_, 0);
-                const bool mine = better(pub_bits, pub_key, m_bits, m_key);
-                f_bits = mine ? pub_bits : m_bits;
-                f_key = mine ? pub_key : m_key;
-                f_x = mine ? __float_as_uint(wx) : (unsigned)__builtin_amdgcn_readlane((int)a_, 1);
-                f_y = mine ? __float_as_uint(wy) : (unsigned)__builtin_amdgcn_readlane((int)b_, 1);
-                f_z = mine ? __float_as_uint(wz) : (unsigned)__builtin_amdgcn_readlane((int)c_, 1);
-                f_wave = mine ? wave : __builtin_amdgcn_readfirstlane((int)m_w);
-            } else {
-                const unsigned late_bit = wprev >= 0 ? (1u << wprev) : 0u;
-                const unsigned all = 0xFFu;
-                lds_word *rp = hp_ + (li < 8u ? 4u * li : 34u + 4u * (li - 8u));
-                unsigned a_, b_, c_, ready;
-                if (hvar & 2) __builtin_amdgcn_s_setprio(0);
-                do {
-                    if (hvar & 1) __builtin_amdgcn_s_sleep(1);
-                    if (hvar & 4) __builtin_amdgcn_s_sleep(6);
-                    TGN_CBAR();
-                    c_ = rp[2];   // {tag | z} first (one pass: a matching tag vouches for the z beside it), then the words stored before it
-                    TGN_CBAR();
-                    a_ = rp[0];
-                    b_ = rp[1];
-                    asm volatile("" ::"v"(a_), "v"(b_), "v"(c_));
-                    ready = (unsigned)(ballot64(c_ == (unsigned)j)) & all;
-                    if (++spins > (1u << 20)) __builtin_trap();
-                } while ((ready | late_bit) != all);
-                // M = best of all waves but the late one (lanes 0..7 hold {value, key}, lanes 8..15 the coordinates)
-                const unsigned in_mask = all & ~late_bit;
-                const unsigned vb = (ln_ < 8u && ((in_mask >> ln_) & 1u)) ? a_ : 0u;
-                unsigned mb = vb;
-                asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                             "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                             "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
-                             : "+v"(mb));
-                mb = (unsigned)__builtin_amdgcn_readlane((int)mb, NW - 1);
-                const unsigned long long wmask = ballot64(vb == mb) & (unsigned long long)in_mask;
-                int wl = __builtin_ctzll(wmask);
-                if (__builtin_expect(__popcll(wmask) > 1, 0)) {  // equal maxima in several waves (rare): the smallest tie key wins
-                    const unsigned kk = ((wmask >> lane) & 1ull) ? b_ : 0xFFFFFFFFu;
-                    const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kk));
-                    wl = __builtin_ctzll(ballot64(kk == kmin) & wmask);
-                }
-                unsigned m_bits = mb, m_key = (unsigned)__builtin_amdgcn_readlane((int)b_, wl);
-                unsigned m_x = (unsigned)__builtin_amdgcn_readlane((int)a_, 8 + wl);
-                unsigned m_y = (unsigned)__builtin_amdgcn_readlane((int)b_, 8 + wl);
-                unsigned m_z = (unsigned)__builtin_amdgcn_readlane((int)c_, 8 + wl);
-                int m_w = wl;
-                if (wprev >= 0) {   // (wave-uniform)
-                    const int helper = wprev == 0 ? 1 : 0;
-                    if (wave == helper) {   // park M for the late wave (it reads it whether it turns out to be late or not)
-                        hp_[78] = m_x;
-                        hp_[79] = m_y;
-                        hp_[80] = m_z;
-                        hp_[72] = m_bits;
-                        hp_[73] = m_key;
-                        hp_[75] = (unsigned)m_w;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        TGN_CBAR();
-                        hp_[74] = (unsigned)j;
-                        TGN_CBAR();
-                    }
-                    unsigned l_bits, l_key, l_x, l_y, l_z;
-                    if (ready & late_bit) {   // it was in already: its record sits in lanes wprev and 8 + wprev
-                        l_bits = (unsigned)__builtin_amdgcn_readlane((int)a_, wprev);
-                        l_key = (unsigned)__builtin_amdgcn_readlane((int)b_, wprev);
-                        l_x = (unsigned)__builtin_amdgcn_readlane((int)a_, 8 + wprev);
-                        l_y = (unsigned)__builtin_amdgcn_readlane((int)b_, 8 + wprev);
-                        l_z = (unsigned)__builtin_amdgcn_readlane((int)c_, 8 + wprev);
-                    } else {
-                        if (hvar & 8) __builtin_amdgcn_s_sleep(10);
-                        lds_word *lp = hp_ + ((li & 1u) ? 34u + 4u * (unsigned)wprev : 4u * (unsigned)wprev);   // even lanes: {value, key, tag}
-                        do {
-                            if (hvar & 1) __builtin_amdgcn_s_sleep(1);
-                            TGN_CBAR();
-                            c_ = lp[2];
-                            TGN_CBAR();
-                            a_ = lp[0];
-                            b_ = lp[1];
-                            asm volatile("" ::"v"(a_), "v"(b_), "v"(c_));
-                            if (++spins > (1u << 20)) __builtin_trap();
-                        } while (__builtin_amdgcn_readlane((int)c_, 0) != j);
-                        l_bits = (unsigned)__builtin_amdgcn_readlane((int)a_, 0);
-                        l_key = (unsigned)__builtin_amdgcn_readlane((int)b_, 0);
-                        l_x = (unsigned)__builtin_amdgcn_readlane((int)a_, 1);
-                        l_y = (unsigned)__builtin_amdgcn_readlane((int)b_, 1);
-                        l_z = (unsigned)__builtin_amdgcn_readlane((int)c_, 1);
-                    }
-                    if (better(l_bits, l_key, m_bits, m_key)) {
-                        m_bits = l_bits;
-                        m_key = l_key;
-                        m_x = l_x;
-                        m_y = l_y;
-                        m_z = l_z;
-                        m_w = wprev;
-                    }
-                }
-                f_bits = m_bits; f_key = m_key; f_x = m_x; f_y = m_y; f_z = m_z; f_wave = m_w;
-                if (hvar & 2) __builtin_amdgcn_s_setprio(2);
-            }
-            if constexpr (CERT) cert.update(f_bits);
-            kwin = f_key;
-            qx = __uint_as_float(f_x);
-            qy = __uint_as_float(f_y);
-            qz = __uint_as_float(f_z);
-            wprev = f_wave;
         } else {
             if (kRecAllLanes || lane == 0) {  // {value bits, tie key} and {x, y, z}: 8 + 12 bytes of the wave's 32-byte record
                 *(uint2 *)(recb + wr_off) = make_uint2(pub_bits, pub_key);
@@ -687,17 +514,6 @@ __device__ __forceinline__ void fps_bucket_body(const FpsArgs &a) {
         if (false) {
         }
     }
-}
-
-template <int NT, int P, int MODE, bool DBG = false, int CB = 4>
-__global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
-    fps_bucket_body<NT, P, MODE, DBG, CB, false>(a);
-}
-// the flag hand-off variant: held to the 232 VGPRs the barrier variant needs, so that the same waves fit beside it on a CU
-// (2 x 232 of a SIMD's 512 registers; the allocation granule is 8)
-template <int NT, int P, int MODE>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_vgpr(228))) void fps_bucket_hand_kernel(FpsArgs a) {
-    fps_bucket_body<NT, P, MODE, false, 4, true>(a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1007,19 +823,10 @@ static int bucket_launch_mode(int b, int n_max, const FpsArgs &a, hipStream_t st
             return check_launch("fps_bucket_kernel<dbg>");
         }
     }
-    static const int handoff = getenv("TGN_FPS_HANDOFF") ? atoi(getenv("TGN_FPS_HANDOFF")) : 0;   // 1: flag hand-off (8-wave kernels)
-#define X(NT_, P_)                                                                                                  \
-    if (nt == NT_ && p == P_) {                                                                                     \
-        if constexpr (NT_ == 512 && P_ <= 48) {                                                                     \
-            if (handoff) {                                                                                          \
-                FpsArgs ah = a;                                                                                     \
-                ah.flags |= ((handoff >> 1) & 15) << 20;                                                            \
-                hipLaunchKernelGGL((fps_bucket_hand_kernel<NT_, P_, MODE>), dim3(b), dim3(NT_), 0, stream, ah);     \
-                return check_launch("fps_bucket_hand_kernel");                                                      \
-            }                                                                                                       \
-        }                                                                                                           \
-        hipLaunchKernelGGL((fps_bucket_kernel<NT_, P_, MODE>), dim3(b), dim3(NT_), 0, stream, a);                   \
-        return check_launch("fps_bucket_kernel");                                                                   \
+#define X(NT_, P_)                                                                                   \
+    if (nt == NT_ && p == P_) {                                                                      \
+        hipLaunchKernelGGL((fps_bucket_kernel<NT_, P_, MODE>), dim3(b), dim3(NT_), 0, stream, a);    \
+        return check_launch("fps_bucket_kernel");                                                    \
     }
     TGN_FPS_BUCKET_CONFIGS(X)
 #undef X
