@@ -181,3 +181,39 @@ def test_unet_sampling_on_a_side_stream_changes_nothing(dev):
             torch.cuda.synchronize()
         for y in outs[1:]:
             close(outs[0].cpu().numpy(), y.cpu().numpy(), "side-stream sampling vs in-place", tol=1e-5)
+
+
+def test_transition_down_survives_graph_replays_with_eager_work_in_between(dev):
+    """Regression: a captured TransitionDown -- offsets, FPS, kNN, fused set abstraction -- replayed with eager
+    allocations and kernels that read its SMALL outputs between the replays.  With the kNN redo counter cleared by
+    hipMemsetAsync (a memset node in the graph) the second replay died with a memory access fault just past torch's
+    private pool; the counter is now cleared by a kernel."""
+    from toothgroupnetwork_amd import point_transformer as PT, pointops as P, synth
+    torch.manual_seed(0)
+    n = 24000
+    pts = T(synth.scan_batch(1, n, "arch", 3)[0], dev)
+    p = pts[:, :3].contiguous()
+    o = P.register_offsets(torch.tensor([n], dtype=torch.int32, device=dev), [n])
+    x = torch.randn(n, 32, device=dev)
+    td = PT.TransitionDown(32, 64, 4, 24).to(dev).eval()
+    with torch.no_grad():
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            for _ in range(2):
+                ref = [t.clone() for t in td([p, x, o])]
+        torch.cuda.current_stream().wait_stream(s_)
+        torch.cuda.synchronize()
+        P.knn_cache_clear()
+        P.fps_prefix_clear()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = td([p, x, o])
+        P.knn_cache_clear()
+        P.fps_prefix_clear()
+        for _ in range(4):
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out[0], ref[0]) and torch.equal(out[2], ref[2])      # eager kernels + temporaries on the small outputs
+            assert float(out[0].double().sum()) == float(ref[0].double().sum())
+            close(out[1].cpu().numpy(), ref[1].cpu().numpy(), "replayed features", tol=1e-6)

@@ -33,6 +33,33 @@ inp_g = inp.clone().requires_grad_(True)
 t_u = timeit(lambda: net(inp_g))
 print(f"PointTransformerUNet forward, {B} x 24000 points: fused eval {t_f:.2f} ms ({B / t_f * 1e3:.1f} scans/s), "
       f"unfused composition (autograd on) {t_u:.2f} ms", flush=True)
+# the same forward as a HIP graph (no host round trip is left in the fused eval path; the redo counter of the kNN kernels is
+# cleared by a kernel, not by a memset node -- DESIGN.md 4.6)
+for presample in (True, False):
+    net.presample = presample
+    try:
+        static_in = inp.clone()
+        s_ = torch.cuda.Stream(); s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_), torch.no_grad():
+            for _ in range(2):
+                ref = net(static_in)
+        torch.cuda.current_stream().wait_stream(s_); torch.cuda.synchronize()
+        P.knn_cache_clear(); P.fps_prefix_clear()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g), torch.no_grad():
+            static_out = net(static_in)
+        P.knn_cache_clear(); P.fps_prefix_clear()
+        oks = []
+        for _ in range(3):
+            g.replay(); torch.cuda.synchronize()
+            oks.append(float((static_out - ref).abs().max()))     # (an eager allocation + kernel between replays)
+        t_g = timeit(g.replay, reps=10)
+        print(f"PointTransformerUNet forward, {B} x 24000 points, HIP graph replay (sampling pyramid {'on a side stream' if presample else 'in line'}): "
+              f"{t_g:.2f} ms ({B / t_g * 1e3:.1f} scans/s); max |replay - eager| over 3 replays {max(oks):.2e}", flush=True)
+        del g, static_out
+    except Exception as e:  # noqa: BLE001
+        print(f"graph capture (presample={presample}) failed: {type(e).__name__} {str(e)[:300]}", flush=True)
+net.presample = True
 # enc1 attention layer alone
 n, c, ns = 24000 * B, 32, 36
 layer = PT.PointTransformerLayer(c, c, 8, ns).to(dev).eval()

@@ -708,6 +708,19 @@ static int knn_heap_launch(int b, int m, int nsample, const float *xyz, const fl
     return check_launch("knn_heap_kernel");
 }
 
+namespace tgn {
+__global__ void knn_zero_word_kernel(int *w) { *w = 0; }
+// The redo counter is cleared by a one-thread KERNEL, not by hipMemsetAsync: under stream capture the memset becomes a
+// memset node of the HIP graph, and replays of graphs holding such a node on a block of torch's private pool faulted on
+// ROCm 7.2 whenever an eager allocation happened between two replays (tools/experiments/pt_capture_parts.py).
+static int zero_redo(int *redo, hipStream_t st) {
+    static const int use_memset = getenv("TGN_KNN_MEMSET") ? atoi(getenv("TGN_KNN_MEMSET")) : 0;
+    if (use_memset) return hipMemsetAsync(redo, 0, sizeof(int), st) == hipSuccess ? 0 : 1;
+    hipLaunchKernelGGL(knn_zero_word_kernel, dim3(1), dim3(1), 0, st, redo);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+}  // namespace tgn
+
 TGN_API size_t tgn_knnquery_workspace_bytes(int m) { return m > 0 ? ((size_t)m + 1) * sizeof(int) : 0; }
 
 TGN_API int tgn_knnquery_ws(int b, int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
@@ -722,8 +735,8 @@ TGN_API int tgn_knnquery_ws(int b, int m, int nsample, const float *xyz, const f
     const bool wave_path = nsample <= kWave - 1 && workspace && workspace_bytes >= tgn_knnquery_workspace_bytes(m);
     if (!wave_path) return knn_heap_launch(b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, nullptr, st);
     int *redo = (int *)workspace;
-    if (hipMemsetAsync(redo, 0, sizeof(int), st) != hipSuccess) {
-        set_error("tgn_knnquery: hipMemsetAsync failed");
+    if (zero_redo(redo, st)) {
+        set_error("tgn_knnquery: clearing the redo counter failed");
         return TGN_ERR_LAUNCH;
     }
     const int qpb = 4 * kKnnQ;  // queries per 256-thread block
@@ -752,8 +765,8 @@ TGN_API int tgn_knnquery_grid(int b, int n, int m, int nsample, const float *xyz
         return tgn_knnquery_ws(b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, workspace, workspace_bytes, stream);
     hipStream_t st = (hipStream_t)stream;
     int *redo = (int *)workspace;
-    if (hipMemsetAsync(redo, 0, sizeof(int), st) != hipSuccess) {
-        set_error("tgn_knnquery_grid: hipMemsetAsync failed");
+    if (zero_redo(redo, st)) {
+        set_error("tgn_knnquery_grid: clearing the redo counter failed");
         return TGN_ERR_LAUNCH;
     }
     float scale = 1.0f;  // cell size relative to the estimated k-neighbour radius (TGN_KNN_GRID_SCALE: experiments)
