@@ -38,9 +38,9 @@ class FirstStage(nn.Module):
         return self.offset_head(x), self.sem_head(x)
 
 
-def losses(offset, sem, xyz, label):
-    """tooth_class_loss (cross entropy, tgn_loss.py:110-129) + batch_center_offset_loss (tgn_loss.py:6-60): per tooth, the
-    mean squared distance of the moved points to the tooth centroid (through square_distance) and the direction term."""
+def losses_loop(offset, sem, xyz, label):
+    """tooth_class_loss (cross entropy, tgn_loss.py:110-129) + batch_center_offset_loss (tgn_loss.py:6-60) the way the
+    reference writes them: a python loop over the teeth with boolean-mask indexing (one host round trip per mask)."""
     ce = F.cross_entropy(sem.float(), label)
     cen, dirl, cnt = 0.0, 0.0, 0
     for t in range(1, 17):
@@ -61,6 +61,29 @@ def losses(offset, sem, xyz, label):
     return ce + 0.03 * cen / cnt + 0.03 * dirl / cnt, ce
 
 
+def losses(offset, sem, xyz, label, teeth=17):
+    """The same two terms without a host round trip: per-tooth sums by index_add over the label column instead of 16 boolean
+    masks (static shapes: the whole step can be captured in a HIP graph).  Same value as losses_loop up to summation order
+    (tests/test_gpu_train_step.py compares them)."""
+    ce = F.cross_entropy(sem.float(), label)
+    off = offset.float()
+    ones = torch.ones_like(label, dtype=torch.float32)
+    n_t = torch.zeros(teeth, device=xyz.device).index_add_(0, label, ones)                       # points per tooth
+    c_t = torch.zeros(teeth, 3, device=xyz.device).index_add_(0, label, xyz) / n_t.clamp_min(1.0)[:, None]
+    valid = ((n_t >= 5) & (torch.arange(teeth, device=xyz.device) >= 1)).float()                  # the loop's `continue`
+    d2 = U.square_distance((xyz + off)[None], c_t[None])[0].gather(1, label[:, None])[:, 0]      # |p + off - c_tooth(p)|^2
+    cen_t = torch.zeros(teeth, device=xyz.device).index_add_(0, label, d2) / n_t.clamp_min(1.0)
+    to_c = c_t[label] - xyz
+    d = to_c / to_c.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    on = off.norm(dim=1, keepdim=True)
+    keep = (on[:, 0] > 2e-4).float()
+    dot = ((off / on.clamp_min(1e-12)) * d).sum(1) - 1.0
+    k_t = torch.zeros(teeth, device=xyz.device).index_add_(0, label, keep)
+    dir_t = torch.zeros(teeth, device=xyz.device).index_add_(0, label, dot * dot * keep) / k_t.clamp_min(1.0)
+    cnt = valid.sum().clamp_min(1.0)
+    return ce + 0.03 * (cen_t * valid).sum() / cnt + 0.03 * (dir_t * valid).sum() / cnt, ce
+
+
 def make_scan(n, seed, dev):
     pts = synth.scan_batch(1, n, "arch", seed)            # (1, n, 6): xyz + normal
     xyz = torch.from_numpy(pts[0, :, :3]).to(dev)
@@ -68,6 +91,41 @@ def make_scan(n, seed, dev):
     tooth = (ang.clamp(0, 3.14159) / 3.1416 * 16).long().clamp(0, 15) + 1
     label = torch.where(xyz[:, 2] < xyz[:, 2].median(), torch.zeros_like(tooth), tooth)
     return torch.from_numpy(pts.transpose(0, 2, 1).copy()).to(dev), xyz, label
+
+
+def run_graph(net, opt, feat, xyz, label, steps, amp):
+    """The whole step -- forward, losses, backward, Adam -- captured once in a HIP graph and replayed (no host round trip is left
+    in it: static-shape losses, trusted kNN indices, capturable fused Adam)."""
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            offset, sem = net(feat)
+            loss, ce = losses(offset, sem, xyz, label)
+        opt.zero_grad(set_to_none=False)
+        loss.backward()
+        opt.step()
+        return loss.detach(), ce.detach()
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        first = step()          # two eager steps on a side stream (allocator warm-up, as torch's capture recipe asks)
+        step()
+    torch.cuda.current_stream().wait_stream(s_)
+    torch.cuda.synchronize()
+    first_loss = float(first[0])
+    from toothgroupnetwork_amd import pointops as P
+    P.knn_cache_clear(); P.fps_prefix_clear()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        loss, ce = step()
+    P.knn_cache_clear(); P.fps_prefix_clear()
+    out = []
+    for it in range(steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); g.replay(); b.record()
+        torch.cuda.synchronize()
+        out.append(dict(ms=a.elapsed_time(b), loss=float(loss), ce=float(ce), bad_grads=0, out_dtype="graph"))
+    out[0]["loss"] = first_loss
+    return out
 
 
 def run(net, opt, feat, xyz, label, steps, amp):
@@ -95,6 +153,7 @@ def main():
     ap.add_argument("--points", type=int, default=24000)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--small", action="store_true", help="reduced widths / depths (tests)")
+    ap.add_argument("--graph", action="store_true", help="also capture the whole step in a HIP graph and time its replays")
     ap.add_argument("--profile", action="store_true", help="print the top GPU kernels of one bf16-autocast step (torch.profiler)")
     args = ap.parse_args()
     dev = torch.device("cuda")
@@ -103,11 +162,24 @@ def main():
     for amp in (False, True):
         torch.manual_seed(0)
         net = (FirstStage((16, 32, 32, 64, 64), (1, 2, 2, 2, 1)) if args.small else FirstStage()).to(dev).train()
-        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
         r = run(net, opt, feat, xyz, label, args.steps, amp)
         res["bf16_autocast" if amp else "fp32"] = dict(ms_per_step=float(np.median([x["ms"] for x in r[1:]])), first_loss=r[0]["loss"],
                                                        last_loss=r[-1]["loss"], bad_grads=sum(x["bad_grads"] for x in r),
                                                        head_dtype=r[0]["out_dtype"], params=sum(p.numel() for p in net.parameters()))
+    if args.graph:
+        for amp in (False, True):
+            for presample in (True, False):
+                try:
+                    torch.manual_seed(0)
+                    net = (FirstStage((16, 32, 32, 64, 64), (1, 2, 2, 2, 1)) if args.small else FirstStage()).to(dev).train()
+                    net.unet.presample = presample
+                    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True, capturable=True)
+                    r = run_graph(net, opt, feat, xyz, label, args.steps, amp)
+                    res[f"graph_{'bf16_autocast' if amp else 'fp32'}_{'side_stream_fps' if presample else 'inline_fps'}"] = dict(
+                        ms_per_step=float(np.median([x["ms"] for x in r[1:]])), first_loss=r[0]["loss"], last_loss=r[-1]["loss"])
+                except Exception as e:  # noqa: BLE001
+                    res[f"graph_{'bf16_autocast' if amp else 'fp32'}_{'side_stream_fps' if presample else 'inline_fps'}"] = f"failed: {type(e).__name__} {str(e)[:200]}"
     if args.profile:
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:

@@ -67,6 +67,64 @@ def pt_softmax_aggregate(x_v, p_r, logit, idx):
     return _SoftmaxAggregate.apply(x_v, p_r, logit, idx.to(torch.int32).contiguous())
 
 
+class _LinearSplitK(Function):
+    """y = x W^T + b for TALL inputs (24 000 ... 864 000 rows) and narrow layers (3 ... 128 wide), the training path's
+    linears.  The forward and the input gradient are ordinary GEMMs; the weight gradient dW = dy^T x is a contraction over
+    the ROWS with a tiny (out x in) result, which rocBLAS runs as one or two tiles walking the whole K (370 us for a 32 x 32
+    result over 24 000 rows -- a third of the training step went there).  Here the rows are cut into slices, the slices
+    contracted as a batch (one tile each: the whole chip) and the partial results summed."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)          # (under autocast: the bf16 GEMM autocast picks)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy2 = gy.reshape(-1, gy.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        if gy2.dtype != x2.dtype:
+            x2 = x2.to(gy2.dtype)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = (gy2 @ weight.to(gy2.dtype)).reshape(x.shape).to(x.dtype)
+        if ctx.needs_input_grad[1]:
+            rows = gy2.shape[0]
+            slices = max(1, min(512, rows // 1024))
+            per = rows // slices
+            main = slices * per
+            gw = torch.bmm(gy2[:main].reshape(slices, per, -1).transpose(1, 2), x2[:main].reshape(slices, per, -1)).sum(0, dtype=torch.float32)
+            if main < rows:
+                gw = gw + (gy2[main:].t() @ x2[main:]).float()
+            gw = gw.to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy2.sum(0, dtype=torch.float32).to(weight.dtype)
+        return gx, gw, gb
+
+
+SPLITK_MIN_ROWS = 4096
+
+
+def _lin(mod, x):
+    """nn.Linear `mod` applied to x; tall inputs in training take the split-K weight gradient."""
+    if torch.is_grad_enabled() and x.numel() // x.shape[-1] >= SPLITK_MIN_ROWS and max(mod.in_features, mod.out_features) <= 256:
+        return _LinearSplitK.apply(x, mod.weight, mod.bias)
+    return mod(x)
+
+
+def _mlp_rows(seq, t):
+    """nn.Sequential of Linear / BatchNorm1d / ReLU applied to t (n, nsample, c): BatchNorm1d normalises every channel over
+    all n * nsample rows -- what the reference gets by transposing to (n, c, nsample) and back (blocks.py:37, 40) -- on the
+    FLATTENED (n * nsample, c) view, without the two transposed copies per BatchNorm."""
+    n, ns = t.shape[0], t.shape[1]
+    t = t.reshape(n * ns, -1)
+    for layer in seq:
+        t = _lin(layer, t) if isinstance(layer, nn.Linear) else layer(t)
+    return t.view(n, ns, -1)
+
+
 def _bn_scale_shift(bn):
     s = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).float()
     return s, (bn.bias.detach() - bn.running_mean * s).float()
@@ -121,7 +179,7 @@ class PointTransformerLayer(nn.Module):
 
     def forward(self, pxo):
         p, x, o = pxo  # (n, 3), (n, c), (b)
-        x_q, x_k, x_v = self.linear_q(x), self.linear_k(x), self.linear_v(x)
+        x_q, x_k, x_v = _lin(self.linear_q, x), _lin(self.linear_k, x), _lin(self.linear_v, x)
         idx, _ = pointops.knnquery(self.nsample, p, p, o, o)           # one search for both groupings of blocks.py:34-35
         g = self.out_planes // self.share_planes
         if (_frozen(self, p, x) and self.nsample <= 64 and self.out_planes % 4 == 0 and g in (4, 8, 16, 32, 64)
@@ -136,11 +194,8 @@ class PointTransformerLayer(nn.Module):
             # (idx comes from this package's kNN: no index check, i.e. no host round trip per layer)
             x_kg = pointops._QueryGroup.apply(p, p, x_k.contiguous(), idx, True)                            # (n, nsample, 3+c)
             p_r, x_kg = x_kg[:, :, 0:3], x_kg[:, :, 3:]
-            for i, layer in enumerate(self.linear_p):
-                p_r = layer(p_r.transpose(1, 2).contiguous()).transpose(1, 2).contiguous() if i == 1 else layer(p_r)
-            w = x_kg - x_q.unsqueeze(1) + p_r
-            for i, layer in enumerate(self.linear_w):
-                w = layer(w.transpose(1, 2).contiguous()).transpose(1, 2).contiguous() if i % 3 == 0 else layer(w)
+            p_r = _mlp_rows(self.linear_p, p_r)
+            w = _mlp_rows(self.linear_w, x_kg - x_q.unsqueeze(1) + p_r)
             return pt_softmax_aggregate(x_v.contiguous(), p_r.contiguous(), w.contiguous(), idx)
 
 
@@ -171,7 +226,7 @@ class TransitionDown(nn.Module):
     def forward(self, pxo):
         p, x, o = pxo  # (n, 3), (n, c), (b)
         if self.stride == 1:
-            return [p, self.relu(self.bn(self.linear(x))), o]
+            return [p, self.relu(self.bn(_lin(self.linear, x))), o]
         pre, self._presampled = getattr(self, "_presampled", None), None
         if pre is not None and pre[0] is p and pre[1] is o:
             # sampled ahead on a side stream (PointTransformerUNet._presample): sampling depends on the coordinates only
@@ -198,8 +253,9 @@ class TransitionDown(nn.Module):
                                       ptr(kidx), 0, 1, ptr(out), stream()), "sa_gather_max")
             return [n_p, out, n_o]
         x = pointops.queryandgroup(self.nsample, p, n_p, x, None, o, n_o, use_xyz=True)  # (m, nsample, 3+c)
-        x = self.relu(self.bn(self.linear(x).transpose(1, 2).contiguous()))              # (m, c, nsample)
-        x = self.pool(x).squeeze(-1)                                                     # (m, c)
+        m = x.shape[0]
+        x = self.relu(self.bn(_lin(self.linear, x.reshape(m * self.nsample, -1))))       # BatchNorm over all m * nsample rows (blocks.py:72)
+        x = x.view(m, self.nsample, -1).max(1)[0]                                        # MaxPool1d(nsample) (:73) -> (m, c)
         return [n_p, x, n_o]
 
 
@@ -243,9 +299,9 @@ class PointTransformerBlock(nn.Module):
     def forward(self, pxo):
         p, x, o = pxo
         identity = x
-        x = self.relu(self.bn1(self.linear1(x)))
+        x = self.relu(self.bn1(_lin(self.linear1, x)))
         x = self.relu(self.bn2(self.transformer2([p, x, o])))
-        x = self.bn3(self.linear3(x))
+        x = self.bn3(_lin(self.linear3, x))
         x = x + identity
         return [p, self.relu(x), o]
 
