@@ -47,7 +47,7 @@ def test_static_losses_equal_the_reference_style_loop(dev):
     ga = torch.autograd.grad(a, (offset, sem))
     b, _ = mod.losses(offset, sem, xyz, label)
     gb = torch.autograd.grad(b, (offset, sem))
-    assert abs(float(a) - float(b)) <= 1e-5 * abs(float(a))
+    assert abs(float(a.detach()) - float(b.detach())) <= 1e-5 * abs(float(a.detach()))
     for x, y in zip(ga, gb):
         assert float((x - y).abs().max()) <= 1e-6 + 1e-4 * float(x.abs().max())
 

@@ -84,6 +84,71 @@ def losses(offset, sem, xyz, label, teeth=17):
     return ce + 0.03 * (cen_t * valid).sum() / cnt + 0.03 * (dir_t * valid).sum() / cnt, ce
 
 
+class TwoStage(nn.Module):
+    """The two passes of GroupingNetworkModule.forward (grouping_network_module.py:16-101): the first-stage network on the whole
+    scan; then, around the centroid of every tooth (the reference clusters the moved foreground points with DBSCAN on the CPU and
+    crops with a KDTree, :45-72; here: the label centroids, a distance matrix and topk -- the crops are what matters for the
+    operators), the `crop` nearest points, centred (ops_utils.centering_object), as ONE batch of ~14 x 3072 points through a second
+    U-Net with offset and mask heads (:82): the small-cloud, many-cloud regime of FPS / kNN (3072 -> 768 -> 192 -> 48 -> 12)."""
+
+    def __init__(self, small=False, crop=3072, teeth=14):
+        super().__init__()
+        mk = (lambda c: FirstStage((16, 32, 32, 64, 64), (1, 2, 2, 2, 1), classes=c)) if small else (lambda c: FirstStage(classes=c))
+        self.first, self.second, self.crop, self.teeth = mk(17), mk(2), crop, teeth
+
+    def forward(self, feat, xyz, label):
+        offset, sem = self.first(feat)                                                   # (N,3), (N,17)
+        with torch.no_grad():
+            T = self.teeth
+            ones = torch.ones_like(label, dtype=torch.float32)
+            n_t = torch.zeros(17, device=xyz.device).index_add_(0, label, ones)
+            c_t = torch.zeros(17, 3, device=xyz.device).index_add_(0, label, xyz) / n_t.clamp_min(1.0)[:, None]
+            cent = c_t[1:1 + T]                                                          # T tooth centroids
+            d = U.square_distance(cent[None], xyz[None])[0]                              # (T, N)
+            idx = d.topk(self.crop, dim=1, largest=False)[1]                             # ops_utils.get_nearest_neighbor_idx
+            crops = feat[0][:, idx.reshape(-1)].view(6, T, self.crop).permute(1, 0, 2).contiguous()   # (T, 6, crop)
+            crops[:, :3] -= crops[:, :3].mean(2, keepdim=True)                           # centering_object
+            mask_gt = (label[idx] == torch.arange(1, 1 + T, device=xyz.device)[:, None]).long().reshape(-1)
+        offset2, mask2 = self.second(crops)                                              # (T*crop, 3), (T*crop, 2)
+        return offset, sem, offset2, mask2, mask_gt
+
+
+def run_two_stage(net, opt, feat, xyz, label, steps, amp, graph):
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            offset, sem, offset2, mask2, mask_gt = net(feat, xyz, label)
+            loss, _ = losses(offset, sem, xyz, label)
+            loss = loss + F.cross_entropy(mask2.float(), mask_gt) + 0.03 * offset2.float().square().sum(1).mean()
+        opt.zero_grad(set_to_none=False)
+        loss.backward()
+        opt.step()
+        return loss.detach()
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        first = float(step())
+        step()
+    torch.cuda.current_stream().wait_stream(s_)
+    torch.cuda.synchronize()
+    fn, lossbuf = step, None
+    if graph:
+        from toothgroupnetwork_amd import pointops as P
+        P.knn_cache_clear(); P.fps_prefix_clear()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            lossbuf = step()
+        P.knn_cache_clear(); P.fps_prefix_clear()
+        fn = g.replay
+    ms, last = [], first
+    for _ in range(steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); r = fn(); b.record()
+        torch.cuda.synchronize()
+        ms.append(a.elapsed_time(b))
+        last = float(lossbuf if graph else r)
+    return dict(ms_per_step=float(np.median(ms[1:])), first_loss=first, last_loss=last)
+
+
 def make_scan(n, seed, dev):
     pts = synth.scan_batch(1, n, "arch", seed)            # (1, n, 6): xyz + normal
     xyz = torch.from_numpy(pts[0, :, :3]).to(dev)
@@ -153,6 +218,8 @@ def main():
     ap.add_argument("--points", type=int, default=24000)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--small", action="store_true", help="reduced widths / depths (tests)")
+    ap.add_argument("--two-stage", action="store_true", help="also time the full two-stage step (first-stage network + ~14 crops of 3072 "
+                    "points through a second U-Net, grouping_network_module.py:16-101), eager and as a HIP graph")
     ap.add_argument("--graph", action="store_true", help="also capture the whole step in a HIP graph and time its replays")
     ap.add_argument("--profile", action="store_true", help="print the top GPU kernels of one bf16-autocast step (torch.profiler)")
     args = ap.parse_args()
@@ -180,6 +247,19 @@ def main():
                         ms_per_step=float(np.median([x["ms"] for x in r[1:]])), first_loss=r[0]["loss"], last_loss=r[-1]["loss"])
                 except Exception as e:  # noqa: BLE001
                     res[f"graph_{'bf16_autocast' if amp else 'fp32'}_{'side_stream_fps' if presample else 'inline_fps'}"] = f"failed: {type(e).__name__} {str(e)[:200]}"
+    if args.two_stage:
+        crop = min(3072, args.points // 2)
+        for graph in (False, True):
+            try:
+                torch.manual_seed(0)
+                net2 = TwoStage(args.small, crop).to(dev).train()
+                net2.first.unet.presample = net2.second.unet.presample = not graph
+                opt2 = torch.optim.Adam(net2.parameters(), lr=1e-3, fused=True, capturable=graph)
+                res[f"two_stage_fp32_{'graph' if graph else 'eager'}"] = dict(
+                    run_two_stage(net2, opt2, feat, xyz, label, args.steps, False, graph), crops=f"14 x {crop}",
+                    params=sum(p.numel() for p in net2.parameters()))
+            except Exception as e:  # noqa: BLE001
+                res[f"two_stage_fp32_{'graph' if graph else 'eager'}"] = f"failed: {type(e).__name__} {str(e)[:300]}"
     if args.profile:
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
