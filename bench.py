@@ -112,8 +112,6 @@ def main():
     shape = hotpath.SHAPE_A if args.shape == "A" else hotpath.SHAPE_B
     xyz, feats, scans = make_inputs(B, device, seed=100 + rank, shape=shape)
     gopts = dict(fused=bool(args.fused))
-    if args.fused and args.shape != "A":
-        raise SystemExit("--fused is defined for shape A (single-scale levels)")
     hp = hotpath.HotPath(B, device, shape=shape, pipeline=bool(args.pipeline), fps_prefix=bool(args.fps_prefix), **gopts)
     for _ in range(max(args.warmup, 1)):                     # (the first run also measures the schedule's plan, hotpath.plan_schedule)
         hp.run(xyz, feats, inputs_on_current_stream=False)   # the synthetic scans are resident before any step
@@ -150,7 +148,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": ("shape_A FUSED (NOT the headline configuration): 24000-pt scans, npoint=[4096,1024,256], nsample=32, "
+        "config": {"workload": ("shape_B FUSED (NOT the headline configuration): the three multi-scale set-abstraction levels of the reference "
+                                "PointNet++ net on 24000-pt scans, FPS + ball queries + chained two-layer MLP kernels") if (args.fused and args.shape == "B") else
+                               ("shape_A FUSED (NOT the headline configuration): 24000-pt scans, npoint=[4096,1024,256], nsample=32, "
                                 "radii=[0.05,0.1,0.2]; FPS + ball query + fused set-abstraction level (gather, centre, two-layer shared "
                                 "MLP [9->64->128, 131->256->512, 515->512->1024] on the fp32 matrix cores, folded BatchNorms, ReLUs, max "
                                 "over K); no grouped tensor and no layer output of size S*K is written, level l feeds level l+1") if args.fused else
@@ -158,6 +158,9 @@ def main():
                                 "D=[6,128,512]; FPS+ball_query+group forward, grouped tensors materialised") if args.shape == "A" else
                                ("shape_B (NOT the headline configuration): 24000-pt scans, npoint=[1024,512,256], multi-scale "
                                 "radii [[.025,.05],[.05,.1],[.1,.2]], nsample [32,64], D=[6,256,1024]; FPS+ball_query+group forward"),
+                   **({"fused_levels": "the reference network's own set-abstraction stack (pointnet_pp.py:13-15): per branch a two-layer "
+                                       "shared MLP [9->128->128, 259->256->512, 1027->784->1024], one chained kernel per branch, the "
+                                       "branches written side by side; nothing of size S*K is written"} if (args.fused and args.shape == "B") else {}),
                    "meshes_per_step_per_gpu": B, "sharding": f"independent meshes x {world} ranks, no data-path collective",
                    "index_dtype": "int32",
                    "fps_levels_2_3": "identity shortcut (FPS of an FPS result; certificate checked on device)"
@@ -221,11 +224,13 @@ def main():
         # with the gather, per gathered row in the direct form) and of the second layers (per gathered row), against 157.3 TFLOP/s
         fl = 0
         Nl = shape["n"]
-        for S, K, D, widths in zip(shape["npoint"], shape["nsample"], shape["d"], shape["mlp"]):
-            direct = (3 + D) <= 16
-            fl += 2 * (S * K if direct else Nl) * (3 + D) * widths[0]
-            if len(widths) == 2:
-                fl += 2 * S * K * widths[0] * widths[1]
+        for S, r, K, D, m in zip(shape["npoint"], shape["radius"], shape["nsample"], shape["d"], shape["mlp"]):
+            brs = hotpath._branches(r, K)
+            for (_, kb), widths in zip(brs, hotpath._branch_mlps(m, len(brs))):
+                direct = (3 + D) <= 16
+                fl += 2 * (S * kb if direct else Nl) * (3 + D) * widths[0]
+                if len(widths) == 2:
+                    fl += 2 * S * kb * widths[0] * widths[1]
             Nl = S
         sa_ms = sum(v for k, v in avg.items() if k.startswith("group"))
         tf = fl * B / (sa_ms * 1e-3) / 1e12

@@ -300,11 +300,13 @@ int tgn_sa_direct_max(int B, int N, int S, int K, int D, int C1, const float *xy
  * C1p = the first layer's width padded with zero columns to a multiple of 16 (b1, W1, A1 padded alike);
  * W2f (C1p/8, C2, 8): W2f[kb][c][i] = scale2[c] * W2[c, 8*kb + i] (zero for padded k); b2 (C2) = shift2 + scale2*bias2.
  * nsample <= 64; idx int32 or int64, local to each cloud, out-of-range handled like tgn_group_points.
+ * out_stride: floats between consecutive rows of `out` (0 = C2): a multi-scale level lets every (radius, nsample) branch write
+ * its columns of the concatenated (B,S,sum C2) tensor directly (pointnet2_utils.py:296-298 concatenates them).
  */
 int tgn_sa_mlp2_direct_supported(int K, int D);
 int tgn_sa_mlp2_max(int B, int N, int S, int K, int D, int C1p, int C2, const float *A1, const float *xyz,
                     const float *points, const float *new_xyz, const float *W1, const float *b1, const void *idx,
-                    int idx_is_int64, const float *W2f, const float *b2, float *out, tgn_stream_t stream);
+                    int idx_is_int64, const float *W2f, const float *b2, float *out, int out_stride, tgn_stream_t stream);
 /* index_points (pointnet2_utils.py:44-61): out[b,j,:] = points[b, idx[b,j], :], idx flattened to (B,M). */
 int tgn_gather_points(int B, int N, int M, int C, const float *points, const void *idx, int idx_is_int64, float *out,
                       tgn_stream_t stream);

@@ -224,3 +224,39 @@ def test_hotpath_fused_levels_vs_oracle(dev, oracle, pipeline, mlp):
         want = oracle.set_abstraction_mlp(cur, new_xyz, feat, gidx, layers, 1e-5, True)   # (identity BatchNorm)
         close(lv["out"].cpu().numpy(), want, f"level {li + 1}")
         cur, feat = new_xyz, lv["out"].cpu().numpy()                  # the GPU's own fp32 output feeds the next level in both chains
+
+
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_hotpath_fused_multi_scale_levels_vs_oracle(dev, oracle, pipeline):
+    """bench.py --shape B --fused 1 in small: two (radius, nsample) branches per level, each one chained two-layer kernel writing
+    its columns of the level's concatenated output (pointnet2_utils.py:296-298), [features, centred xyz] row order."""
+    from toothgroupnetwork_amd import hotpath, synth
+    mlp = [[[24, 32], [40, 48]], [[64, 72], [64, 56]]]
+    shape = dict(n=3000, npoint=[384, 96], radius=[[0.1, 0.2], [0.25, 0.5]], nsample=[[16, 32], [32, 64]], d=[6, 80], mlp=mlp,
+                 xyz_first=False)
+    B = 2
+    scans = synth.scan_batch(B, 3000, "arch", 43)
+    pts = T(scans, dev)
+    xyz = pts[:, :, :3].contiguous()
+    hp = hotpath.HotPath(B, dev, shape=shape, pipeline=pipeline, fused=True)
+    for _ in range(3):
+        levels = hp.run(xyz, [pts])
+    torch.cuda.synchronize()
+    cur, feat = scans[:, :, :3].copy(), scans
+    for li, lv in enumerate(levels):
+        fidx = oracle.farthest_point_sample(cur, lv["S"])
+        new_xyz = oracle.index_points(cur, fidx)
+        col = 0
+        for br, (r, K) in zip(lv["branches"], hotpath._branches(shape["radius"][li], shape["nsample"][li])):
+            gidx = oracle.query_ball_point(r, K, cur, new_xyz)
+            assert np.array_equal(br["group_idx"].cpu().numpy(), gidx)
+            # br["layers"] holds (C_out, C_in) matrices in [x, y, z, features] column order; the oracle groups [features, xyz] here
+            (W1, b1), (W2, b2) = br["layers"]
+            W1f = np.concatenate([W1[:, 3:], W1[:, :3]], 1)
+            ident = lambda b: (np.ones(len(b)), np.zeros(len(b)), np.zeros(len(b)), np.full(len(b), 1.0 - 1e-5))
+            want = oracle.set_abstraction_mlp(cur, new_xyz, feat, gidx, [(W1f, b1) + ident(b1), (W2, b2) + ident(b2)], 1e-5, False)
+            c2 = W2.shape[0]
+            close(lv["out"][:, :, col:col + c2].cpu().numpy(), want, f"level {li + 1} branch K={K}")
+            col += c2
+        assert col == lv["out"].shape[2]
+        cur, feat = new_xyz, lv["out"].cpu().numpy()

@@ -32,7 +32,7 @@ constexpr int kFS = 12;                        // fragment row stride in floats:
 constexpr int kFrag = 2 * 128 * kFS;           // one operand tile [k parity][row][k-step]
 
 template <typename IdxT, bool DIRECT>
-__global__ __launch_bounds__(256, 2) void sa_mlp2_max_kernel(long long Q, int N, int S, int K, int D, int C1p, int C2,
+__global__ __launch_bounds__(256, 2) void sa_mlp2_max_kernel(long long Q, int N, int S, int K, int D, int C1p, int C2, int ostride,
                                                               const float *__restrict__ A1,       // commuted: (B,N,C1p)
                                                               const float *__restrict__ xyz,      // direct: (B,N,3)
                                                               const float *__restrict__ points,   // direct: (B,N,D)
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256, 2) void sa_mlp2_max_kernel(long long Q, int N,
                                                               const IdxT *__restrict__ idx,       // (B,S,K)
                                                               const float *__restrict__ W2f,      // (C1p/8, C2, 8)
                                                               const float *__restrict__ b2,       // (C2)
-                                                              float *__restrict__ out,            // (B,S,C2)
+                                                              float *__restrict__ out,            // (B,S,C2), row stride `ostride` floats
                                                               int *__restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *FA = smem, *FB = smem + 2 * kFrag, *cst = smem + 4 * kFrag;
@@ -203,12 +203,12 @@ __global__ __launch_bounds__(256, 2) void sa_mlp2_max_kernel(long long Q, int N,
             const float bias = b2[col];
             if (kshift == 6) {   // 64 rows = one query
                 const long long qq = q0 + wm;
-                if (qq < Q) out[(size_t)qq * C2 + col] = fmaxf(fmaxf(cm[0][j], cm[1][j]) + bias, 0.0f);
+                if (qq < Q) out[(size_t)qq * ostride + col] = fmaxf(fmaxf(cm[0][j], cm[1][j]) + bias, 0.0f);
             } else {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const long long qq = q0 + wm * 2 + i;
-                    if (qq < Q) out[(size_t)qq * C2 + col] = fmaxf(cm[i][j] + bias, 0.0f);
+                    if (qq < Q) out[(size_t)qq * ostride + col] = fmaxf(cm[i][j] + bias, 0.0f);
                 }
             }
         }
@@ -224,15 +224,16 @@ TGN_API int tgn_sa_mlp2_direct_supported(int K, int D) { return (D >= 0 && 3 + D
 
 TGN_API int tgn_sa_mlp2_max(int B, int N, int S, int K, int D, int C1p, int C2, const float *A1, const float *xyz,
                             const float *points, const float *new_xyz, const float *W1, const float *b1, const void *idx,
-                            int idx_is_int64, const float *W2f, const float *b2, float *out, tgn_stream_t stream) {
+                            int idx_is_int64, const float *W2f, const float *b2, float *out, int out_stride, tgn_stream_t stream) {
     const long long Q = (long long)B * S;
     if (Q <= 0 || C2 <= 0) return TGN_OK;
     const bool direct = A1 == nullptr;
+    if (out_stride <= 0) out_stride = C2;
     if (!new_xyz || !W1 || !b1 || !idx || !W2f || !b2 || !out || (direct && (!xyz || (D > 0 && !points)))) {
         set_error("tgn_sa_mlp2_max: null pointer");
         return TGN_ERR_INVALID_ARGUMENT;
     }
-    if (K < 1 || K > 64 || C1p < 16 || (C1p & 15) || N < 1 || (direct && !tgn_sa_mlp2_direct_supported(K, D)) ||
+    if (K < 1 || K > 64 || C1p < 16 || (C1p & 15) || N < 1 || out_stride < C2 || (direct && !tgn_sa_mlp2_direct_supported(K, D)) ||
         (((uintptr_t)A1 | (uintptr_t)W2f | (uintptr_t)W1 | (uintptr_t)b1) & 15)) {
         set_error("tgn_sa_mlp2_max: needs 1 <= nsample <= 64, a first-layer width padded to a multiple of 16, 16-byte aligned "
                   "operands, and 3+D <= 16 for the direct form");
@@ -257,7 +258,7 @@ TGN_API int tgn_sa_mlp2_max(int B, int N, int S, int K, int D, int C1p, int C2, 
     if (lds > 48 * 1024)                                                                                                  \
         (void)hipFuncSetAttribute((const void *)sa_mlp2_max_kernel<IT, DIR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   80 * 1024);                                                                             \
-    hipLaunchKernelGGL((sa_mlp2_max_kernel<IT, DIR>), dim3((unsigned)blocks), dim3(256), lds, st, Q, N, S, K, D, C1p, C2, \
+    hipLaunchKernelGGL((sa_mlp2_max_kernel<IT, DIR>), dim3((unsigned)blocks), dim3(256), lds, st, Q, N, S, K, D, C1p, C2, out_stride, \
                        A1, xyz, points, new_xyz, W1, b1, (const IT *)idx, W2f, b2, out, err)
     if (idx_is_int64) {
         if (direct) {

@@ -20,7 +20,17 @@ SHAPE_A = dict(n=24000, npoint=[4096, 1024, 256], radius=[0.05, 0.1, 0.2], nsamp
 # Shape B of SURVEY.md section 8: what the reference instantiates (models/modules/pointnet_pp.py:13-15, scale 4) --
 # multi-scale grouping, two radii per level, grouped layout [features, centred xyz] (pointnet2_utils.py:285)
 SHAPE_B = dict(n=24000, npoint=[1024, 512, 256], radius=[[0.025, 0.05], [0.05, 0.1], [0.1, 0.2]],
-               nsample=[[32, 64], [32, 64], [32, 64]], d=[6, 256, 1024], xyz_first=False)
+               nsample=[[32, 64], [32, 64], [32, 64]], d=[6, 256, 1024], xyz_first=False,
+               mlp=[[128, 128], [256, 512], [784, 1024]])   # fused mode: the reference's own two-layer MLPs, the same in both
+#                branches of a level (pointnet_pp.py:13-15, scale 4); the branches' outputs sit side by side: D of the next level
+
+
+def _branch_mlps(mlp_level, nbranches):
+    """shape['mlp'][level]: one list of widths for every branch, or one list per branch"""
+    if isinstance(mlp_level[0], (list, tuple)):
+        assert len(mlp_level) == nbranches
+        return [list(m) for m in mlp_level]
+    return [list(mlp_level)] * nbranches
 
 
 def _branches(radius, nsample):
@@ -42,7 +52,8 @@ def algorithmic_bytes(n, npoint, nsample, d, fused=False, radius=None, mlp=None,
         ks = [k for _, k in _branches(radius[i] if radius is not None else 0.0, nsample[i])]
         fps = 12 * N + 4 * S
         ball = sum(12 * N + 12 * S + 4 * S * K for K in ks)
-        group = sum(4 * S * K + 4 * N * (3 + D) + 12 * S + (4 * S * mlp[i][-1] if fused else 4 * S * K * (3 + D)) for K in ks)
+        outs = [m[-1] for m in _branch_mlps(mlp[i], len(ks))] if fused else [0] * len(ks)
+        group = sum(4 * S * K + 4 * N * (3 + D) + 12 * S + (4 * S * co if fused else 4 * S * K * (3 + D)) for K, co in zip(ks, outs))
         levels.append(dict(fps=fps, ball=ball, group=group, total=fps + ball + group))
         N = S
     return sum(l["total"] for l in levels), levels
@@ -84,9 +95,9 @@ class HotPath:
     of FPS level 1, and whether the last level's query moves in front of them -- and are measured, not assumed: the first
     run times three launches (plan_schedule).  `plan=dict(spacer_us=.., last_query_early=..)` fixes them instead.
 
-    fused=True: every level is a whole set-abstraction level (shape['mlp']: one- or two-layer shared MLP, eval-mode
-    BatchNorm folded, synthetic seeded weights): FPS -> ball query -> tgn_sa_mlp2_max / tgn_sa_direct_max / transform +
-    gather-max.  No grouped tensor and no (B,S,K,.) layer output is written; level l's (B,S,C_out) output is level l+1's
+    fused=True: every level is a whole set-abstraction level (shape['mlp']: one- or two-layer shared MLP per (radius,
+    nsample) branch, eval-mode BatchNorm folded, synthetic seeded weights): FPS -> ball query -> tgn_sa_mlp2_max /
+    tgn_sa_direct_max / transform + gather-max; the branches of a multi-scale level write side by side into one tensor.  No grouped tensor and no (B,S,K,.) layer output is written; level l's (B,S,C_out) output is level l+1's
     feature input.  These kernels are bound by the fp32 matrix cores and do not fit beside an FPS level-1 workgroup (120 VGPRs,
     62 KiB of LDS): the pipelined fused schedule is FPS + ball queries of step k+1 on stream F over the set-abstraction
     kernels of step k on stream G."""
@@ -156,9 +167,17 @@ class HotPath:
                     grouped=None if self.fused else torch.empty(B, S, kb, 3 + D, **f32), ws_bytes=nbytes,
                     ws=torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None))
             if self.fused:
-                if len(lv["branches"]) != 1:
-                    raise ValueError("HotPath(fused=True) takes single-scale levels (the modules concatenate multi-scale branches)")
-                lv.update(self._fused_operands(li, N, S, lv["branches"][0]["K"], D, shape["mlp"][li], device))
+                mlps = _branch_mlps(shape["mlp"][li], len(lv["branches"]))
+                if len(mlps) > 1 and any(len(m) != 2 for m in mlps):
+                    raise ValueError("HotPath(fused=True): multi-scale levels need two-layer shared MLPs (the chained kernel writes "
+                                     "its columns of the concatenated output)")
+                lv["out"] = torch.empty(B, S, sum(m[-1] for m in mlps), **f32)      # the branches side by side (pointnet2_utils.py:296-298)
+                col = 0
+                for bi, (br, widths) in enumerate(zip(lv["branches"], mlps)):
+                    br.update(self._fused_operands(10 * li + bi, N, S, br["K"], D, widths, device))
+                    br["out"] = lv["out"][:, :, col:col + widths[-1]]
+                    col += widths[-1]
+                lv.update({k: lv["branches"][0][k] for k in ("layers", "C1", "C_out")})
             lv.update({k: lv["branches"][0][k] for k in ("K", "r2", "group_idx", "grouped", "ws", "ws_bytes")})
             levels.append(lv)
             N = S
@@ -199,7 +218,6 @@ class HotPath:
                        direct=bool(self.L.tgn_sa_mlp2_direct_supported(K, D)))
         out["layers"] = layers
         out["A"] = None if out["direct"] else torch.empty(self.B, N, C1p, **f32)
-        out["out"] = torch.empty(self.B, S, widths[-1], **f32)
         return out
 
     def _ball(self, lv, br, cur_xyz, st, prebuilt=False):
@@ -217,22 +235,23 @@ class HotPath:
                                                 ptr(br["grouped"]), 0, -1, self.group_max_blocks, st), "group_points")
 
     def _sa(self, lv, br, cur_xyz, pts, st):
-        """one fused set-abstraction level on stream st"""
+        """one fused (radius, nsample) branch of a set-abstraction level on stream st"""
         L, B = self.L, self.B
-        if not lv["direct"]:
-            check(L.tgn_sa_point_transform(B * lv["N"], lv["D"], lv["C1p"], ptr(cur_xyz), ptr(pts), ptr(lv["Wt"]), ptr(lv["A"]), st),
+        if not br["direct"]:
+            check(L.tgn_sa_point_transform(B * lv["N"], lv["D"], br["C1p"], ptr(cur_xyz), ptr(pts), ptr(br["Wt"]), ptr(br["A"]), st),
                   "sa_point_transform")
-        if lv["nlayers"] == 2:
-            return check(L.tgn_sa_mlp2_max(B, lv["N"], lv["S"], br["K"], lv["D"], lv["C1p"], lv["C_out"], ptr(lv["A"]), ptr(cur_xyz),
-                                           ptr(pts), ptr(lv["new_xyz"]), ptr(lv["Wd"] if lv["direct"] else lv["Wxs"]), ptr(lv["b1"]),
-                                           ptr(br["group_idx"]), self.idx64, ptr(lv["W2f"]), ptr(lv["b2"]), ptr(lv["out"]), st),
+        out = br["out"]
+        if br["nlayers"] == 2:
+            return check(L.tgn_sa_mlp2_max(B, lv["N"], lv["S"], br["K"], lv["D"], br["C1p"], br["C_out"], ptr(br["A"]), ptr(cur_xyz),
+                                           ptr(pts), ptr(lv["new_xyz"]), ptr(br["Wd"] if br["direct"] else br["Wxs"]), ptr(br["b1"]),
+                                           ptr(br["group_idx"]), self.idx64, ptr(br["W2f"]), ptr(br["b2"]), ptr(out), out.stride(1), st),
                          "sa_mlp2_max")
-        if lv["direct"]:
-            return check(L.tgn_sa_direct_max(B, lv["N"], lv["S"], br["K"], lv["D"], lv["C1"], ptr(cur_xyz), ptr(lv["new_xyz"]),
-                                             ptr(pts), ptr(lv["Wd"]), ptr(lv["b1"]), ptr(br["group_idx"]), self.idx64, 1,
-                                             ptr(lv["out"]), st), "sa_direct_max")
-        return check(L.tgn_sa_gather_max(B, lv["N"], lv["S"], br["K"], lv["C1"], ptr(lv["A"]), ptr(lv["new_xyz"]), ptr(lv["Wxs"]),
-                                         ptr(lv["b1"]), ptr(br["group_idx"]), self.idx64, 1, ptr(lv["out"]), st), "sa_gather_max")
+        if br["direct"]:
+            return check(L.tgn_sa_direct_max(B, lv["N"], lv["S"], br["K"], lv["D"], br["C1"], ptr(cur_xyz), ptr(lv["new_xyz"]),
+                                             ptr(pts), ptr(br["Wd"]), ptr(br["b1"]), ptr(br["group_idx"]), self.idx64, 1,
+                                             ptr(out), st), "sa_direct_max")
+        return check(L.tgn_sa_gather_max(B, lv["N"], lv["S"], br["K"], br["C1"], ptr(br["A"]), ptr(lv["new_xyz"]), ptr(br["Wxs"]),
+                                         ptr(br["b1"]), ptr(br["group_idx"]), self.idx64, 1, ptr(out), st), "sa_gather_max")
 
     def _consume(self, i, lv, cur_xyz, feats, levels, st):
         """what follows the ball query of level i: the grouping (materialised) or the fused level"""

@@ -520,12 +520,13 @@ def _pad_cols(t, C1p):
     return out
 
 
-def sa_level_mlp2_max(xyz, new_xyz, points, idx, convs, bns, xyz_first):
+def sa_level_mlp2_max(xyz, new_xyz, points, idx, convs, bns, xyz_first, out=None):
     """A whole set-abstraction level with a TWO-layer shared MLP after sampling and ball query:
         max_k relu(bn2(conv2(relu(bn1(conv1([xyz[idx]-new_xyz, points[idx]]))))))  ->  (B,S,C2)
     (pointnet2_utils.py:162-169 + 229-236, or 281-294 for Msg) in ONE kernel after the per-point transform of the first
     layer (wide inputs) or with the first layer computed from the gathered rows (3+D <= 16): nothing of size S*K is
-    written, no torch convolution runs (tgn_sa_mlp2_max; the second layer on the fp32 matrix cores)."""
+    written, no torch convolution runs (tgn_sa_mlp2_max; the second layer on the fp32 matrix cores).  out: optional (B,S,C2)
+    view into a wider row-major tensor (last stride 1) -- a multi-scale level writes its branches side by side."""
     B, N, _ = xyz.shape
     _, S, K = idx.shape
     D = 0 if points is None else points.shape[2]
@@ -535,7 +536,9 @@ def sa_level_mlp2_max(xyz, new_xyz, points, idx, convs, bns, xyz_first):
     W2f, b2 = fold_second_layer(convs[1], bns[1], C1p)
     C2 = b2.shape[0]
     idx = idx.contiguous()
-    out = torch.empty(B, S, C2, dtype=torch.float32, device=xyz.device)
+    if out is None:
+        out = torch.empty(B, S, C2, dtype=torch.float32, device=xyz.device)
+    assert out.shape == (B, S, C2) and out.stride(2) == 1 and out.stride(0) == S * out.stride(1) and out.dtype == torch.float32
     L = lib()
     b1 = _pad_cols(f["b2"], C1p)
     if L.tgn_sa_mlp2_direct_supported(K, D):
@@ -545,7 +548,7 @@ def sa_level_mlp2_max(xyz, new_xyz, points, idx, convs, bns, xyz_first):
         W1 = _pad_cols(f["Wxs"], C1p)
     _lib.begin_index_check()
     check(L.tgn_sa_mlp2_max(B, N, S, K, D, C1p, C2, ptr(A1), ptr(xyz), ptr(points), ptr(new_xyz), ptr(W1), ptr(b1), ptr(idx),
-                            int(idx.dtype == torch.int64), ptr(W2f), ptr(b2), ptr(out), stream()), "sa_mlp2_max")
+                            int(idx.dtype == torch.int64), ptr(W2f), ptr(b2), ptr(out), out.stride(1), stream()), "sa_mlp2_max")
     _lib.raise_on_index_error("set abstraction (grouping)")
     return out
 
@@ -668,7 +671,20 @@ class PointNetSetAbstractionMsg(nn.Module):
         points_c = None if points is None else _f32c(points)
         fuse = _can_fuse(self, xyz, points)
         new_points_list = []
+        chained = fuse and all(len(c) == 2 and _fused_shape_ok(k, c[0].out_channels) and _mlp2_shape_ok(k, c[0].out_channels)
+                               for c, k in zip(self.conv_blocks, self.nsample_list))
         with _lib.deferred_index_check("set abstraction (grouping)"):      # one flag read for all branches
+            if chained:
+                # every branch is one chained kernel: they write their columns of the concatenated output side by side (:296-298)
+                widths = [c[1].out_channels for c in self.conv_blocks]
+                cat = torch.empty(xyz_c.shape[0], S, sum(widths), dtype=torch.float32, device=xyz_c.device)
+                col = 0
+                for i, radius in enumerate(self.radius_list):
+                    group_idx = query_ball_point(radius, self.nsample_list[i], xyz_c, new_xyz)
+                    sa_level_mlp2_max(xyz_c, new_xyz, points_c, group_idx, self.conv_blocks[i], self.bn_blocks[i], False,
+                                      out=cat[:, :, col:col + widths[i]])
+                    col += widths[i]
+                return new_xyz.permute(0, 2, 1), cat.permute(0, 2, 1)
             for i, radius in enumerate(self.radius_list):
                 K = self.nsample_list[i]
                 group_idx = query_ball_point(radius, K, xyz_c, new_xyz)
