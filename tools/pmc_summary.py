@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise the two PMC passes of tools/gpu_pmc.sh into profiles/r02_pmc_traffic.json (read by bench.py for
+"""Summarise the two PMC passes of tools/gpu_pmc.sh into profiles/<tag>_pmc_traffic.json (read by bench.py for
 roofline.traffic) and copy the raw counter CSVs next to it.
 
     python tools/pmc_summary.py [gpurun_out] [profiles]
@@ -17,6 +17,7 @@ import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
+tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
 LEVELS = 3
 
 
@@ -28,7 +29,7 @@ def read(counter):
             continue
         rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"].split("(")[0], float(row["Counter_Value"]) * 1024.0))
     rows.sort()
-    shutil.copy(path, os.path.join(dst, f"r02_pmc_{counter}_counter_collection.csv"))
+    shutil.copy(path, os.path.join(dst, f"{tag}_pmc_{counter}_counter_collection.csv"))
     return rows
 
 
@@ -43,7 +44,7 @@ def classify(name):
 
 
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python bench.py "
-                 "--steps 2 --warmup 1 --cpu-meshes 0 --no-kernel-timing; 256 scans per launch; bytes = counter x 1024, "
+                 "--pipeline 0 --steps 2 --warmup 1 --cpu-meshes 0 --no-kernel-timing (one stream: the dispatch order identifies the level); 256 scans per launch; bytes = counter x 1024, "
                  "NOT doubled (MI355X_MICROARCH.md notes FETCH_SIZE under-reports wide streaming reads by 2x on gfx950; "
                  "these kernels read 4 B per lane).  Mean over the dispatches of each kernel class and level.",
        "per_kernel": {}}
@@ -62,6 +63,6 @@ for name, pk in out["per_kernel"].items():
     pk["dispatches"] = max(len(pk["fetch_bytes_per_dispatch"]), len(pk["write_bytes_per_dispatch"]))
 for k, v in sorted(acc.items()):
     out[k] = {"fetch": sum(v["fetch"]) / max(len(v["fetch"]), 1), "write": sum(v["write"]) / max(len(v["write"]), 1)}
-json.dump(out, open(os.path.join(dst, "r02_pmc_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 for k in sorted(acc):
     print(f"{k:10s} fetch {out[k]['fetch'] / 1e6:10.1f} MB  write {out[k]['write'] / 1e6:10.1f} MB per launch")

@@ -110,9 +110,10 @@ def _default_fps_batch(xyz_list, npoint):
 def preprocess_scans(pairs, save_path, batch=16, fps_batch=None, workers=None):
     """pairs: [(obj_path, json_path)] -> one "<id>_<jaw>_sampled_points.npy" per scan under save_path, exactly the arrays
     preprocess_data.py writes.  Scans with more than 24 000 vertices are farthest-point-sampled `batch` at a time in one
-    launch; the host side of a batch (OBJ parse + normals in the native library, which releases the GIL, json, scaling) runs
-    on `workers` threads (default: min(batch, host cores / ranks on the node)).
-    Returns {"scans", "sampled", "points_in", "checksum", "seconds_load", "seconds_fps"}."""
+    launch.  Three stages overlap: the host side of batch k+1 (OBJ parse + normals in the native library, which releases the
+    GIL, json, scaling) runs on `workers` threads (default: min(batch, host cores / ranks on the node)) while the GPU samples
+    batch k and a writer thread saves batch k-1.
+    Returns {"scans", "sampled", "points_in", "checksum", "seconds_load" (time the loop WAITED for loads), "seconds_fps"}."""
     from concurrent.futures import ThreadPoolExecutor
     fps_batch = fps_batch or _default_fps_batch
     os.makedirs(save_path, exist_ok=True)
@@ -120,29 +121,37 @@ def preprocess_scans(pairs, save_path, batch=16, fps_batch=None, workers=None):
         local = max(int(os.environ.get("LOCAL_WORLD_SIZE", "1")), 1)
         workers = max(1, min(int(batch), (os.cpu_count() or 1) // local))
     stats = dict(scans=0, sampled=0, points_in=0, checksum=0.0, seconds_load=0.0, seconds_fps=0.0)
-    pool = ThreadPoolExecutor(max_workers=workers) if workers > 1 else None
-    for s in range(0, len(pairs), max(int(batch), 1)):
-        t0 = time.perf_counter()
-        chunk = pairs[s:s + batch]
-        loaded = list(pool.map(lambda oj: load_scan(*oj), chunk)) if pool else [load_scan(o, j) for o, j in chunk]
-        t1 = time.perf_counter()
-        stats["points_in"] += sum(int(lv.shape[0]) for lv, _, _ in loaded)
-        big = [i for i, (lv, _, _) in enumerate(loaded) if lv.shape[0] > N_SAMPLED]
-        if big:
-            idx = fps_batch([loaded[i][0][:, :3] for i in big], N_SAMPLED)
-            for i, ix in zip(big, idx):
-                lv, name, jaw = loaded[i]
-                loaded[i] = (lv[np.asarray(ix)[:N_SAMPLED]], name, jaw)        # gen_utils.resample_pcd: pcd[idx[:n]]
-                stats["checksum"] += float(np.asarray(ix, dtype=np.int64).sum())
-        t2 = time.perf_counter()
-        for lv, name, jaw in loaded:
-            np.save(os.path.join(save_path, sampled_points_name(name, jaw)), lv)
-        stats["scans"] += len(loaded)
-        stats["sampled"] += len(big)
-        stats["seconds_load"] += t1 - t0
-        stats["seconds_fps"] += t2 - t1
-    if pool:
+    step = max(int(batch), 1)
+    chunks = [pairs[s:s + step] for s in range(0, len(pairs), step)]
+    pool = ThreadPoolExecutor(max_workers=workers)
+    writer = ThreadPoolExecutor(max_workers=2)
+    submit = lambda chunk: [pool.submit(load_scan, o, j) for o, j in chunk]
+    pending, writes = (submit(chunks[0]) if chunks else []), []
+    try:
+        for k in range(len(chunks)):
+            t0 = time.perf_counter()
+            loaded = [f.result() for f in pending]
+            pending = submit(chunks[k + 1]) if k + 1 < len(chunks) else []     # parsed while the GPU samples this batch
+            t1 = time.perf_counter()
+            stats["points_in"] += sum(int(lv.shape[0]) for lv, _, _ in loaded)
+            big = [i for i, (lv, _, _) in enumerate(loaded) if lv.shape[0] > N_SAMPLED]
+            if big:
+                idx = fps_batch([loaded[i][0][:, :3] for i in big], N_SAMPLED)
+                for i, ix in zip(big, idx):
+                    lv, name, jaw = loaded[i]
+                    loaded[i] = (lv[np.asarray(ix)[:N_SAMPLED]], name, jaw)        # gen_utils.resample_pcd: pcd[idx[:n]]
+                    stats["checksum"] += float(np.asarray(ix, dtype=np.int64).sum())
+            t2 = time.perf_counter()
+            writes += [writer.submit(np.save, os.path.join(save_path, sampled_points_name(name, jaw)), lv) for lv, name, jaw in loaded]
+            stats["scans"] += len(loaded)
+            stats["sampled"] += len(big)
+            stats["seconds_load"] += t1 - t0
+            stats["seconds_fps"] += t2 - t1
+        for w in writes:
+            w.result()                                                             # (re-raises a failed write)
+    finally:
         pool.shutdown()
+        writer.shutdown()
     return stats
 
 
