@@ -175,3 +175,26 @@ def test_the_phased_plan_follows_its_measurements():
     assert not H.plan_schedule(3.33, 3.2, 0.17, 3)["last_query_early"]         # no room left
     assert not H.plan_schedule(3.33, 0.1, 0.17, 1)["last_query_early"]         # a single level has nothing to move
     assert H.plan_schedule(1.0, 0.5, 0.0, 2)["spacer_us"] == 0 and H.plan_schedule(9.0, 0.5, 2.0, 2)["spacer_us"] == 300
+
+
+def test_cpulist_parsing_and_numa_pinning_are_best_effort():
+    """sharding.parse_cpulist reads sysfs cpulists; pin_to_gpu_numa gives up quietly where there is no GPU / no sysfs entry."""
+    from toothgroupnetwork_amd import sharding as S
+
+    assert S.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert S.parse_cpulist("") == [] and S.parse_cpulist("5") == [5]
+    before = sorted(os.sched_getaffinity(0))
+    assert S.pin_to_gpu_numa(0, sysfs="/nonexistent") is None
+    assert sorted(os.sched_getaffinity(0)) == before
+
+
+def test_fused_plan_shapes_and_algorithmic_bytes():
+    """hotpath: per-branch shared-MLP widths of a level (one list for all branches or one per branch) and the fused byte model"""
+    from toothgroupnetwork_amd import hotpath as H
+
+    assert H._branch_mlps([64, 128], 2) == [[64, 128], [64, 128]]
+    assert H._branch_mlps([[8, 16], [24, 32]], 2) == [[8, 16], [24, 32]]
+    total, per = H.algorithmic_bytes(**H.SHAPE_B, fused=True)
+    # level 3, both branches: indices + inputs + centres + the (S, 1024) output each
+    assert per[2]["group"] == sum(4 * 256 * k + 4 * 512 * 1027 + 12 * 256 + 4 * 256 * 1024 for k in (32, 64))
+    assert total == 15687936

@@ -40,7 +40,7 @@ def main(argv=None, fps_batch=None):
     ap.add_argument("--source_json_data_path", default=None)
     ap.add_argument("--save_data_path", default="data_preprocessed_path")
     ap.add_argument("--synthetic", type=int, default=0, help="generate this many synthetic raw scans instead of reading a dataset")
-    ap.add_argument("--batch", type=int, default=16, help="scans per FPS launch")
+    ap.add_argument("--batch", type=int, default=32, help="scans per FPS launch (a launch costs ~50 ms whatever its size: the sampling chain of one raw scan)")
     ap.add_argument("--backend", default=None)
     args = ap.parse_args(argv)
     rank, local_rank, world, device = sharding.init_from_env(backend=args.backend)
