@@ -172,7 +172,8 @@ def test_the_phased_plan_follows_its_measurements():
     a = H.plan_schedule(3.33, 2.95, 0.17, 3)
     assert a["last_query_early"] and 90 <= a["spacer_us"] <= 110
     assert not H.plan_schedule(0.9, 9.0, 0.17, 3)["last_query_early"]          # Shape B
-    assert not H.plan_schedule(3.33, 3.2, 0.17, 3)["last_query_early"]         # no room left
+    assert not H.plan_schedule(3.33, 3.25, 0.17, 3)["last_query_early"]        # no room left
+    assert H.plan_schedule(3.33, 3.05, 0.15, 3)["last_query_early"]            # what the box measures for Shape A
     assert not H.plan_schedule(3.33, 0.1, 0.17, 1)["last_query_early"]         # a single level has nothing to move
     assert H.plan_schedule(1.0, 0.5, 0.0, 2)["spacer_us"] == 0 and H.plan_schedule(9.0, 0.5, 2.0, 2)["spacer_us"] == 300
 

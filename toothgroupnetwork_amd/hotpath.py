@@ -66,10 +66,11 @@ def plan_schedule(fps_l1_ms, group_ms, setup_ms, n_levels):
                         at that moment stretches it) -- 0.6 x the time of an FPS launch that only sets up;
       last_query_early  whether the LAST level's ball query (a 22-VGPR scan: two of its waves fit per SIMD beside an FPS
                         level-1 workgroup) moves in front of the groupings, beside the next step's FPS level 1.  It pays when
-                        the groupings leave room there (Shape A: 3.0 of 3.3 ms; measured 4.69 -> 4.62 ms per step) and costs
+                        the groupings leave room there (Shape A: 3.05 of 3.33 ms -- with the 0.15 ms the query itself takes there it just fits;
+                        measured 4.69 -> 4.62 ms per step) and costs
                         when they do not (Shape B, whose groupings take ten times the FPS launch: 2 % slower)."""
     spacer_us = int(max(0.0, min(300.0, 600.0 * setup_ms)))
-    return dict(spacer_us=spacer_us, last_query_early=bool(n_levels >= 2 and group_ms + 0.25 <= fps_l1_ms),
+    return dict(spacer_us=spacer_us, last_query_early=bool(n_levels >= 2 and group_ms + 0.15 <= fps_l1_ms),
                 fps_l1_ms=float(fps_l1_ms), group_ms=float(group_ms), setup_ms=float(setup_ms))
 
 
