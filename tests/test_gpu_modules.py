@@ -372,3 +372,32 @@ def test_shape_b_at_full_size_matches_the_oracle(dev, oracle):
                     assert np.array_equal(br["grouped"][b].cpu().numpy(), grouped), (pipeline, b, li, bi, "group")
         del hp
         torch.cuda.empty_cache()
+
+
+def test_feature_propagation_commuted_first_layer_equals_the_plain_form(dev, monkeypatch):
+    """PointNetFeaturePropagation: the first convolution applied to the COARSE features before the interpolation (exact
+    algebra, S instead of N rows) against the reference order interpolate -> concat -> convolve (pointnet2_utils.py:333-350):
+    outputs and parameter / input gradients agree to rounding, in eval and in training mode."""
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    torch.manual_seed(3)
+    B, N, S, D1, D2 = 2, 3000, 400, 6, 96
+    pts = T(synth.scan_batch(B, N, "arch", 12), dev)
+    xyz1 = pts[:, :, :3].permute(0, 2, 1).contiguous()
+    xyz2 = xyz1[:, :, ::7][:, :, :S].contiguous()
+    fp = U.PointNetFeaturePropagation(D1 + D2, [64, 32]).to(dev)
+    for mode in ("eval", "train"):
+        getattr(fp, mode)()
+        res = {}
+        for commute in (True, False):
+            monkeypatch.setattr(U, "COMMUTE_FP", commute)
+            p1 = torch.randn(B, D1, N, device=dev, generator=torch.Generator(device=dev).manual_seed(5)).requires_grad_(True)
+            p2 = torch.randn(B, D2, S, device=dev, generator=torch.Generator(device=dev).manual_seed(6)).requires_grad_(True)
+            fp.zero_grad()
+            fp.mlp_bns[0].running_mean.zero_(); fp.mlp_bns[0].running_var.fill_(1.0)
+            y = fp(xyz1, xyz2, p1, p2)
+            (y * torch.linspace(0.5, 1.5, y.shape[1], device=dev)[None, :, None]).sum().backward()
+            res[commute] = [y.detach(), p1.grad, p2.grad, fp.mlp_convs[0].weight.grad.clone(), fp.mlp_convs[1].weight.grad.clone()]
+        ya, yb = res[True][0], res[False][0]
+        assert float(((ya - yb).abs() / (1.0 + yb.abs())).max()) <= 2e-5, mode                  # outputs: elementwise
+        for a, b in zip(res[True][1:], res[False][1:]):                                          # gradients (BatchNorm's backward
+            assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()), mode              # subtracts batch means: conditioning)

@@ -395,6 +395,7 @@ def three_interpolate(points2, dist, idx):
 # fused set abstraction (eval mode): the first shared-MLP layer without the grouped (B,S,K,3+D) tensor
 # ---------------------------------------------------------------------------------------------
 FUSED_SA = os.environ.get("TGN_FUSED_SA", "1") != "0"
+COMMUTE_FP = os.environ.get("TGN_COMMUTE_FP", "1") != "0"   # feature propagation: first convolution on the coarse points (below)
 
 
 def _can_fuse(module, *tensors):
@@ -720,6 +721,27 @@ class PointNetFeaturePropagation(nn.Module):
         B, N, C = xyz1.shape
         _, S, _ = xyz2.shape
 
+        if (COMMUTE_FP and S > 1 and S < N and len(self.mlp_convs) > 0 and not (xyz1.requires_grad or xyz2.requires_grad)
+                and points2.dtype == torch.float32):
+            # The first 1x1 convolution commutes with the interpolation (a weighted sum whose weights do not depend on the
+            # features): W * [p1, sum_i w_i f2[idx_i]] + b = W1 * p1 + sum_i w_i (W2 * f2)[idx_i] + b.  The coarse features are
+            # transformed ONCE per coarse point (S rows instead of N: fp1 of the reference net 1024 instead of 24 000 rows of a
+            # 512-wide contraction), and neither the interpolated (B,N,D2) tensor nor the concatenated (B,D1+D2,N) one exists.
+            # Exact algebra; fp32 rounding differs in summation order only.  Differentiable like the plain form.
+            conv0 = self.mlp_convs[0]
+            W = conv0.weight.squeeze(-1)                                        # (C1, D1 + D2), columns [points1, points2] (:345)
+            D2 = points2.shape[2]
+            D1 = W.shape[1] - D2
+            dist, idx = three_nn(xyz1, xyz2)
+            y = three_interpolate(F.linear(points2, W[:, D1:]), dist, idx)      # (B, N, C1)
+            if points1 is not None:
+                y = y + F.linear(points1.permute(0, 2, 1), W[:, :D1])
+            if conv0.bias is not None:
+                y = y + conv0.bias
+            new_points = F.relu(self.mlp_bns[0](y.permute(0, 2, 1)))
+            for i in range(1, len(self.mlp_convs)):
+                new_points = F.relu(self.mlp_bns[i](self.mlp_convs[i](new_points)))
+            return new_points
         if S == 1:
             interpolated_points = points2.repeat(1, N, 1)
         elif xyz1.requires_grad or xyz2.requires_grad:
