@@ -180,9 +180,13 @@ class PointTransformerLayer(nn.Module):
     def forward(self, pxo):
         p, x, o = pxo  # (n, 3), (n, c), (b)
         x_q, x_k, x_v = _lin(self.linear_q, x), _lin(self.linear_k, x), _lin(self.linear_v, x)
-        idx, _ = pointops.knnquery(self.nsample, p, p, o, o)           # one search for both groupings of blocks.py:34-35
+        idx = pointops.knn_indices(self.nsample, p, p, o, o)            # one search for both groupings of blocks.py:34-35 (read-only)
         g = self.out_planes // self.share_planes
-        if (_frozen(self, p, x) and self.nsample <= 64 and self.out_planes % 4 == 0 and g in (4, 8, 16, 32, 64)
+        # the fused kernel gives a point to a wave, which walks the layer's c x c/8 weight matrix on its own: right for the wide
+        # stages (24 000 points x 32 channels: 0.09 ms), wrong for the deep ones -- 93 points x 512 channels keep 93 lone waves busy
+        # for 0.94 ms where the composition below needs 0.15 (profiled: 4.3 of the forward's 13 ms went there)
+        deep = self.out_planes * g >= 8192 and p.shape[0] < 4096
+        if (_frozen(self, p, x) and not deep and self.nsample <= 64 and self.out_planes % 4 == 0 and g in (4, 8, 16, 32, 64)
                 and x_q.dtype == torch.float32):
             return pt_attention(p.contiguous(), x_q.contiguous(), x_k.contiguous(), x_v.contiguous(), idx, fold_pt_layer(self))
         # training: the reference's composition with the softmax + weighted sum as one differentiable kernel pair.
@@ -238,7 +242,7 @@ class TransitionDown(nn.Module):
         C1 = self.linear.out_features
         if _frozen(self, p, x) and self.nsample <= 64 and C1 % 4 == 0 and x.dtype == torch.float32:
             # the whole down-sampling step fused: (m, nsample, 3+c) is never built (blocks.py:71-73)
-            kidx, _ = pointops.knnquery(self.nsample, p, n_p, o, n_o)
+            kidx = pointops.knn_indices(self.nsample, p, n_p, o, n_o)
             s, t = _bn_scale_shift(self.bn)
             W = self.linear.weight.detach().float()                        # (C1, 3+c), columns [xyz, features] (use_xyz=True)
             Wt = torch.cat([W[:, 3:], W[:, :3]], 1).mul(s[:, None]).t().contiguous()   # rows [features..., x, y, z]

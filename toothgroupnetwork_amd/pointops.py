@@ -223,6 +223,13 @@ def knn_cache_clear():
     _KNN_CACHE.clear()
 
 
+def knn_indices(nsample, xyz, new_xyz, offset, new_offset):
+    """The neighbour rows of knnquery -- (m, nsample) int32 -- for callers inside this package that only READ them: the memo's own
+    tensor (no clone) and no distance output (no sqrt pass); 84 of each per Point-Transformer forward otherwise."""
+    require_cuda(xyz, offset, new_offset)
+    return _knn_cached(nsample, xyz, new_xyz, offset, new_offset)[0]
+
+
 class KNNQuery(Function):
     @staticmethod
     def forward(ctx, nsample, xyz, new_xyz, offset, new_offset):
