@@ -307,6 +307,16 @@ int tgn_sa_mlp2_direct_supported(int K, int D);
 int tgn_sa_mlp2_max(int B, int N, int S, int K, int D, int C1p, int C2, const float *A1, const float *xyz,
                     const float *points, const float *new_xyz, const float *W1, const float *b1, const void *idx,
                     int idx_is_int64, const float *W2f, const float *b2, float *out, int out_stride, tgn_stream_t stream);
+/*
+ * Weight gradient of a tall, narrow linear layer (training path of the Point-Transformer mirrors; blocks.py:19-30 declares the
+ * layers): the rows are cut into tgn_linear_wgrad_slices(rows) slices, slice s contributes
+ *   part[s][o][i] = sum_{r in slice} gy[r][o] * x[r][i]      (slices, cout, cin)
+ *   bpart[s][o]   = sum_{r in slice} gy[r][o]                (slices, cout), optional (NULL to skip)
+ * on the fp32 matrix cores straight from global memory; the caller sums over s.  x (rows, cin), gy (rows, cout), row-major fp32.
+ */
+long long tgn_linear_wgrad_slices(long long rows);
+int tgn_linear_wgrad_partials(long long rows, int cin, int cout, const float *x, const float *gy, float *part, float *bpart,
+                              tgn_stream_t stream);
 /* index_points (pointnet2_utils.py:44-61): out[b,j,:] = points[b, idx[b,j], :], idx flattened to (B,M). */
 int tgn_gather_points(int B, int N, int M, int C, const float *points, const void *idx, int idx_is_int64, float *out,
                       tgn_stream_t stream);

@@ -217,3 +217,21 @@ def test_transition_down_survives_graph_replays_with_eager_work_in_between(dev):
             assert torch.equal(out[0], ref[0]) and torch.equal(out[2], ref[2])      # eager kernels + temporaries on the small outputs
             assert float(out[0].double().sum()) == float(ref[0].double().sum())
             close(out[1].cpu().numpy(), ref[1].cpu().numpy(), "replayed features", tol=1e-6)
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(24000, 32, 32), (864000, 32, 4), (6000, 64, 64), (9001, 256, 32), (4097, 3, 3), (50000, 3, 64),
+                                            (12345, 35, 64), (70001, 128, 100)])
+def test_tall_narrow_weight_gradient_kernel(dev, rows, cin, cout):
+    """tgn_linear_wgrad_partials (row slices contracted on the fp32 matrix cores straight from global memory) through
+    _LinearSplitK: dW, db and dx against torch's own linear backward in float64."""
+    from toothgroupnetwork_amd import point_transformer as PT
+    g = torch.Generator(device="cpu").manual_seed(rows + cin)
+    x = torch.randn(rows, cin, generator=g).to(dev).requires_grad_(True)
+    lin = torch.nn.Linear(cin, cout).to(dev)
+    gy = torch.randn(rows, cout, generator=g).to(dev)
+    y = PT._LinearSplitK.apply(x, lin.weight, lin.bias)
+    gx, gw, gb = torch.autograd.grad(y, (x, lin.weight, lin.bias), gy)
+    x64, w64, gy64 = x.detach().double(), lin.weight.detach().double(), gy.double()
+    for got, want, what in ((gw, gy64.t() @ x64, "dW"), (gb, gy64.sum(0), "db"), (gx, gy64 @ w64, "dx")):
+        scale = float(want.abs().max())
+        assert float((got.double() - want).abs().max()) <= 2e-5 * max(scale, 1.0) * max(1.0, (rows / 24000) ** 0.5), what

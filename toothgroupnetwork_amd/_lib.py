@@ -79,6 +79,8 @@ SIGNATURES = {
     "tgn_sa_gather_act": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "tgn_sa_direct_supported": (c_int, [c_int, c_int, c_int]),
     "tgn_sa_mlp2_direct_supported": (c_int, [c_int, c_int]),
+    "tgn_linear_wgrad_slices": (ctypes.c_longlong, [ctypes.c_longlong]),
+    "tgn_linear_wgrad_partials": (c_int, [ctypes.c_longlong, c_int, c_int, _P, _P, _P, _P, _P]),
     "tgn_sa_mlp2_max": (c_int, [c_int] * 7 + [_P] * 7 + [c_int, _P, _P, _P, c_int, _P]),
     "tgn_sa_direct_max": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "tgn_gather_points": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P]),

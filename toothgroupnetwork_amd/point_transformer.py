@@ -92,14 +92,28 @@ class _LinearSplitK(Function):
             gx = (gy2 @ weight.to(gy2.dtype)).reshape(x.shape).to(x.dtype)
         if ctx.needs_input_grad[1]:
             rows = gy2.shape[0]
-            slices = max(1, min(512, rows // 1024))
-            per = rows // slices
-            main = slices * per
-            gw = torch.bmm(gy2[:main].reshape(slices, per, -1).transpose(1, 2), x2[:main].reshape(slices, per, -1)).sum(0, dtype=torch.float32)
-            if main < rows:
-                gw = gw + (gy2[main:].t() @ x2[main:]).float()
-            gw = gw.to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if gy2.dtype == torch.float32 and gy2.is_cuda:
+                # one pass over gy and x on the fp32 matrix cores, a (cout, cin) partial per row slice (csrc/linear.hip); the bias
+                # gradient comes out of the same pass
+                gyc, xc = gy2.contiguous(), x2.contiguous()
+                slices = int(lib().tgn_linear_wgrad_slices(rows))
+                part = torch.empty(slices, gyc.shape[1], xc.shape[1], dtype=torch.float32, device=gy2.device)
+                want_b = ctx.has_bias and ctx.needs_input_grad[2]
+                bpart = torch.empty(slices, gyc.shape[1], dtype=torch.float32, device=gy2.device) if want_b else None
+                check(lib().tgn_linear_wgrad_partials(rows, xc.shape[1], gyc.shape[1], ptr(xc), ptr(gyc), ptr(part), ptr(bpart), stream()),
+                      "linear_wgrad")
+                gw = part.sum(0).to(weight.dtype)
+                if want_b:
+                    gb = bpart.sum(0).to(weight.dtype)
+            else:                                                  # bf16 under autocast: sliced batch GEMM
+                slices = max(1, min(512, rows // 1024))
+                per = rows // slices
+                main = slices * per
+                gw = torch.bmm(gy2[:main].reshape(slices, per, -1).transpose(1, 2), x2[:main].reshape(slices, per, -1)).sum(0, dtype=torch.float32)
+                if main < rows:
+                    gw = gw + (gy2[main:].t() @ x2[main:]).float()
+                gw = gw.to(weight.dtype)
+        if gb is None and ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy2.sum(0, dtype=torch.float32).to(weight.dtype)
         return gx, gw, gb
 
