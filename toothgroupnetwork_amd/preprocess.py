@@ -112,20 +112,32 @@ def preprocess_scans(pairs, save_path, batch=16, fps_batch=None, workers=None):
     preprocess_data.py writes.  Scans with more than 24 000 vertices are farthest-point-sampled `batch` at a time in one
     launch.  Three stages overlap: the host side of batch k+1 (OBJ parse + normals in the native library, which releases the
     GIL, json, scaling) runs on `workers` threads (default: min(batch, host cores / ranks on the node)) while the GPU samples
-    batch k and a writer thread saves batch k-1.
+    batch k and writer threads select and save batch k-1 (the main thread only packs, launches and copies the indices back).
     Returns {"scans", "sampled", "points_in", "checksum", "seconds_load" (time the loop WAITED for loads), "seconds_fps"}."""
     from concurrent.futures import ThreadPoolExecutor
     fps_batch = fps_batch or _default_fps_batch
     os.makedirs(save_path, exist_ok=True)
     if workers is None:
         local = max(int(os.environ.get("LOCAL_WORLD_SIZE", "1")), 1)
-        workers = max(1, min(int(batch), (os.cpu_count() or 1) // local))
+        workers = int(os.environ.get("TGN_PREPROCESS_WORKERS", "0")) or max(1, min(int(batch), (os.cpu_count() or 1) // local))
     stats = dict(scans=0, sampled=0, points_in=0, checksum=0.0, seconds_load=0.0, seconds_fps=0.0)
     step = max(int(batch), 1)
     chunks = [pairs[s:s + step] for s in range(0, len(pairs), step)]
     pool = ThreadPoolExecutor(max_workers=workers)
-    writer = ThreadPoolExecutor(max_workers=2)
-    submit = lambda chunk: [pool.submit(load_scan, o, j) for o, j in chunk]
+    writer = ThreadPoolExecutor(max_workers=4)
+
+    def load(obj_path, json_path):
+        # (worker thread) the fp32 copy of the coordinates the sampler wants is made here too: numpy releases the GIL for it
+        lv, name, jaw = load_scan(obj_path, json_path)
+        return lv, name, jaw, (np.ascontiguousarray(lv[:, :3], dtype=np.float32) if lv.shape[0] > N_SAMPLED else None)
+
+    def select_and_save(lv, ix, name, jaw):
+        # (writer thread) gen_utils.resample_pcd: pcd[idx[:n]], then np.save (preprocess_data.py:56-58)
+        if ix is not None:
+            lv = lv[np.asarray(ix)[:N_SAMPLED]]
+        np.save(os.path.join(save_path, sampled_points_name(name, jaw)), lv)
+
+    submit = lambda chunk: [pool.submit(load, o, j) for o, j in chunk]
     pending, writes = (submit(chunks[0]) if chunks else []), []
     try:
         for k in range(len(chunks)):
@@ -133,16 +145,14 @@ def preprocess_scans(pairs, save_path, batch=16, fps_batch=None, workers=None):
             loaded = [f.result() for f in pending]
             pending = submit(chunks[k + 1]) if k + 1 < len(chunks) else []     # parsed while the GPU samples this batch
             t1 = time.perf_counter()
-            stats["points_in"] += sum(int(lv.shape[0]) for lv, _, _ in loaded)
-            big = [i for i, (lv, _, _) in enumerate(loaded) if lv.shape[0] > N_SAMPLED]
-            if big:
-                idx = fps_batch([loaded[i][0][:, :3] for i in big], N_SAMPLED)
-                for i, ix in zip(big, idx):
-                    lv, name, jaw = loaded[i]
-                    loaded[i] = (lv[np.asarray(ix)[:N_SAMPLED]], name, jaw)        # gen_utils.resample_pcd: pcd[idx[:n]]
-                    stats["checksum"] += float(np.asarray(ix, dtype=np.int64).sum())
+            stats["points_in"] += sum(int(item[0].shape[0]) for item in loaded)
+            big = [i for i, item in enumerate(loaded) if item[3] is not None]
+            idx = fps_batch([loaded[i][3] for i in big], N_SAMPLED) if big else []
+            picked = dict(zip(big, idx))
+            for ix in idx:
+                stats["checksum"] += float(np.asarray(ix, dtype=np.int64).sum())
             t2 = time.perf_counter()
-            writes += [writer.submit(np.save, os.path.join(save_path, sampled_points_name(name, jaw)), lv) for lv, name, jaw in loaded]
+            writes += [writer.submit(select_and_save, lv, picked.get(i), name, jaw) for i, (lv, name, jaw, _) in enumerate(loaded)]
             stats["scans"] += len(loaded)
             stats["sampled"] += len(big)
             stats["seconds_load"] += t1 - t0
