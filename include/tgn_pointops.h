@@ -360,6 +360,21 @@ int tgn_obj_read(const char *path, double *vertices, long long *faces, long long
  * cross products, normalised, (0,0,1) where undefined.  triangles are ZERO-based.  Parity unpinned (no open3d here).
  */
 int tgn_vertex_normals(const double *vertices, long long nv, const long long *triangles, long long nf, double *normals);
+/*
+ * One scan of the preprocess loop in one call that never holds the interpreter lock (preprocess_data.py:37-52): reads the
+ * ground-truth json ({"jaw": "upper"|"lower", "labels": [FDI numbers]}), remaps the labels to 0..16 (:39-44), reads the OBJ
+ * with tgn_obj_read's semantics, computes the vertex normals, centres the vertices and maps [y_min, y_max] to [-1, 1]
+ * (:48-50, with numpy's summation order), and holds the (n, 7) float64 rows [x y z nx ny nz label] behind *handle.
+ * jaw receives the json's "jaw" string (NUL-terminated, at most jaw_cap - 1 bytes).
+ * TGN_ERR_UNSUPPORTED: the json is not the plain shape above (floats among the labels, escapes, missing keys) -- the caller
+ * falls back to a general json parser; TGN_ERR_INVALID_ARGUMENT: what the reference raises on (unreadable file, bad OBJ
+ * token, label count != vertex count).
+ */
+int tgn_scan_open(const char *obj_path, const char *json_path, double y_min, double y_max, void **handle,
+                  long long *n_vertices, char *jaw, int jaw_cap);
+/* Copies the rows to labeled (n,7) double and, when xyz32 is not NULL, the float32 coordinates to xyz32 (n,3); frees the
+ * handle (both pointers NULL: only frees). */
+int tgn_scan_take(void *handle, double *labeled, float *xyz32);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,17 @@ def test_obj_reader_quirks_and_errors(tmp_path):
             preprocess.read_obj(str(p))
     with pytest.raises(ValueError):
         preprocess.read_obj(str(tmp_path / "missing.obj"))
+    # float() spellings: both parsers behind parse_double (from_chars for plain decimals, strtod for the rest)
+    toks = ["+1.5", "-.5e+2", "5.", "1e400", "-1e400", "1e-400", "inf", "-Infinity", "nan", "0.1", "123456789.123456789e-5",
+            "2.2250738585072014e-308", "4.9e-324", "17976931348623157e292"]
+    p.write_text("".join(f"v {t} 0 1\n" for t in toks))
+    v, _ = preprocess.read_obj(str(p))
+    want = np.array([float(t) for t in toks])
+    assert np.array_equal(v[:, 0].view(np.uint64)[~np.isnan(want)], want.view(np.uint64)[~np.isnan(want)]) and np.isnan(v[8, 0])
+    for bad in ("0x10", "+-1", "1e", "--1", "1.2.3", "e5", "+"):
+        p.write_text(f"v {bad} 0 1\n")
+        with pytest.raises(ValueError):
+            preprocess.read_obj(str(p))
     # a vertex no triangle touches keeps its zero sum (Eigen's normalize() leaves a zero vector alone; open3d's (0,0,1)
     # is for NaN only); a triangle index out of range is an error
     n = preprocess.vertex_normals(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [5, 5, 5]], float), np.array([[0, 1, 2]]))
@@ -62,6 +73,58 @@ def test_obj_reader_quirks_and_errors(tmp_path):
     lab = preprocess.remap_fdi_labels([0, 11, 18, 21, 28, 31, 38, 41, 48], "upper").reshape(-1)
     assert lab.tolist()[:5] == [0, 1, 8, 9, 16]
     assert preprocess.remap_fdi_labels([0, 31, 38, 41, 48], "lower").reshape(-1).tolist() == [0, 1, 8, 9, 16]
+
+
+def test_native_scan_loader_equals_the_python_path(tmp_path):
+    """tgn_scan_open / tgn_scan_take (the GIL-free load of the sharded runner) against load_scan, which follows
+    preprocess_data.py:37-52 step by step in numpy: identical bits, on json files in several legal layouts; json shapes the
+    strict reader does not take are handed back (None) so that Python's json decides."""
+    from toothgroupnetwork_amd import preprocess, synth
+    obj = tmp_path / "AB12_lower.obj"
+    obj.write_text(synth.obj_text(60, 45, seed=5, style="slashes"))
+    n = 60 * 45
+    rng = np.random.default_rng(3)
+    for jaw in ("lower", "upper"):
+        labels = synth.fdi_labels(n, jaw, seed=9)
+        labels[:12] = [0, 5, 9, 10, 19, 20, 29, 30, 39, 48, 55, -3]            # values outside the jaw's own range too
+        texts = [json.dumps({"id_patient": "AB12", "jaw": jaw, "labels": labels, "instances": rng.integers(0, 9, n).tolist()}),
+                 json.dumps({"labels": labels, "nested": {"labels": [1.5, "x", {"jaw": "no"}], "s": "a\\\"]}"}, "f": -1.5e-3,
+                             "t": True, "z": None, "jaw": jaw}, indent=2),
+                 '{"jaw":"%s","labels":[%s]}' % (jaw, ",".join(map(str, labels))),
+                 '\n {\t"labels" : [ %s ] ,\r\n "jaw"\n:\n"%s" , "labels2": [] }\n' % (" , ".join(map(str, labels)), jaw)]
+        for text in texts:
+            jp = tmp_path / "gt.json"
+            jp.write_text(text)
+            want, name, wjaw = preprocess.load_scan(str(obj), str(jp))
+            got = preprocess.load_scan_native(str(obj), str(jp), with_xyz32=True)
+            assert got is not None, text[:60]
+            assert got[1] == name == "AB12_lower" and got[2] == wjaw == jaw and got[3] is None
+            assert got[0].dtype == want.dtype and np.array_equal(got[0].view(np.uint64), want.view(np.uint64))
+    # more than N_SAMPLED vertices: the float32 copy of the coordinates comes along
+    obj.write_text(synth.obj_text(250, 100, seed=6))
+    labels = synth.fdi_labels(25000, "upper", seed=1)
+    (tmp_path / "gt.json").write_text(json.dumps({"jaw": "upper", "labels": labels}))
+    want = preprocess.load_scan(str(obj), str(tmp_path / "gt.json"))[0]
+    got = preprocess.load_scan_native(str(obj), str(tmp_path / "gt.json"), with_xyz32=True)
+    assert np.array_equal(got[0].view(np.uint64), want.view(np.uint64))
+    assert got[3].dtype == np.float32 and np.array_equal(got[3], want[:, :3].astype(np.float32))
+    assert preprocess.load_scan_native(str(obj), str(tmp_path / "gt.json"))[3] is None
+    # not the plain shape -> None (Python's json module decides what happens); the reference's errors stay errors
+    jp = tmp_path / "odd.json"
+    for text in ('{"jaw": "upper", "labels": [11.0, 12]}', '{"jaw": "upper"}', '{"labels": [1]}', '{"jaw": "up\\u0070er", "labels": [1]}',
+                 '{"jaw": "upper", "labels": [1] ', '[1, 2]', '{"jaw": "upper", "labels": [01]}', '{"jaw": "upper", "labels": [1], "x": tru}',
+                 '{"jaw": "upper", "labels": [1,]}', '{"jaw": "upper", "labels": [123456789012345678901]}', ''):
+        jp.write_text(text)
+        assert preprocess.load_scan_native(str(obj), str(jp)) is None, text
+    jp.write_text(json.dumps({"jaw": "upper", "labels": labels[:-1]}))
+    with pytest.raises(ValueError):
+        preprocess.load_scan_native(str(obj), str(jp))                           # np.concatenate raises in the reference
+    with pytest.raises(ValueError):
+        preprocess.load_scan(str(obj), str(jp))
+    with pytest.raises(ValueError):
+        preprocess.load_scan_native(str(tmp_path / "missing.obj"), str(tmp_path / "gt.json"))
+    with pytest.raises(ValueError):
+        preprocess.load_scan_native(str(obj), str(tmp_path / "missing.json"))
 
 
 def _oracle_fps_batch(xyz_list, npoint):

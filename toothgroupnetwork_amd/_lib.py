@@ -94,7 +94,11 @@ SIGNATURES = {
     "tgn_obj_count": (c_int, [ctypes.c_char_p, _P, _P]),
     "tgn_obj_read": (c_int, [ctypes.c_char_p, _P, _P, ctypes.c_longlong, ctypes.c_longlong, _P, _P]),
     "tgn_vertex_normals": (c_int, [_P, ctypes.c_longlong, _P, ctypes.c_longlong, _P]),
+    "tgn_scan_open": (c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_double, ctypes.c_double, _P, _P, ctypes.c_char_p, c_int]),
+    "tgn_scan_take": (c_int, [_P, _P, _P]),
 }
+
+ERR_INVALID_ARGUMENT, ERR_LAUNCH, ERR_UNSUPPORTED = 1, 2, 3     # TGN_ERR_* of include/tgn_pointops.h
 
 FPS_FMA = 1
 FPS_LOCAL_INDEX = 2

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <charconv>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,30 @@ static size_t split_ws(const char *s, const char *e, Tok *out, size_t cap) {
 
 static bool parse_double(const Tok &t, double *v) {
     if (t.n == 0 || t.n > 400) return false;
+    // plain decimal tokens (every coordinate of a real scan): std::from_chars is correctly rounded like float() / strtod and
+    // does not go through the locale.  Anything else ("inf", "nan", ...) takes the strtod path below.
+    {
+        const char *b = t.p, *e = t.p + t.n;
+        bool plain = true;
+        for (const char *c = b; c < e; ++c)
+            if (!((*c >= '0' && *c <= '9') || *c == '.' || *c == '-' || *c == '+' || *c == 'e' || *c == 'E')) plain = false;
+        if (plain) {
+            if (*b == '+') {
+                ++b;
+                if (b < e && (*b == '-' || *b == '+')) return false;
+            }
+            double r;
+            const auto res = std::from_chars(b, e, r);
+            if (res.ec == std::errc() && res.ptr == e) {
+                *v = r;
+                return true;
+            }
+            if (!(res.ec == std::errc::result_out_of_range && res.ptr == e)) return false;
+            // overflow / underflow: strtod's inf / 0 below
+        }
+        for (const char *c = b; c < e; ++c)
+            if (*c == 'x' || *c == 'X') return false;                                   // float() takes no hex literals
+    }
     char buf[408];
     memcpy(buf, t.p, t.n);
     buf[t.n] = 0;
@@ -102,7 +127,8 @@ static int read_file(const char *path, std::string &data) {
 
 // One pass over the text; vertices / faces may be null (counting pass).
 static int parse_obj(const std::string &data, double *vertices, long long *faces, long long cap_v, long long cap_f,
-                     long long *nv_out, long long *nf_out) {
+                     long long *nv_out, long long *nf_out, std::vector<double> *vsink = nullptr,
+                     std::vector<long long> *fsink = nullptr) {
     const char *s = data.data(), *end = s + data.size();
     long long nv = 0, nf = 0, line_no = 0;
     while (s < end) {
@@ -124,6 +150,7 @@ static int parse_obj(const std::string &data, double *vertices, long long *faces
                     set_error("tgn_obj_read: line %lld: could not convert a coordinate to float", line_no);
                     return TGN_ERR_INVALID_ARGUMENT;
                 }
+            if (vsink) vsink->insert(vsink->end(), c, c + 3);
             if (vertices) {
                 if (nv >= cap_v) {
                     set_error("tgn_obj_read: more vertices than the buffer holds");
@@ -146,6 +173,7 @@ static int parse_obj(const std::string &data, double *vertices, long long *faces
                     set_error("tgn_obj_read: line %lld: invalid literal for int() in a face", line_no);
                     return TGN_ERR_INVALID_ARGUMENT;
                 }
+            if (fsink) fsink->insert(fsink->end(), idx, idx + 3);
             if (faces) {
                 if (nf >= cap_f) {
                     set_error("tgn_obj_read: more faces than the buffer holds");
@@ -163,6 +191,181 @@ static int parse_obj(const std::string &data, double *vertices, long long *faces
     *nf_out = nf;
     return TGN_OK;
 }
+
+
+// ---- the ground-truth json of a scan (preprocess_data.py:37-38): {"jaw": "upper" | "lower", "labels": [FDI numbers], ...}.
+// A strict reader for exactly that: a top-level object whose "labels" member is an array of plain integers and whose "jaw"
+// member is a string without escapes.  Anything else is TGN_ERR_UNSUPPORTED and the caller goes through Python's json.
+struct JsonCur {
+    const char *s, *e;
+    void ws() {
+        while (s < e && (*s == ' ' || *s == '\t' || *s == '\n' || *s == '\r')) ++s;
+    }
+    bool eat(char c) {
+        ws();
+        if (s < e && *s == c) {
+            ++s;
+            return true;
+        }
+        return false;
+    }
+    // s at the opening quote; leaves s behind the closing one.  plain: no backslash inside.
+    bool string(const char **b, size_t *n, bool *plain) {
+        ws();
+        if (s >= e || *s != '"') return false;
+        ++s;
+        *b = s;
+        *plain = true;
+        while (s < e && *s != '"') {
+            if (*s == '\\') {
+                *plain = false;
+                ++s;
+            }
+            ++s;
+        }
+        if (s >= e) return false;
+        *n = (size_t)(s - *b);
+        ++s;
+        return true;
+    }
+    // skips any value (nesting by bracket counting, strings honoured)
+    bool skip_value() {
+        ws();
+        if (s >= e) return false;
+        if (*s == '"') {
+            const char *b;
+            size_t n;
+            bool plain;
+            return string(&b, &n, &plain);
+        }
+        if (*s == '{' || *s == '[') {
+            long depth = 0;
+            while (s < e) {
+                if (*s == '"') {
+                    const char *b;
+                    size_t n;
+                    bool plain;
+                    if (!string(&b, &n, &plain)) return false;
+                    continue;
+                }
+                if (*s == '{' || *s == '[') ++depth;
+                if (*s == '}' || *s == ']') {
+                    --depth;
+                    if (depth == 0) {
+                        ++s;
+                        return true;
+                    }
+                }
+                ++s;
+            }
+            return false;
+        }
+        const char *b = s;
+        while (s < e && *s != ',' && *s != '}' && *s != ']' && *s != ' ' && *s != '\t' && *s != '\n' && *s != '\r') ++s;
+        return scalar_ok(b, (size_t)(s - b));
+    }
+    // true / false / null / a JSON number (plus the NaN / Infinity spellings Python's json accepts)
+    static bool scalar_ok(const char *b, size_t n) {
+        auto is = [&](const char *w) { return strlen(w) == n && !memcmp(b, w, n); };
+        if (is("true") || is("false") || is("null") || is("NaN") || is("Infinity") || is("-Infinity")) return true;
+        size_t i = 0;
+        auto digits = [&]() {
+            const size_t i0 = i;
+            while (i < n && b[i] >= '0' && b[i] <= '9') ++i;
+            return i - i0;
+        };
+        if (i < n && b[i] == '-') ++i;
+        const size_t int0 = i, nd = digits();
+        if (nd == 0 || (nd > 1 && b[int0] == '0')) return false;
+        if (i < n && b[i] == '.') {
+            ++i;
+            if (digits() == 0) return false;
+        }
+        if (i < n && (b[i] == 'e' || b[i] == 'E')) {
+            ++i;
+            if (i < n && (b[i] == '+' || b[i] == '-')) ++i;
+            if (digits() == 0) return false;
+        }
+        return i == n;
+    }
+    bool int_array(std::vector<long long> &out) {
+        out.clear();
+        if (!eat('[')) return false;
+        if (eat(']')) return true;
+        for (;;) {
+            ws();
+            bool neg = false;
+            if (s < e && *s == '-') {
+                neg = true;
+                ++s;
+            }
+            const char *d = s;
+            long long v = 0;
+            while (s < e && *s >= '0' && *s <= '9') {
+                if (s - d >= 18) return false;
+                v = v * 10 + (*s - '0');
+                ++s;
+            }
+            if (s == d || (s - d > 1 && *d == '0')) return false;           // no digits / leading zero: not JSON
+            if (s < e && (*s == '.' || *s == 'e' || *s == 'E')) return false;  // a float: Python's path decides
+            out.push_back(neg ? -v : v);
+            if (eat(',')) continue;
+            return eat(']');
+        }
+    }
+};
+
+static int parse_scan_json(const std::string &data, std::vector<long long> &labels, std::string &jaw) {
+    JsonCur c{data.data(), data.data() + data.size()};
+    bool have_labels = false, have_jaw = false;
+    if (!c.eat('{')) return TGN_ERR_UNSUPPORTED;
+    if (!c.eat('}')) {
+        for (;;) {
+            const char *kb;
+            size_t kn;
+            bool plain;
+            if (!c.string(&kb, &kn, &plain) || !c.eat(':')) return TGN_ERR_UNSUPPORTED;
+            if (!plain) return TGN_ERR_UNSUPPORTED;          // an escaped key could spell "labels" / "jaw"
+            if (kn == 6 && !memcmp(kb, "labels", 6)) {
+                if (!c.int_array(labels)) return TGN_ERR_UNSUPPORTED;
+                have_labels = true;
+            } else if (kn == 3 && !memcmp(kb, "jaw", 3)) {
+                const char *vb;
+                size_t vn;
+                if (!c.string(&vb, &vn, &plain) || !plain) return TGN_ERR_UNSUPPORTED;
+                for (size_t i = 0; i < vn; ++i)
+                    if ((unsigned char)vb[i] < 0x20 || (unsigned char)vb[i] >= 0x7f) return TGN_ERR_UNSUPPORTED;
+                jaw.assign(vb, vn);
+                have_jaw = true;
+            } else if (!c.skip_value()) {
+                return TGN_ERR_UNSUPPORTED;
+            }
+            if (c.eat(',')) continue;
+            if (c.eat('}')) break;
+            return TGN_ERR_UNSUPPORTED;
+        }
+    }
+    c.ws();
+    if (c.s != c.e || !have_labels || !have_jaw) return TGN_ERR_UNSUPPORTED;
+    return TGN_OK;
+}
+
+static long long floordiv10(long long a) { return a / 10 - ((a % 10 != 0 && a < 0) ? 1 : 0); }
+
+// preprocess_data.py:39-44, in the order numpy applies the four masked assignments
+static long long remap_fdi(long long l, bool lower) {
+    if (lower) l -= 20;
+    if (floordiv10(l) == 1) l %= 10;
+    if (floordiv10(l) == 2) l = l % 10 + 8;
+    if (l < 0) l = 0;
+    return l;
+}
+
+struct Scan {
+    std::vector<double> labeled;   // (n, 7)
+    std::string jaw;
+    long long n = 0;
+};
 
 }  // namespace tgn
 
@@ -233,5 +436,84 @@ TGN_API int tgn_vertex_normals(const double *vertices, long long nv, const long 
             n[2] = 1.0;
         }
     }
+    return TGN_OK;
+}
+
+// One scan of the preprocess loop, preprocess_data.py:37-52 in one GIL-free call: the ground-truth json (jaw, FDI labels ->
+// 0..16), the OBJ (vertices + open3d-style normals), the centring and the fixed-range scaling, concatenated to the (n, 7)
+// float64 rows [x y z nx ny nz label] the reference holds in `labeled_vertices` before sampling.  The arithmetic repeats
+// numpy's: np.mean(axis=0) of a C-ordered (n, 3) view is a row-by-row running sum per column, and
+// ((v - mean) - Ymin) / (Ymax - Ymin) * 2 - 1 is evaluated per element in that order.
+// Returns TGN_ERR_UNSUPPORTED for a json this strict reader does not take (the caller then uses Python's json module) and
+// TGN_ERR_INVALID_ARGUMENT where the reference raises (unreadable file, bad OBJ token, label count != vertex count).
+TGN_API int tgn_scan_open(const char *obj_path, const char *json_path, double y_min, double y_max, void **handle,
+                          long long *n_vertices, char *jaw, int jaw_cap) {
+    if (!obj_path || !json_path || !handle || !n_vertices || !jaw || jaw_cap < 2) {
+        set_error("tgn_scan_open: bad argument");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    *handle = nullptr;
+    std::string data;
+    if (int rc = read_file(json_path, data)) return rc;
+    std::vector<long long> labels;
+    std::string jaw_s;
+    if (parse_scan_json(data, labels, jaw_s) != TGN_OK || (long long)jaw_s.size() >= jaw_cap) {
+        set_error("tgn_scan_open: %s is not a plain {\"jaw\": str, \"labels\": [int]} object", json_path);
+        return TGN_ERR_UNSUPPORTED;
+    }
+    if (int rc = read_file(obj_path, data)) return rc;
+    long long nv = 0, nf = 0;
+    std::vector<double> v;
+    std::vector<long long> f;
+    v.reserve(data.size() / 24);                                // ~ "v -12.345678 -12.345678 -12.345678\n" per vertex, two
+    f.reserve(data.size() / 12);                                //   "f 123456 123457 123458\n" per vertex: a first guess
+    if (int rc = parse_obj(data, nullptr, nullptr, 0, 0, &nv, &nf, &v, &f)) return rc;
+    std::string().swap(data);
+    std::vector<double> nrm((size_t)nv * 3);
+    for (auto &x : f) x -= 1;                                   // gen_utils.py:226
+    if (int rc = tgn_vertex_normals(v.data(), nv, f.data(), nf, nrm.data())) return rc;
+    if ((long long)labels.size() != nv) {
+        set_error("tgn_scan_open: %lld labels for %lld vertices (np.concatenate raises)", (long long)labels.size(), nv);
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    Scan *sc = new Scan();
+    sc->n = nv;
+    sc->jaw = jaw_s;
+    sc->labeled.resize((size_t)nv * 7);
+    double sum[3] = {0.0, 0.0, 0.0};
+    for (long long i = 0; i < nv; ++i)
+        for (int a = 0; a < 3; ++a) sum[a] += v[i * 3 + a];
+    const double mean[3] = {sum[0] / (double)nv, sum[1] / (double)nv, sum[2] / (double)nv};
+    const double range = y_max - y_min;
+    const bool lower = jaw_s == "lower";
+    for (long long i = 0; i < nv; ++i) {
+        double *row = sc->labeled.data() + i * 7;
+        for (int a = 0; a < 3; ++a) {
+            const double centred = v[i * 3 + a] - mean[a];
+            const double unit = (centred - y_min) / range;
+            row[a] = unit * 2.0 - 1.0;                          // (x * 2 is exact, so a contracted fma gives the same bits)
+            row[3 + a] = nrm[i * 3 + a];
+        }
+        row[6] = (double)remap_fdi(labels[i], lower);
+    }
+    memcpy(jaw, jaw_s.c_str(), jaw_s.size() + 1);
+    *n_vertices = nv;
+    *handle = sc;
+    return TGN_OK;
+}
+
+// Copies the (n, 7) rows out (and, when xyz32 is given, the float32 copy of the coordinates the sampler takes) and frees
+// the handle.  With both pointers null it only frees.
+TGN_API int tgn_scan_take(void *handle, double *labeled, float *xyz32) {
+    Scan *sc = (Scan *)handle;
+    if (!sc) {
+        set_error("tgn_scan_take: null handle");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    if (labeled) memcpy(labeled, sc->labeled.data(), sc->labeled.size() * sizeof(double));
+    if (xyz32)
+        for (long long i = 0; i < sc->n; ++i)
+            for (int a = 0; a < 3; ++a) xyz32[i * 3 + a] = (float)sc->labeled[i * 7 + a];
+    delete sc;
     return TGN_OK;
 }

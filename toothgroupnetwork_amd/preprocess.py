@@ -102,6 +102,31 @@ def load_scan(obj_path, json_path):
     return np.concatenate([vertices, labels], axis=1), str(base_name), loaded["jaw"]
 
 
+def load_scan_native(obj_path, json_path, with_xyz32=False):
+    """load_scan in ONE native call that never holds the interpreter lock (tgn_scan_open / tgn_scan_take): what the sharded
+    runner's load threads use, since json.load, the label remap and the numpy glue of load_scan serialise on the GIL.
+    -> (labeled_vertices, base_name, jaw, xyz32 or None); xyz32 = float32 copy of the coordinates when with_xyz32 and the
+    scan has more than N_SAMPLED vertices.  Returns None when the json is not the plain {"jaw": str, "labels": [int]} shape
+    (the caller then takes load_scan); raises ValueError where load_scan raises."""
+    L = _lib.lib()
+    handle, nv = ctypes.c_void_p(), ctypes.c_longlong(0)
+    jaw = ctypes.create_string_buffer(64)
+    rc = L.tgn_scan_open(os.fsencode(obj_path), os.fsencode(json_path), Y_AXIS_MIN, Y_AXIS_MAX, ctypes.byref(handle),
+                         ctypes.byref(nv), jaw, len(jaw))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    if rc:
+        raise ValueError(L.tgn_last_error().decode("utf-8", "replace"))
+    try:
+        lv = np.empty((nv.value, 7), dtype=np.float64)
+        x32 = np.empty((nv.value, 3), dtype=np.float32) if with_xyz32 and nv.value > N_SAMPLED else None
+    except BaseException:
+        L.tgn_scan_take(handle, None, None)
+        raise
+    L.tgn_scan_take(handle, lv.ctypes.data_as(ctypes.c_void_p), x32.ctypes.data_as(ctypes.c_void_p) if x32 is not None else None)
+    return lv, str(os.path.basename(obj_path).split(".")[0]), jaw.value.decode("ascii"), x32
+
+
 def _default_fps_batch(xyz_list, npoint):
     from . import resample
     return resample.fps_batch(xyz_list, npoint)
@@ -128,6 +153,9 @@ def preprocess_scans(pairs, save_path, batch=16, fps_batch=None, workers=None):
 
     def load(obj_path, json_path):
         # (worker thread) the fp32 copy of the coordinates the sampler wants is made here too: numpy releases the GIL for it
+        fast = load_scan_native(obj_path, json_path, with_xyz32=True)
+        if fast is not None:
+            return fast
         lv, name, jaw = load_scan(obj_path, json_path)
         return lv, name, jaw, (np.ascontiguousarray(lv[:, :3], dtype=np.float32) if lv.shape[0] > N_SAMPLED else None)
 
