@@ -16,6 +16,7 @@ a small fp64 vector at the end.
 import ctypes
 import json
 import os
+import threading
 import time
 
 import numpy as np
@@ -127,36 +128,54 @@ def load_scan_native(obj_path, json_path, with_xyz32=False):
     return lv, str(os.path.basename(obj_path).split(".")[0]), jaw.value.decode("ascii"), x32
 
 
+_sampler_local = threading.local()
+
+
 def _default_fps_batch(xyz_list, npoint):
+    """resample.fps_batch on a HIP stream of the calling thread's own: the sampler threads of preprocess_scans each keep a
+    launch in flight, and launches on different streams share the GPU (one workgroup per scan, 256 CUs)."""
+    import torch
     from . import resample
-    return resample.fps_batch(xyz_list, npoint)
+    stream = getattr(_sampler_local, "stream", None)
+    if stream is None:
+        stream = _sampler_local.stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        return resample.fps_batch(xyz_list, npoint)
 
 
-def preprocess_scans(pairs, save_path, batch=16, fps_batch=None, workers=None):
+def preprocess_scans(pairs, save_path, batch=16, fps_batch=None, workers=None, samplers=None):
     """pairs: [(obj_path, json_path)] -> one "<id>_<jaw>_sampled_points.npy" per scan under save_path, exactly the arrays
-    preprocess_data.py writes.  Scans with more than 24 000 vertices are farthest-point-sampled `batch` at a time in one
-    launch.  Three stages overlap: the host side of batch k+1 (OBJ parse + normals in the native library, which releases the
-    GIL, json, scaling) runs on `workers` threads (default: min(batch, host cores / ranks on the node)) while the GPU samples
-    batch k and writer threads select and save batch k-1 (the main thread only packs, launches and copies the indices back).
-    Returns {"scans", "sampled", "points_in", "checksum", "seconds_load" (time the loop WAITED for loads), "seconds_fps"}."""
+    preprocess_data.py writes.  Scans with more than 24 000 vertices are farthest-point-sampled up to `batch` at a time in
+    one launch.  Three stages overlap: load threads (`workers`, default min(32, host cores / ranks on the node): more only contend for page faults) run the
+    host side of a scan in one native call that never holds the interpreter lock (load_scan_native: json, OBJ parse,
+    normals, scaling); `samplers` threads (default 2, TGN_PREPROCESS_SAMPLERS) each pack a batch, launch the FPS on a
+    stream of their own and hand the picks to writer threads, which select and save.  The FPS launch is bound by its
+    iteration count, not by the number of scans in it (one workgroup per scan), so the loop takes WHATEVER the loaders have
+    finished (in submission order, at least batch/4, at most batch): the batch grows until the GPU keeps up with the host
+    cores, nobody waits for a fixed-size batch to fill, and two launches in flight share the chip.
+    Returns {"scans", "sampled", "points_in", "checksum", "batches", "seconds_load" (time the loop WAITED for loads),
+    "seconds_fps" (summed over the sampler threads)}."""
+    from collections import deque
     from concurrent.futures import ThreadPoolExecutor
     fps_batch = fps_batch or _default_fps_batch
     os.makedirs(save_path, exist_ok=True)
     if workers is None:
         local = max(int(os.environ.get("LOCAL_WORLD_SIZE", "1")), 1)
-        workers = int(os.environ.get("TGN_PREPROCESS_WORKERS", "0")) or max(1, min(int(batch), (os.cpu_count() or 1) // local))
-    stats = dict(scans=0, sampled=0, points_in=0, checksum=0.0, seconds_load=0.0, seconds_fps=0.0)
+        workers = int(os.environ.get("TGN_PREPROCESS_WORKERS", "0")) or max(1, min(32, (os.cpu_count() or 1) // local))
+    if samplers is None:
+        samplers = max(int(os.environ.get("TGN_PREPROCESS_SAMPLERS", "2")), 1)
+    stats = dict(scans=0, sampled=0, points_in=0, checksum=0.0, batches=0, seconds_load=0.0, seconds_fps=0.0)
     step = max(int(batch), 1)
-    chunks = [pairs[s:s + step] for s in range(0, len(pairs), step)]
+    at_least = max(step // 4, 1)
     pool = ThreadPoolExecutor(max_workers=workers)
+    sampler = ThreadPoolExecutor(max_workers=samplers)
     writer = ThreadPoolExecutor(max_workers=4)
 
     def load(obj_path, json_path):
-        # (worker thread) the fp32 copy of the coordinates the sampler wants is made here too: numpy releases the GIL for it
         fast = load_scan_native(obj_path, json_path, with_xyz32=True)
         if fast is not None:
             return fast
-        lv, name, jaw = load_scan(obj_path, json_path)
+        lv, name, jaw = load_scan(obj_path, json_path)         # a json the strict native reader hands back
         return lv, name, jaw, (np.ascontiguousarray(lv[:, :3], dtype=np.float32) if lv.shape[0] > N_SAMPLED else None)
 
     def select_and_save(lv, ix, name, jaw):
@@ -165,30 +184,57 @@ def preprocess_scans(pairs, save_path, batch=16, fps_batch=None, workers=None):
             lv = lv[np.asarray(ix)[:N_SAMPLED]]
         np.save(os.path.join(save_path, sampled_points_name(name, jaw)), lv)
 
-    submit = lambda chunk: [pool.submit(load, o, j) for o, j in chunk]
-    pending, writes = (submit(chunks[0]) if chunks else []), []
+    def sample(loaded):
+        # (sampler thread) one FPS launch over the scans of this batch that need it, then the writes
+        t0 = time.perf_counter()
+        big = [i for i, item in enumerate(loaded) if item[3] is not None]
+        idx = fps_batch([loaded[i][3] for i in big], N_SAMPLED) if big else []
+        picked = dict(zip(big, idx))
+        checksum = sum(float(np.asarray(ix, dtype=np.int64).sum()) for ix in idx)
+        dt = time.perf_counter() - t0
+        writes = [writer.submit(select_and_save, lv, picked.get(i), name, jaw) for i, (lv, name, jaw, _) in enumerate(loaded)]
+        return len(loaded), len(big), sum(int(item[0].shape[0]) for item in loaded), checksum, dt, writes
+
+    todo, inflight, sampling, writes = iter(pairs), deque(), deque(), []
+
+    def top_up():                                               # at most 2 * batch scans loaded or loading at any time
+        while len(inflight) < 2 * step:
+            nxt = next(todo, None)
+            if nxt is None:
+                return
+            inflight.append(pool.submit(load, *nxt))
+
+    def retire(fut):
+        n, nbig, pts, checksum, dt, ws = fut.result()
+        stats["scans"] += n
+        stats["sampled"] += nbig
+        stats["points_in"] += pts
+        stats["checksum"] += checksum
+        stats["batches"] += 1
+        stats["seconds_fps"] += dt
+        writes.extend(ws)
+
     try:
-        for k in range(len(chunks)):
+        top_up()
+        while inflight:
             t0 = time.perf_counter()
-            loaded = [f.result() for f in pending]
-            pending = submit(chunks[k + 1]) if k + 1 < len(chunks) else []     # parsed while the GPU samples this batch
-            t1 = time.perf_counter()
-            stats["points_in"] += sum(int(item[0].shape[0]) for item in loaded)
-            big = [i for i, item in enumerate(loaded) if item[3] is not None]
-            idx = fps_batch([loaded[i][3] for i in big], N_SAMPLED) if big else []
-            picked = dict(zip(big, idx))
-            for ix in idx:
-                stats["checksum"] += float(np.asarray(ix, dtype=np.int64).sum())
-            t2 = time.perf_counter()
-            writes += [writer.submit(select_and_save, lv, picked.get(i), name, jaw) for i, (lv, name, jaw, _) in enumerate(loaded)]
-            stats["scans"] += len(loaded)
-            stats["sampled"] += len(big)
-            stats["seconds_load"] += t1 - t0
-            stats["seconds_fps"] += t2 - t1
+            loaded = []
+            while inflight and (len(loaded) < at_least or (len(loaded) < step and inflight[0].done())):
+                loaded.append(inflight.popleft().result())
+            top_up()                                            # parsed while the GPU samples
+            stats["seconds_load"] += time.perf_counter() - t0
+            while len(sampling) >= samplers:
+                retire(sampling.popleft())
+            sampling.append(sampler.submit(sample, loaded))
+        while sampling:
+            retire(sampling.popleft())
         for w in writes:
             w.result()                                                             # (re-raises a failed write)
     finally:
+        for f in inflight:
+            f.cancel()
         pool.shutdown()
+        sampler.shutdown()
         writer.shutdown()
     return stats
 
@@ -209,19 +255,19 @@ def list_scans(source_obj_data_path, source_json_data_path):
 def preprocess_sharded(pairs, save_path, rank, world, batch=16, fps_batch=None, device=None, mode="round_robin"):
     """BASELINE.json config 5: rank `rank` of `world` preprocesses its shard of `pairs` (round robin: raw scans differ in
     size); ONE collective at the end gathers the per-rank counters.  Returns the job totals (identical on every rank):
-    {"scans", "sampled", "points_in", "checksum", "seconds" (max over ranks), "per_rank_scans", "meshes_per_s"}."""
+    {"scans", "sampled", "points_in", "checksum", "seconds" (max over ranks), "per_rank_scans", "fps_launches", "meshes_per_s"}."""
     mine = [pairs[i] for i in sharding.shard_indices(len(pairs), rank, world, mode)]
     sharding.barrier()
     t0 = time.perf_counter()
     st = preprocess_scans(mine, save_path, batch=batch, fps_batch=fps_batch)
     dt = time.perf_counter() - t0
     mat = sharding.gather_metrics([st["scans"], st["sampled"], st["points_in"], st["checksum"], dt, st["seconds_load"],
-                                   st["seconds_fps"]], device=device).cpu().numpy()
+                                   st["seconds_fps"], st["batches"]], device=device).cpu().numpy()
     tot = mat.sum(0)
     seconds = float(mat[:, 4].max())
     return {"scans": int(round(tot[0])), "sampled": int(round(tot[1])), "points_in": int(round(tot[2])), "checksum": float(tot[3]),
             "seconds": seconds, "seconds_load_max": float(mat[:, 5].max()), "seconds_fps_max": float(mat[:, 6].max()),
-            "per_rank_scans": [int(round(v)) for v in mat[:, 0]], "meshes_per_s": float(tot[0] / seconds) if seconds > 0 else 0.0}
+            "per_rank_scans": [int(round(v)) for v in mat[:, 0]], "fps_launches": int(round(tot[7])), "meshes_per_s": float(tot[0] / seconds) if seconds > 0 else 0.0}
 
 
 def transfer_labels(sampled_xyz, sampled_labels, vertices, candidates=4):
