@@ -161,6 +161,33 @@ def test_fps_large_cloud_workspace_kernel(dev, oracle, mode):
     assert np.array_equal(out2.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("n,mode", [(70000, 0), (150000, 3), (250000, 0), (262144, 1)])
+def test_fps_large_cloud_every_metadata_group_count(dev, oracle, n, mode):
+    """The large-cloud kernel keeps 64 buckets per wave and register group: 1, 2, 3 and 4 groups (up to its 262 144-point
+    limit), duplicated vertices and NaN coordinates included, next to a small cloud in the same launch."""
+    from toothgroupnetwork_amd import _lib
+    L = _lib.lib()
+    a = synth.arch_cloud(n, 11, False)
+    a[5000:5400] = a[100:500]                       # exact ties between buckets and waves
+    a[[3, n // 2, n - 1]] = np.nan
+    c = synth.uniform_cloud(3000, 4)
+    xyz_np = np.concatenate([a, c])
+    off_np = np.cumsum([n, c.shape[0]]).astype(np.int32)
+    noff_np = np.cumsum([2500, 400]).astype(np.int32)
+    flags = (_lib.FPS_FMA if mode & 1 else 0) | (_lib.FPS_TREE_TIES if mode & 2 else 0)
+    xyz, off, noff = T(xyz_np, dev), T(off_np, dev), T(noff_np, dev)
+    ref = oracle.furthestsampling(xyz_np, off_np, noff_np, mode=mode)
+    nbytes = int(L.tgn_fps_workspace_bytes(2, n))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    out = torch.empty(int(noff_np[-1]), dtype=torch.int32, device=dev)
+    nx = torch.empty(int(noff_np[-1]), 3, dtype=torch.float32, device=dev)
+    _lib.check(L.tgn_furthestsampling_ws(2, n, _lib.ptr(xyz), _lib.ptr(off), _lib.ptr(noff), _lib.ptr(ws), nbytes,
+                                         _lib.ptr(out), _lib.ptr(nx), flags, _lib.stream()))
+    got = out.cpu().numpy()
+    assert np.array_equal(got, ref)
+    assert np.array_equal(nx.cpu().numpy(), xyz_np[ref], equal_nan=True)
+
+
 def test_fps_oversized_cloud_through_python_api(dev, oracle):
     from toothgroupnetwork_amd import _lib, pointops as P
     n = _lib.lib().tgn_fps_resident_capacity() + 1500

@@ -27,6 +27,8 @@
 // average; what remains is the latency of ~3 bucket updates on the busiest wave plus the block hand-off).
 #include "fps_common.h"
 
+#include <type_traits>
+
 #include <stdlib.h>
 
 
@@ -517,37 +519,46 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Large clouds (raw scans of 10^5 points, preprocess_data.py:55-56 resamples N_raw -> 24 000): the same exact
-// bucket skipping with the points in a cell-sorted workspace instead of registers.  The streaming fallback re-reads
-// 20 B per point per iteration (2 MB at 10^5 points; 18-36 us per iteration measured); here an iteration tests
-// ~N/64 bucket boxes held in LDS and touches only the few buckets the new sample can change (1 KiB each, L2-resident).
-//   workspace per cloud: rec[NBpad] float4 (x, y, z, running min distance) + sidx[NBpad] int (original index),
-//   sorted by 15-bit Z-order cell (counting sort: LDS histogram -> scan -> scatter); bucket = 64 consecutive records.
+// Large clouds (raw scans of 10^5 points, preprocess_data.py:55-56 resamples N_raw -> 24 000): the same exact bucket
+// skipping with the points in a cell-sorted, L2-resident workspace instead of registers.  (The streaming fallback of
+// fps.hip re-reads 20 B per point per iteration: 2 MB at 10^5 points, 18-36 us per iteration measured.)
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kStreamThreads = 1024;
 constexpr int kStreamMaxBuckets = 4096;           // 262 144 points
 constexpr int kStreamCells = 32768;
-constexpr int kStreamListCap = 1024;
 
 __host__ __device__ inline size_t fps_stream_cloud_bytes(int n_max) {
     const size_t npad = ((size_t)n_max + 63) / 64 * 64;
     return npad * (sizeof(float4) + sizeof(int));
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kStreamThreads) void fps_bucket_stream_kernel(FpsArgs a) {
+// Every wave OWNS its buckets, as in the register-resident kernel: the bucket boxes, maxima and arg-max points (coordinates,
+// tie key) of a wave live in its own VGPR lanes (G groups of 64 buckets), only the 64 points of a bucket stay in the
+// workspace.  An iteration is: G box tests on the metadata lanes, the records of the few touched buckets requested from L2
+// (the first two of a group in flight together), update + refresh in registers, the wave's candidate from registers, ONE
+// hand-off record per wave and ONE barrier.  (Round 2's form kept the bucket planes in LDS, collected the touched buckets
+// in an LDS list for the waves to share, and read the winner's coordinates back from memory: three barriers and a
+// dependent global read per iteration, 1.97 us per iteration at 108 000 points against 1.06 now.)
+//   workspace per cloud: rec[NBpad] float4 (x, y, z, original index as bits; read-only after set-up) +
+//                        dist[NBpad] float (running minimum, one 256-B line per bucket)
+//   bucket b (sorted positions [64b, 64b+64)) -> slot b / NW of wave (b % NW) ^ fold(slot): Z-order neighbours (index
+//   distances 1, 2, 4 ... and NW, 2 NW, ...) sit in different waves and are updated concurrently.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NW>
+__device__ __forceinline__ int fps_owner_bucket(int wave, int slot) {
+    return slot * NW + (wave ^ ((slot ^ (slot >> 4)) & (NW - 1)));
+}
+
+template <int MODE, int G>
+__global__ __launch_bounds__(kStreamThreads) void fps_bucket_owner_kernel(FpsArgs a) {
     constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0, CERT = (MODE & kFpsModeCert) != 0;
-    constexpr int NT = kStreamThreads, NW = NT / kWave, NBM = kStreamMaxBuckets;
-    // 128 KiB: cell histogram during set-up, then the bucket planes lo[3], hi[3], bmax (float) and bkey (u32)
-    __shared__ unsigned lds[kStreamCells];
+    constexpr int NT = kStreamThreads, NW = NT / kWave;
+    static_assert(NW == 16 && G >= 1 && G <= 4, "16 waves x G x 64 buckets");
+    __shared__ unsigned lds[kStreamCells];   // 128 KiB: cell histogram during set-up, then the parked result rows
     __shared__ float red[6][NW];
-    __shared__ unsigned long long slots[2][NW];
-    __shared__ int tlist[kStreamListCap];
-    __shared__ int tcount;
     __shared__ int wave_tot[NW];
-    float *plo0 = (float *)lds, *plo1 = plo0 + NBM, *plo2 = plo1 + NBM, *phi0 = plo2 + NBM, *phi1 = phi0 + NBM,
-          *phi2 = phi1 + NBM, *pmax = phi2 + NBM;
-    unsigned *pkey = lds + 7 * NBM;
+    __shared__ float4 hand[2][NW][2];        // per wave: {value bits, tie key} and {x, y, z} of its candidate
+    float4 *outbuf = (float4 *)lds;          // [NT]
 
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     int start_n, n, start_m, m;
@@ -561,11 +572,12 @@ __global__ __launch_bounds__(kStreamThreads) void fps_bucket_stream_kernel(FpsAr
     const int NB = (n + 63) / 64;
     const int npad = NB * 64;
     float4 *__restrict__ rec = (float4 *)wsb;
-    int *__restrict__ sidx = (int *)(wsb + (((size_t)a.n_max + 63) / 64 * 64) * sizeof(float4));
+    float *__restrict__ dist = (float *)(wsb + (((size_t)a.n_max + 63) / 64 * 64) * sizeof(float4));
 
     // ---- set-up 1: bounding box -------------------------------------------------------------------------------
     {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll 4
         for (int k = tid; k < n; k += NT) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -586,7 +598,6 @@ __global__ __launch_bounds__(kStreamThreads) void fps_bucket_stream_kernel(FpsAr
         }
     }
     for (int i = tid; i < kStreamCells; i += NT) lds[i] = 0;
-    if (tid == 0) tcount = 0;
     __syncthreads();
     float glo[3], gscale[3];
 #pragma unroll
@@ -611,6 +622,7 @@ __global__ __launch_bounds__(kStreamThreads) void fps_bucket_stream_kernel(FpsAr
         return spread5(cc[0]) | (spread5(cc[1]) << 1) | (spread5(cc[2]) << 2);
     };
     // ---- set-up 2: counting sort by Z-order cell into the workspace ---------------------------------------------
+#pragma unroll 4
     for (int i = tid; i < n; i += NT) atomicAdd(&lds[cell_of(i)], 1u);
     __syncthreads();
     {
@@ -637,137 +649,254 @@ __global__ __launch_bounds__(kStreamThreads) void fps_bucket_stream_kernel(FpsAr
         for (int i = 0; i < PER; ++i) lds[tid * PER + i] = tbase + local[i];  // running insert position
     }
     __syncthreads();
+#pragma unroll 4
     for (int i = tid; i < n; i += NT) {
         const unsigned pos = atomicAdd(&lds[cell_of(i)], 1u);
-        rec[pos] = make_float4(base[(size_t)i * 3 + 0], base[(size_t)i * 3 + 1], base[(size_t)i * 3 + 2], 1e10f);
-        sidx[pos] = i;
+        rec[pos] = make_float4(base[(size_t)i * 3 + 0], base[(size_t)i * 3 + 1], base[(size_t)i * 3 + 2], __int_as_float(i));
+        dist[pos] = 1e10f;  // pointops.py:22
     }
     for (int i = n + tid; i < npad; i += NT) {
-        rec[i] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);  // padding never wins
-        sidx[i] = 0x7FFFFFFF;
+        rec[i] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0x7FFFFFFF));
+        dist[i] = -1.0f;  // padding never wins (real distances are >= 0)
     }
     __syncthreads();  // workspace complete and visible to the whole workgroup; histogram no longer needed
-    // ---- set-up 3: bucket planes ---------------------------------------------------------------------------------
-    for (int bk = wave; bk < NBM; bk += NW) {
-        float l0 = INFINITY, l1 = INFINITY, l2 = INFINITY, h0 = -INFINITY, h1 = -INFINITY, h2 = -INFINITY, mx = -1.0f;
-        unsigned key = 0xFFFFFFFFu;
-        if (bk < NB) {
+
+    // ---- set-up 3: the metadata of my buckets into my lanes -----------------------------------------------------------
+    float blo0[G], blo1[G], blo2[G], bhi0[G], bhi1[G], bhi2[G], bmax[G], ax[G], ay[G], az[G];
+    unsigned akey[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        blo0[g] = blo1[g] = blo2[g] = INFINITY;
+        bhi0[g] = bhi1[g] = bhi2[g] = -INFINITY;
+        bmax[g] = -1.0f;
+        ax[g] = ay[g] = az[g] = 0.0f;
+        akey[g] = 0xFFFFFFFFu;
+        for (int l = 0; l < kWave; ++l) {   // wave-uniform trip
+            const int bk = fps_owner_bucket<NW>(wave, g * kWave + l);
+            if (bk >= NB) continue;
             const float4 r = rec[bk * kWave + lane];
-            const bool valid = r.w >= 0.0f;
-            l0 = wave_min_f32_dpp(valid ? r.x : INFINITY);
-            h0 = wave_max_f32_dpp(valid ? r.x : -INFINITY);
-            l1 = wave_min_f32_dpp(valid ? r.y : INFINITY);
-            h1 = wave_max_f32_dpp(valid ? r.y : -INFINITY);
-            l2 = wave_min_f32_dpp(valid ? r.z : INFINITY);
-            h2 = wave_max_f32_dpp(valid ? r.z : -INFINITY);
-            mx = wave_max_f32_dpp(r.w);
-            const unsigned o = (unsigned)sidx[bk * kWave + lane];
-            key = wave_min_u32_shfl(valid ? (TREE ? compat_key((int)o, log2bs) : o) : 0xFFFFFFFFu);
-        }
-        if (lane == 0) {
-            plo0[bk] = l0;
-            plo1[bk] = l1;
-            plo2[bk] = l2;
-            phi0[bk] = h0;
-            phi1[bk] = h1;
-            phi2[bk] = h2;
-            pmax[bk] = mx;
-            pkey[bk] = key;
+            const float dv = dist[bk * kWave + lane];
+            const bool valid = dv >= 0.0f;
+            // NaN coordinates are left out of the box: such a point can never be updated anyway (min ignores NaN)
+            const float l0 = wave_min_f32_dpp(valid ? r.x : INFINITY), h0 = wave_max_f32_dpp(valid ? r.x : -INFINITY);
+            const float l1 = wave_min_f32_dpp(valid ? r.y : INFINITY), h1 = wave_max_f32_dpp(valid ? r.y : -INFINITY);
+            const float l2 = wave_min_f32_dpp(valid ? r.z : INFINITY), h2 = wave_max_f32_dpp(valid ? r.z : -INFINITY);
+            const float mx = wave_max_f32_dpp(dv);   // 1e10: the bucket holds a real point
+            // initial arg-max of the bucket: all real points sit at 1e10, the smallest tie key wins
+            const unsigned o = __float_as_uint(r.w);
+            const unsigned kl = valid ? (TREE ? compat_key((int)o, log2bs) : o) : 0xFFFFFFFFu;
+            const unsigned kmin = wave_min_u32_dpp(kl);
+            const int wl = __builtin_ctzll(ballot64(kl == kmin) | (1ull << 63));
+            const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.x), wl));
+            const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.y), wl));
+            const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.z), wl));
+            if (lane == l) {   // (a v_writelane with a lane number in an SGPR needs M0 on gfx9: the masked moves are as short)
+                blo0[g] = l0;
+                blo1[g] = l1;
+                blo2[g] = l2;
+                bhi0[g] = h0;
+                bhi1[g] = h1;
+                bhi2[g] = h2;
+                bmax[g] = mx;
+                ax[g] = cx;
+                ay[g] = cy;
+                az[g] = cz;
+                akey[g] = kmin;
+            }
         }
     }
+
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
     if (n > 0) {
         qx = base[0];
         qy = base[1];
         qz = base[2];
     }
-    int hold_k = 0;
-    float hold_x = qx, hold_y = qy, hold_z = qz;
-    __syncthreads();
+    if (tid == 0) outbuf[0] = make_float4(__int_as_float(0), qx, qy, qz);  // row 0: sampling_cuda_kernel.cu:39
+
+    // cached wave candidate (wave-uniform)
+    float wm = -1.0f, wx = 0.0f, wy = 0.0f, wz = 0.0f;
+    unsigned wkey = 0, pub_bits = 0u, pub_key = 0xFFFFFFFFu;
+    int wslot = -1;
+    constexpr unsigned kRecParity = NW * 32u;
+    char *recb = (char *)hand;
+    unsigned wr_off = (unsigned)wave * 32u, rd_off = (unsigned)(lane & (NW - 1)) * 32u;
+    bool dirty = true;
 
     for (int j = 1; j < m; ++j) {
-        // ---- A. every thread tests its buckets; touched ones go to the list ----------------------------------------
-        for (int bk = tid; bk < NBM; bk += NT) {  // NBM is a multiple of NT: uniform trip count, ballots are safe
-            bool need = false;
-            if (bk < NB) {
-                const float ex = fmaxf(fmaxf(plo0[bk] - qx, qx - phi0[bk]), 0.0f);
-                const float ey = fmaxf(fmaxf(plo1[bk] - qy, qy - phi1[bk]), 0.0f);
-                const float ez = fmaxf(fmaxf(plo2[bk] - qz, qz - phi2[bk]), 0.0f);
-                const float L = FMA ? dist_direct_fma(ex, ey, ez) : dist_direct_nofma(ex, ey, ez);
-                need = !(L >= pmax[bk]);
-            }
-            const unsigned long long mk = __ballot(need);
-            if (mk) {
-                int wbase = 0;
-                if (lane == 0) wbase = atomicAdd(&tcount, (int)__popcll(mk));
-                wbase = __builtin_amdgcn_readfirstlane(wbase);
-                const int pos = wbase + mbcnt(mk);
-                if (need && pos < kStreamListCap) tlist[pos] = bk;
-            }
-            if (bk - tid + NT >= NB) break;  // uniform: no bucket left in later rounds
+        // ---- A. which of my buckets can the new sample change? (monotone lower bound, exact) -------------
+        unsigned long long mask[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float ex = fmaxf(fmaxf(blo0[g] - qx, qx - bhi0[g]), 0.0f);
+            const float ey = fmaxf(fmaxf(blo1[g] - qy, qy - bhi1[g]), 0.0f);
+            const float ez = fmaxf(fmaxf(blo2[g] - qz, qz - bhi2[g]), 0.0f);
+            const float L = FMA ? dist_direct_fma(ex, ey, ez) : dist_direct_nofma(ex, ey, ez);
+            mask[g] = ballot64(!(L >= bmax[g]));   // lanes without a bucket: bmax = -1, never set
         }
-        __syncthreads();
-        // ---- B. update the touched buckets (waves take them round-robin) ---------------------------------------------
-        {
-            const int cnt = tcount;
-            const bool overflow = cnt > kStreamListCap;  // fall back to re-testing every bucket
-            const int total = overflow ? NB : cnt;
-            for (int e = wave; e < total; e += NW) {
-                int bk = overflow ? e : tlist[e];
-                if (overflow) {
-                    const float ex = fmaxf(fmaxf(plo0[bk] - qx, qx - phi0[bk]), 0.0f);
-                    const float ey = fmaxf(fmaxf(plo1[bk] - qy, qy - phi1[bk]), 0.0f);
-                    const float ez = fmaxf(fmaxf(plo2[bk] - qz, qz - phi2[bk]), 0.0f);
-                    const float L = FMA ? dist_direct_fma(ex, ey, ez) : dist_direct_nofma(ex, ey, ez);
-                    if (L >= pmax[bk]) continue;  // wave-uniform
-                }
-                const int p = bk * kWave + lane;
-                const float4 r = rec[p];
-                const float dx = r.x - qx, dy = r.y - qy, dz = r.z - qz;
-                const float dd = FMA ? dist_direct_fma(dx, dy, dz) : dist_direct_nofma(dx, dy, dz);
-                const float nd = vmin_f32(dd, r.w);
-                rec[p].w = nd;
+        // ---- B. the touched buckets: records from L2.  The first two of a group are requested together (one latency for
+        //         both), the rare third and later ones one at a time.  The running minima go back unconditionally: with a
+        //         conditional store the wait in front of the second record's use could not be counted exactly. ----------
+        auto process = [&](auto gtag, int l, int p, const float4 &r, float dv) __attribute__((always_inline)) {
+            constexpr int g = decltype(gtag)::value;
+            const float dx = r.x - qx, dy = r.y - qy, dz = r.z - qz;
+            const float dd = FMA ? dist_direct_fma(dx, dy, dz) : dist_direct_nofma(dx, dy, dz);
+            const bool closer = dd < dv;
+            const float nd = vmin_f32(dd, dv);  // min(d, tmp[k]) sampling_cuda_kernel.cu:55
+            dist[p] = nd;
+            const float bold = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bmax[g]), l));
+            // Distances only shrink: unless a point that HELD the bucket's maximum gets closer, the bucket's maximum and
+            // arg-max are unchanged and the 64-lane refresh is skipped.
+            if (ballot64(dv == bold && closer) != 0ull) {  // wave-uniform
                 const float mx = wave_max_f32_dpp(nd);
-                const unsigned o = (unsigned)sidx[p];
-                const unsigned kl = (nd == mx) ? (TREE ? compat_key((int)o, log2bs) : o) : 0xFFFFFFFFu;
-                const unsigned key = wave_min_u32_dpp(kl);
-                pmax[bk] = mx;   // wave-uniform values: every lane stores them (no exec juggling around two LDS stores)
-                pkey[bk] = key;
+                const unsigned o = __float_as_uint(r.w);
+                const unsigned ko = TREE ? compat_key((int)o, log2bs) : o;
+                const unsigned long long eq = ballot64(nd == mx);
+                int wl = __builtin_ctzll(eq | (1ull << 63));
+                if (__builtin_expect(__popcll(eq) != 1, 0)) {  // exact tie inside the bucket (rare): the smallest tie key wins
+                    const unsigned kl = nd == mx ? ko : 0xFFFFFFFFu;
+                    const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kl));
+                    wl = __builtin_ctzll(ballot64(kl == kmin) | (1ull << 63));
+                }
+                const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.x), wl));
+                const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.y), wl));
+                const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.z), wl));
+                const int ck = __builtin_amdgcn_readlane((int)ko, wl);
+                if (lane == l) {   // one exec-masked block of five scalar-source moves
+                    bmax[g] = mx;
+                    ax[g] = cx;
+                    ay[g] = cy;
+                    az[g] = cz;
+                    akey[g] = (unsigned)ck;
+                }
+                if (g * kWave + l == wslot) dirty = true;
             }
+        };
+        auto walk = [&](auto gtag) __attribute__((always_inline)) {
+            constexpr int g = decltype(gtag)::value;
+            unsigned long long mm = mask[g];
+            if (__builtin_expect(mm != 0ull, 0)) {  // wave-uniform
+                const int l0 = __builtin_ctzll(mm);
+                mm &= mm - 1ull;
+                const int p0 = fps_owner_bucket<NW>(wave, g * kWave + l0) * kWave + lane;
+                const float4 r0 = rec[p0];
+                const float d0 = dist[p0];
+                if (mm == 0ull) {
+                    process(gtag, l0, p0, r0, d0);
+                } else {
+                    const int l1 = __builtin_ctzll(mm);
+                    mm &= mm - 1ull;
+                    const int p1 = fps_owner_bucket<NW>(wave, g * kWave + l1) * kWave + lane;
+                    const float4 r1 = rec[p1];
+                    const float d1 = dist[p1];
+                    process(gtag, l0, p0, r0, d0);
+                    process(gtag, l1, p1, r1, d1);
+                    while (mm != 0ull) {
+                        const int l2 = __builtin_ctzll(mm);
+                        mm &= mm - 1ull;
+                        const int p2 = fps_owner_bucket<NW>(wave, g * kWave + l2) * kWave + lane;
+                        const float4 r2 = rec[p2];
+                        const float d2 = dist[p2];
+                        process(gtag, l2, p2, r2, d2);
+                    }
+                }
+            }
+        };
+        walk(std::integral_constant<int, 0>{});
+        if constexpr (G > 1) walk(std::integral_constant<int, 1>{});
+        if constexpr (G > 2) walk(std::integral_constant<int, 2>{});
+        if constexpr (G > 3) walk(std::integral_constant<int, 3>{});
+        // ---- C. wave candidate = max over my bucket maxima (recomputed only if its bucket changed) ---------
+        if (dirty) {
+            float v = bmax[0], cx = ax[0], cy = ay[0], cz = az[0];
+            unsigned kk = akey[0];
+            int gs = 0;
+#pragma unroll
+            for (int g = 1; g < G; ++g) {
+                const bool better = bmax[g] > v || (bmax[g] == v && akey[g] < kk);
+                v = better ? bmax[g] : v;
+                kk = better ? akey[g] : kk;
+                cx = better ? ax[g] : cx;
+                cy = better ? ay[g] : cy;
+                cz = better ? az[g] : cz;
+                gs = better ? g : gs;
+            }
+            wm = wave_max_f32_dpp(v);
+            const unsigned long long cm = wm >= 0.0f ? ballot64(v == wm) : 0ull;
+            int sl = cm ? __builtin_ctzll(cm) : 0;
+            if (__builtin_expect(__popcll(cm) > 1, 0)) {
+                const unsigned kl = ((cm >> lane) & 1ull) ? kk : 0xFFFFFFFFu;
+                const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kl));
+                sl = __builtin_ctzll(ballot64(kl == kmin) | (1ull << 63));
+            }
+            wkey = (unsigned)__builtin_amdgcn_readlane((int)kk, sl);
+            wslot = __builtin_amdgcn_readlane(gs, sl) * kWave + sl;
+            wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), sl));
+            wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), sl));
+            wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cz), sl));
+            pub_bits = wm < 0.0f ? 0u : __float_as_uint(wm);  // a wave without points publishes (0, ~0)
+            pub_key = wm < 0.0f ? 0xFFFFFFFFu : wkey;
+            dirty = false;
         }
+        // ---- D. block argmax over the wave candidates: one LDS record per wave, ONE barrier ------------------
+        *(uint2 *)(recb + wr_off) = make_uint2(pub_bits, pub_key);          // every lane stores the same bytes (no exec juggling)
+        *(float3 *)(recb + wr_off + 16) = make_float3(wx, wy, wz);
         __syncthreads();
-        if (tid == 0) tcount = 0;
-        // ---- C. block argmax over all bucket maxima -------------------------------------------------------------------
-        unsigned long long pk = 0ull;
-        for (int bk = tid; bk < NB; bk += NT) {
-            const float v = pmax[bk];
-            const unsigned long long c = v < 0.0f ? 0ull : pack64(__float_as_uint(v), 0xFFFFFFFFu - pkey[bk]);
-            pk = c > pk ? c : pk;
+        const uint2 r0 = *(const uint2 *)(recb + rd_off);        // every lane reads record lane % NW
+        const float3 r1 = *(const float3 *)(recb + rd_off + 16);
+        rd_off ^= kRecParity;  // double-buffered by iteration parity: one barrier per iteration is enough
+        wr_off ^= kRecParity;
+        const unsigned vb = r0.x;
+        unsigned mb = vb;
+        asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                     : "+v"(mb));
+        mb = (unsigned)__builtin_amdgcn_readlane((int)mb, NW - 1);
+        if constexpr (CERT) cert.update(mb);
+        const unsigned long long wmask = ballot64(vb == mb) & ((1ull << NW) - 1ull);  // lanes 0..NW-1 hold the records
+        int wl = __builtin_ctzll(wmask | (1ull << 63));
+        if (__builtin_expect(__popcll(wmask) > 1, 0)) {  // equal maxima in several waves (rare): the smallest tie key wins
+            const unsigned kq = ((wmask >> lane) & 1ull) ? r0.y : 0xFFFFFFFFu;
+            const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kq));
+            wl = __builtin_ctzll(ballot64(kq == kmin) | (1ull << 63));
         }
-        const unsigned long long bmax64 = fps_block_max<NW>(pk, slots, j & 1, wave, lane);
-        if constexpr (CERT) cert.update((unsigned)(bmax64 >> 32));
-        const unsigned key = 0xFFFFFFFFu - (unsigned)bmax64;
-        int k = bmax64 == 0ull ? 0 : (TREE ? compat_index(key, log2bs) : (int)key);
+        const unsigned kwin = (unsigned)__builtin_amdgcn_readlane((int)r0.y, wl);
+        qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.x), wl));
+        qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.y), wl));
+        qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.z), wl));
+        int k = kwin == 0xFFFFFFFFu ? 0 : (TREE ? compat_index(kwin, log2bs) : (int)kwin);
         k = __builtin_amdgcn_readfirstlane(k);
-        if (n > 0) {
-            qx = base[(size_t)k * 3 + 0];
-            qy = base[(size_t)k * 3 + 1];
-            qz = base[(size_t)k * 3 + 2];
+        if (tid == 0) outbuf[j & (NT - 1)] = make_float4(__int_as_float(k), qx, qy, qz);
+        if ((j & (NT - 1)) == NT - 1) {  // wave-uniform
+            __syncthreads();
+            const float4 o = outbuf[tid];
+            fps_emit(a, start_m + j - (NT - 1) + tid, start_n, __float_as_int(o.x), o.y, o.z, o.w);
+            __syncthreads();
         }
-        if ((j & (NT - 1)) == tid) {
-            hold_k = k;
-            hold_x = qx;
-            hold_y = qy;
-            hold_z = qz;
-        }
-        if ((j & (NT - 1)) == NT - 1) fps_emit(a, start_m + j - (NT - 1) + tid, start_n, hold_k, hold_x, hold_y, hold_z);
     }
-    {
+    if (((m - 1) & (NT - 1)) != NT - 1) {  // rows of the last, partial chunk
+        __syncthreads();
         const int cb = ((m - 1) / NT) * NT;
-        if (((m - 1) & (NT - 1)) != NT - 1 && cb + tid <= m - 1)
-            fps_emit(a, start_m + cb + tid, start_n, hold_k, hold_x, hold_y, hold_z);
+        if (cb + tid <= m - 1) {
+            const float4 o = outbuf[tid];
+            fps_emit(a, start_m + cb + tid, start_n, __float_as_int(o.x), o.y, o.z, o.w);
+        }
     }
     if (a.prefix_out && tid == 0) a.prefix_out[blockIdx.x] = CERT ? cert.value(m) : 1;  // not tracked: no claim
+}
+
+template <int G>
+static void fps_owner_launch_g(int mode, int b, const FpsArgs &a, hipStream_t stream) {
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((fps_bucket_owner_kernel<0, G>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
+        case 1: hipLaunchKernelGGL((fps_bucket_owner_kernel<1, G>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((fps_bucket_owner_kernel<2, G>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((fps_bucket_owner_kernel<3, G>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((fps_bucket_owner_kernel<4, G>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
+        default: hipLaunchKernelGGL((fps_bucket_owner_kernel<5, G>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
+    }
 }
 
 size_t fps_stream_workspace_bytes(int b, int n_max) {
@@ -777,15 +906,12 @@ size_t fps_stream_workspace_bytes(int b, int n_max) {
 
 int fps_bucket_stream_launch(int mode, int b, int n_max, const FpsArgs &a, hipStream_t stream) {
     if (!a.ws || n_max > kStreamMaxBuckets * kWave || a.ws_bytes < fps_stream_workspace_bytes(b, n_max)) return -1;
-    switch (mode) {
-        case 0: hipLaunchKernelGGL((fps_bucket_stream_kernel<0>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
-        case 1: hipLaunchKernelGGL((fps_bucket_stream_kernel<1>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((fps_bucket_stream_kernel<2>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
-        case 3: hipLaunchKernelGGL((fps_bucket_stream_kernel<3>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((fps_bucket_stream_kernel<4>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
-        default: hipLaunchKernelGGL((fps_bucket_stream_kernel<5>), dim3(b), dim3(kStreamThreads), 0, stream, a); break;
-    }
-    return check_launch("fps_bucket_stream_kernel");
+    const int slots = ((n_max + 63) / 64 + 15) / 16;   // buckets per wave
+    if (slots <= 64) fps_owner_launch_g<1>(mode, b, a, stream);
+    else if (slots <= 128) fps_owner_launch_g<2>(mode, b, a, stream);
+    else if (slots <= 192) fps_owner_launch_g<3>(mode, b, a, stream);
+    else fps_owner_launch_g<4>(mode, b, a, stream);
+    return check_launch("fps_bucket_owner_kernel");
 }
 
 #define TGN_FPS_BUCKET_CONFIGS(X) X(256, 8) X(256, 16) X(512, 16) X(512, 24) X(512, 32) X(512, 48) X(512, 56)

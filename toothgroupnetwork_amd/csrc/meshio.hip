@@ -49,30 +49,27 @@ static size_t split_ws(const char *s, const char *e, Tok *out, size_t cap) {
 
 static bool parse_double(const Tok &t, double *v) {
     if (t.n == 0 || t.n > 400) return false;
-    // plain decimal tokens (every coordinate of a real scan): std::from_chars is correctly rounded like float() / strtod and
-    // does not go through the locale.  Anything else ("inf", "nan", ...) takes the strtod path below.
-    {
-        const char *b = t.p, *e = t.p + t.n;
-        bool plain = true;
-        for (const char *c = b; c < e; ++c)
-            if (!((*c >= '0' && *c <= '9') || *c == '.' || *c == '-' || *c == '+' || *c == 'e' || *c == 'E')) plain = false;
-        if (plain) {
-            if (*b == '+') {
-                ++b;
-                if (b < e && (*b == '-' || *b == '+')) return false;
-            }
-            double r;
-            const auto res = std::from_chars(b, e, r);
-            if (res.ec == std::errc() && res.ptr == e) {
-                *v = r;
-                return true;
-            }
-            if (!(res.ec == std::errc::result_out_of_range && res.ptr == e)) return false;
-            // overflow / underflow: strtod's inf / 0 below
-        }
-        for (const char *c = b; c < e; ++c)
-            if (*c == 'x' || *c == 'X') return false;                                   // float() takes no hex literals
+    // Decimal tokens (every coordinate of a real scan): std::from_chars is correctly rounded like float() / strtod and does not
+    // go through the locale.  The other spellings float() takes ("inf", "nan", ...) go through strtod below.
+    const char *b = t.p, *e = t.p + t.n;
+    if (*b == '+') {
+        ++b;
+        if (b < e && (*b == '-' || *b == '+')) return false;
     }
+    char c0 = b < e ? *b : 0;
+    if (c0 == '-' && b + 1 < e) c0 = b[1];
+    if ((c0 >= '0' && c0 <= '9') || c0 == '.') {
+        double r;
+        const auto res = std::from_chars(b, e, r);
+        if (res.ec == std::errc() && res.ptr == e) {
+            *v = r;
+            return true;
+        }
+        if (!(res.ec == std::errc::result_out_of_range && res.ptr == e)) return false;   // "0x10", "1e", "1.2.3", ...
+        // overflow / underflow: strtod's inf / 0 below
+    }
+    for (const char *c = b; c < e; ++c)
+        if (*c == 'x' || *c == 'X') return false;                                       // float() takes no hex literals
     char buf[408];
     memcpy(buf, t.p, t.n);
     buf[t.n] = 0;
@@ -91,6 +88,20 @@ static bool parse_face_index(Tok t, bool cut, long long *v) {
             }
     }
     if (t.n == 0 || t.n > 60) return false;
+    {   // [+-]digits, at most 18 of them: what every face of a real scan is
+        const char *c = t.p, *e = t.p + t.n;
+        const bool neg = *c == '-';
+        if (*c == '-' || *c == '+') ++c;
+        if (c < e && e - c <= 18) {
+            long long r = 0;
+            for (; c < e && *c >= '0' && *c <= '9'; ++c) r = r * 10 + (*c - '0');
+            if (c == e) {
+                *v = neg ? -r : r;
+                return true;
+            }
+            return false;   // a non-digit: int() raises
+        }
+    }
     char buf[64];
     memcpy(buf, t.p, t.n);
     buf[t.n] = 0;
