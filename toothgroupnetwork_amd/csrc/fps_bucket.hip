@@ -525,7 +525,6 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kStreamThreads = 1024;
 constexpr int kStreamMaxBuckets = 4096;           // 262 144 points
-constexpr int kStreamCells = 32768;
 
 __host__ __device__ inline size_t fps_stream_cloud_bytes(int n_max) {
     const size_t npad = ((size_t)n_max + 63) / 64 * 64;
@@ -549,12 +548,12 @@ __device__ __forceinline__ int fps_owner_bucket(int wave, int slot) {
     return slot * NW + (wave ^ ((slot ^ (slot >> 4)) & (NW - 1)));
 }
 
-template <int MODE, int G>
-__global__ __launch_bounds__(kStreamThreads) void fps_bucket_owner_kernel(FpsArgs a) {
+template <int MODE, int G, int NT = kStreamThreads, int CB = 5>
+__global__ __launch_bounds__(NT) void fps_bucket_owner_kernel(FpsArgs a) {
     constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0, CERT = (MODE & kFpsModeCert) != 0;
-    constexpr int NT = kStreamThreads, NW = NT / kWave;
-    static_assert(NW == 16 && G >= 1 && G <= 4, "16 waves x G x 64 buckets");
-    __shared__ unsigned lds[kStreamCells];   // 128 KiB: cell histogram during set-up, then the parked result rows
+    constexpr int NW = NT / kWave, kCells = 1 << (3 * CB);
+    static_assert((NW == 16 || NW == 8) && G >= 1 && G <= 4 && kCells % NT == 0 && kCells >= 4 * NT, "NW waves x G x 64 buckets");
+    __shared__ unsigned lds[kCells];         // (128 KiB at CB = 5) cell histogram during set-up, then the parked result rows
     __shared__ float red[6][NW];
     __shared__ int wave_tot[NW];
     __shared__ float4 hand[2][NW][2];        // per wave: {value bits, tie key} and {x, y, z} of its candidate
@@ -564,7 +563,7 @@ __global__ __launch_bounds__(kStreamThreads) void fps_bucket_owner_kernel(FpsArg
     int start_n, n, start_m, m;
     fps_segment(a, blockIdx.x, start_n, n, start_m, m);
     if (m <= 0) return;
-    if (fps_prefix_shortcut<kStreamThreads>(a, blockIdx.x, start_n, n, start_m, m)) return;
+    if (fps_prefix_shortcut<NT>(a, blockIdx.x, start_n, n, start_m, m)) return;
     FpsPrefixCert cert;
     const float *__restrict__ base = a.xyz + (size_t)start_n * 3;
     const int log2bs = a.ref_log2_block;
@@ -597,7 +596,7 @@ __global__ __launch_bounds__(kStreamThreads) void fps_bucket_owner_kernel(FpsArg
             }
         }
     }
-    for (int i = tid; i < kStreamCells; i += NT) lds[i] = 0;
+    for (int i = tid; i < kCells; i += NT) lds[i] = 0;
     __syncthreads();
     float glo[3], gscale[3];
 #pragma unroll
@@ -609,14 +608,14 @@ __global__ __launch_bounds__(kStreamThreads) void fps_bucket_owner_kernel(FpsArg
         }
         const float ext = h - l;
         glo[c] = l;
-        gscale[c] = (ext > 0.0f && ext < 3.0e38f) ? 32.0f / ext : 0.0f;
+        gscale[c] = (ext > 0.0f && ext < 3.0e38f) ? (float)(1 << CB) / ext : 0.0f;
     }
     auto cell_of = [&](int i) -> unsigned {
         unsigned cc[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float t = (base[(size_t)i * 3 + c] - glo[c]) * gscale[c];
-            t = fminf(fmaxf(t, 0.0f), 31.0f);  // NaN -> 0
+            t = fminf(fmaxf(t, 0.0f), (float)((1 << CB) - 1));  // NaN -> 0
             cc[c] = (unsigned)(int)t;
         }
         return spread5(cc[0]) | (spread5(cc[1]) << 1) | (spread5(cc[2]) << 2);
@@ -626,7 +625,7 @@ __global__ __launch_bounds__(kStreamThreads) void fps_bucket_owner_kernel(FpsArg
     for (int i = tid; i < n; i += NT) atomicAdd(&lds[cell_of(i)], 1u);
     __syncthreads();
     {
-        constexpr int PER = kStreamCells / NT;  // 32 cells per thread
+        constexpr int PER = kCells / NT;  // cells per thread
         unsigned local[PER];
         unsigned sum = 0;
 #pragma unroll
@@ -848,11 +847,17 @@ __global__ __launch_bounds__(kStreamThreads) void fps_bucket_owner_kernel(FpsArg
         wr_off ^= kRecParity;
         const unsigned vb = r0.x;
         unsigned mb = vb;
-        asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
-                     : "+v"(mb));
+        if constexpr (NW == 8)
+            asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                         : "+v"(mb));
+        else
+            asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                         : "+v"(mb));
         mb = (unsigned)__builtin_amdgcn_readlane((int)mb, NW - 1);
         if constexpr (CERT) cert.update(mb);
         const unsigned long long wmask = ballot64(vb == mb) & ((1ull << NW) - 1ull);  // lanes 0..NW-1 hold the records
