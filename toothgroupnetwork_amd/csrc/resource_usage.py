@@ -6,7 +6,7 @@ import sys
 
 src = sys.argv[1]
 out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
-                      "-munsafe-fp-atomics", "-ffp-contract=off", "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"],
+                      "-munsafe-fp-atomics", "-ffp-contract=off", "-Rpass-analysis=kernel-resource-usage", *sys.argv[2:], "-c", src, "-o", "/dev/null"],
                      capture_output=True, text=True).stderr
 cur = None
 rows = []
