@@ -25,6 +25,8 @@ variants = ([(1, -1, 0)] + [(2, p, mb) for p in (2, 16) for mb in (0, 1024, 512)
             + [(7, p, mb) for p in (0, 2, 16) for mb in (0, 1024, 256)])
 if len(sys.argv) > 1 and sys.argv[1] == "pairs":   # level 1: the pairs kernel (impl 10) against the per-element / staged kernels
     variants = [(1, -1, 0), (2, 16, 0)] + [(10, p, mb) for p in (16, 0, 2) for mb in (0, 2048, 1024, 512, 256)]
+if len(sys.argv) > 1 and sys.argv[1] == "rows":    # the row-piece kernel only: nt / write-through stores, whole chip / the grid it gets beside FPS
+    variants = [(7, p, mb) for p in (2, 16) for mb in (0, 256)]
 print(f"{'impl':>4} {'pol':>3} {'maxb':>5} | " + " | ".join(f"L{i + 1} ms   GB/s" for i in range(3)))
 for impl, pol, mb in variants:
     row = []
