@@ -71,6 +71,8 @@ class _LatentMLP(nn.Module):
         self.infer = nn.Sequential(nn.Linear(fdim, d_out), nn.BatchNorm1d(d_out), nn.ReLU(inplace=True))
 
     def forward(self, x):
+        if PT._frozen(self, x) and x.dtype == torch.float32:
+            return PT.mlp_eval(self.infer, x)
         return self.infer(x)
 
 

@@ -20,9 +20,10 @@ Same constructor signatures, sub-module and parameter names as the reference cla
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.autograd import Function
 
-from . import _lib, pointops
+from . import _derived, _lib, pointops
 from ._lib import check, lib, ptr, stream
 
 _fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
@@ -144,10 +145,45 @@ def _bn_scale_shift(bn):
     return s, (bn.bias.detach() - bn.running_mean * s).float()
 
 
+def folded_linear(lin, bn):
+    """(W', b') with eval-mode `bn` folded into `lin`: bn(lin(x)) == x @ W'.T + b'; memoised on `bn`."""
+    def fold():
+        s, t = _bn_scale_shift(bn)
+        W = (lin.weight.detach().float() * s[:, None]).contiguous()
+        b = t if lin.bias is None else lin.bias.detach().float() * s + t
+        return W, b.contiguous()
+    return _derived.cached(bn, "folded_linear", _derived.sources(lin, bn), None, fold)
+
+
+def mlp_eval(seq, x):
+    """nn.Sequential of Linear / BatchNorm1d / ReLU in eval mode with every BatchNorm that follows a Linear folded into it (one GEMM
+    with bias instead of GEMM + normalisation) and the ReLUs in place."""
+    layers = list(seq)
+    i = 0
+    while i < len(layers):
+        m = layers[i]
+        if isinstance(m, nn.Linear) and i + 1 < len(layers) and isinstance(layers[i + 1], nn.BatchNorm1d):
+            x = F.linear(x, *folded_linear(m, layers[i + 1]))
+            i += 2
+        elif isinstance(m, nn.ReLU):
+            x = torch.relu_(x) if not x.requires_grad else torch.relu(x)
+            i += 1
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
 def fold_pt_layer(layer):
-    """Operands of tgn_pt_attention_forward from a PointTransformerLayer in eval mode (include/tgn_pointops.h)."""
+    """Operands of tgn_pt_attention_forward from a PointTransformerLayer in eval mode (include/tgn_pointops.h); memoised on the
+    layer until one of its parameters / running statistics changes (_derived.cached)."""
     lp0, bnp, lp3 = layer.linear_p[0], layer.linear_p[1], layer.linear_p[3]
     bnw0, lw2, bnw3, lw5 = layer.linear_w[0], layer.linear_w[2], layer.linear_w[3], layer.linear_w[5]
+    return _derived.cached(layer, "pt_attention", _derived.sources(lp0, bnp, lp3, bnw0, lw2, bnw3, lw5), None,
+                           lambda: _fold_pt_layer(lp0, bnp, lp3, bnw0, lw2, bnw3, lw5))
+
+
+def _fold_pt_layer(lp0, bnp, lp3, bnw0, lw2, bnw3, lw5):
     sp, tp = _bn_scale_shift(bnp)
     a1, t1 = _bn_scale_shift(bnw0)
     s3, t3 = _bn_scale_shift(bnw3)
@@ -244,6 +280,8 @@ class TransitionDown(nn.Module):
     def forward(self, pxo):
         p, x, o = pxo  # (n, 3), (n, c), (b)
         if self.stride == 1:
+            if _frozen(self, x) and x.dtype == torch.float32:
+                return [p, torch.relu_(F.linear(x, *folded_linear(self.linear, self.bn))), o]
             return [p, self.relu(self.bn(_lin(self.linear, x))), o]
         pre, self._presampled = getattr(self, "_presampled", None), None
         if pre is not None and pre[0] is p and pre[1] is o:
@@ -257,17 +295,21 @@ class TransitionDown(nn.Module):
         if _frozen(self, p, x) and self.nsample <= 64 and C1 % 4 == 0 and x.dtype == torch.float32:
             # the whole down-sampling step fused: (m, nsample, 3+c) is never built (blocks.py:71-73)
             kidx = pointops.knn_indices(self.nsample, p, n_p, o, n_o)
-            s, t = _bn_scale_shift(self.bn)
-            W = self.linear.weight.detach().float()                        # (C1, 3+c), columns [xyz, features] (use_xyz=True)
-            Wt = torch.cat([W[:, 3:], W[:, :3]], 1).mul(s[:, None]).t().contiguous()   # rows [features..., x, y, z]
             n, c = x.shape
             m = n_p.shape[0]
+
+            def fold():
+                s, t = _bn_scale_shift(self.bn)
+                W = self.linear.weight.detach().float()                    # (C1, 3+c), columns [xyz, features] (use_xyz=True)
+                Wt = torch.cat([W[:, 3:], W[:, :3]], 1).mul(s[:, None]).t().contiguous()   # rows [features..., x, y, z]
+                return Wt, Wt[c:].contiguous(), t.contiguous()
+            Wt, Wxyz, t = _derived.cached(self, "down", _derived.sources(self.linear, self.bn), c, fold)
             A = torch.empty(n, C1, dtype=torch.float32, device=x.device)
             L = lib()
             check(L.tgn_sa_point_transform(n, c, C1, ptr(p.contiguous()), ptr(x.contiguous()), ptr(Wt), ptr(A), stream()),
                   "sa_point_transform")
             out = torch.empty(m, C1, dtype=torch.float32, device=x.device)
-            check(L.tgn_sa_gather_max(1, n, m, self.nsample, C1, ptr(A), ptr(n_p), ptr(Wt[c:].contiguous()), ptr(t.contiguous()),
+            check(L.tgn_sa_gather_max(1, n, m, self.nsample, C1, ptr(A), ptr(n_p), ptr(Wxyz), ptr(t),
                                       ptr(kidx), 0, 1, ptr(out), stream()), "sa_gather_max")
             return [n_p, out, n_o]
         x = pointops.queryandgroup(self.nsample, p, n_p, x, None, o, n_o, use_xyz=True)  # (m, nsample, 3+c)
@@ -295,9 +337,13 @@ class TransitionUp(nn.Module):
                                           output_size=x.shape[0])   # (the size is known: no device->host round trip)
             cnt = torch.diff(o, prepend=o.new_zeros(1)).to(x.dtype).unsqueeze(1)
             mean = torch.zeros(o.shape[0], x.shape[1], dtype=x.dtype, device=x.device).index_add_(0, seg, x) / cnt
+            if _frozen(self, x) and x.dtype == torch.float32:
+                return mlp_eval(self.linear1, torch.cat((x, mlp_eval(self.linear2, mean)[seg]), 1))
             return self.linear1(torch.cat((x, self.linear2(mean)[seg]), 1))
         p1, x1, o1 = pxo1
         p2, x2, o2 = pxo2
+        if _frozen(self, x1, x2) and x1.dtype == torch.float32 and x2.dtype == torch.float32:
+            return mlp_eval(self.linear1, x1).add_(pointops.interpolation(p2, p1, mlp_eval(self.linear2, x2).contiguous(), o2, o1))
         return self.linear1(x1) + pointops.interpolation(p2, p1, self.linear2(x2).contiguous(), o2, o1)
 
 
@@ -317,6 +363,12 @@ class PointTransformerBlock(nn.Module):
     def forward(self, pxo):
         p, x, o = pxo
         identity = x
+        if _frozen(self, x) and x.dtype == torch.float32:
+            # eval: bn1 / bn3 folded into their linears (a GEMM with bias each), bn2 one fused normalisation kernel
+            x = torch.relu_(F.linear(x, *folded_linear(self.linear1, self.bn1)))
+            x = torch.relu_(self.bn2(self.transformer2([p, x, o])))
+            x = F.linear(x, *folded_linear(self.linear3, self.bn3)).add_(identity)
+            return [p, torch.relu_(x), o]
         x = self.relu(self.bn1(_lin(self.linear1, x)))
         x = self.relu(self.bn2(self.transformer2([p, x, o])))
         x = self.bn3(_lin(self.linear3, x))

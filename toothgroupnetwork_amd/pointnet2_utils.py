@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.autograd import Function
 
-from . import _lib
+from . import _derived, _lib
 from . import _fps_prefix
 from ._fps_prefix import PrefixBook
 from ._lib import as_int, check, lib, ptr, require_cuda, stream
@@ -422,7 +422,13 @@ def fold_first_layer(conv, bn, D, xyz_first):
       Wt  (D+3, C1) rows [features..., x, y, z]   -- tgn_sa_point_transform
       Wxs (3, C1)   the x, y, z rows of Wt        -- centre term of tgn_sa_gather_max / tgn_sa_gather_act
       Wd  (16, C1)  rows [x, y, z, features..., 0] -- tgn_sa_direct_max
-      b2  (C1,)"""
+      b2  (C1,)
+    Memoised on `bn` until a parameter / running statistic of the two modules changes (_derived.cached)."""
+    return _derived.cached(bn, "first_layer", _derived.sources(conv, bn), (D, bool(xyz_first)),
+                           lambda: _fold_first_layer(conv, bn, D, xyz_first))
+
+
+def _fold_first_layer(conv, bn, D, xyz_first):
     C1 = conv.out_channels
     W = conv.weight.detach().reshape(C1, -1).float()                       # (C1, 3+D) in the module's channel order
     bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(C1, device=W.device)
@@ -502,6 +508,10 @@ def fold_second_layer(conv, bn, C1p):
     """The second Conv2d(1x1) + eval-mode BatchNorm2d of a shared MLP as the operands of tgn_sa_mlp2_max:
       W2f (C1p/8, C2, 8): W2f[kb, c, i] = scale[c] * W[c, 8*kb + i], zero for the padded input channels
       b2  (C2,)          = shift + scale * bias"""
+    return _derived.cached(bn, "second_layer", _derived.sources(conv, bn), C1p, lambda: _fold_second_layer(conv, bn, C1p))
+
+
+def _fold_second_layer(conv, bn, C1p):
     C2, C1 = conv.out_channels, conv.in_channels
     W = conv.weight.detach().reshape(C2, C1).float()
     bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(C2, device=W.device)
@@ -531,22 +541,24 @@ def sa_level_mlp2_max(xyz, new_xyz, points, idx, convs, bns, xyz_first, out=None
     B, N, _ = xyz.shape
     _, S, K = idx.shape
     D = 0 if points is None else points.shape[2]
-    f = fold_first_layer(convs[0], bns[0], D, xyz_first)
-    C1 = f["C1"]
-    C1p = (C1 + 15) // 16 * 16
-    W2f, b2 = fold_second_layer(convs[1], bns[1], C1p)
+    L = lib()
+    direct = bool(L.tgn_sa_mlp2_direct_supported(K, D))
+
+    def operands():   # (memoised on the second BatchNorm: ~40 small launches per branch otherwise, every forward)
+        f = fold_first_layer(convs[0], bns[0], D, xyz_first)
+        C1p = (f["C1"] + 15) // 16 * 16
+        W2f, b2 = fold_second_layer(convs[1], bns[1], C1p)
+        return dict(C1p=C1p, W2f=W2f, b2=b2, b1=_pad_cols(f["b2"], C1p),
+                    W1=_pad_cols(f["Wd"] if direct else f["Wxs"], C1p),      # direct: (16, C1p) rows [x, y, z, features..., 0]
+                    Wt=None if direct else _pad_cols(f["Wt"], C1p))
+    ops = _derived.cached(bns[1], "mlp2", _derived.sources(convs[0], bns[0], convs[1], bns[1]), (D, bool(xyz_first), direct), operands)
+    C1p, W2f, b2, b1, W1 = ops["C1p"], ops["W2f"], ops["b2"], ops["b1"], ops["W1"]
     C2 = b2.shape[0]
     idx = idx.contiguous()
     if out is None:
         out = torch.empty(B, S, C2, dtype=torch.float32, device=xyz.device)
     assert out.shape == (B, S, C2) and out.stride(2) == 1 and out.stride(0) == S * out.stride(1) and out.dtype == torch.float32
-    L = lib()
-    b1 = _pad_cols(f["b2"], C1p)
-    if L.tgn_sa_mlp2_direct_supported(K, D):
-        A1, W1 = None, _pad_cols(f["Wd"], C1p)                       # (16, C1p): rows [x, y, z, features..., 0]
-    else:
-        A1 = sa_point_transform(xyz, points, _pad_cols(f["Wt"], C1p))    # (B, N, C1p)
-        W1 = _pad_cols(f["Wxs"], C1p)
+    A1 = None if direct else sa_point_transform(xyz, points, ops["Wt"])      # (B, N, C1p)
     _lib.begin_index_check()
     check(L.tgn_sa_mlp2_max(B, N, S, K, D, C1p, C2, ptr(A1), ptr(xyz), ptr(points), ptr(new_xyz), ptr(W1), ptr(b1), ptr(idx),
                             int(idx.dtype == torch.int64), ptr(W2f), ptr(b2), ptr(out), out.stride(1), stream()), "sa_mlp2_max")
