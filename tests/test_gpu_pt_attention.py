@@ -235,3 +235,41 @@ def test_tall_narrow_weight_gradient_kernel(dev, rows, cin, cout):
     for got, want, what in ((gw, gy64.t() @ x64, "dW"), (gb, gy64.sum(0), "db"), (gx, gy64 @ w64, "dx")):
         scale = float(want.abs().max())
         assert float((got.double() - want).abs().max()) <= 2e-5 * max(scale, 1.0) * max(1.0, (rows / 24000) ** 0.5), what
+
+
+@pytest.mark.gpu
+def test_fused_eval_block_follows_weight_updates(dev):
+    """The eval block memoises its folded operands (toothgroupnetwork_amd/_derived.py): after an optimiser-style in-place update,
+    a load_state_dict and a change of the BatchNorm statistics it must give what the unfolded composition gives."""
+    from toothgroupnetwork_amd import point_transformer as PT, synth
+    torch.manual_seed(5)
+    blk = PT.PointTransformerBlock(32, 32, 8, 16).to(dev).eval()
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    p = torch.from_numpy(synth.arch_cloud(3000, seed=2, with_normals=False)).to(dev)
+    x = torch.randn(3000, 32, device=dev)
+    o = torch.tensor([3000], dtype=torch.int32, device=dev)
+
+    def both():
+        with torch.no_grad():
+            fused = blk([p, x, o])[1]
+        for q in blk.parameters():
+            q.requires_grad_(True)
+        ref = blk([p, x, o])[1].detach()                                       # grad enabled + trainable parameters: composition
+        return fused, ref
+    a, b = both()
+    close(a.cpu().numpy(), b.cpu().numpy(), "fused eval block vs composition", tol=2e-5)
+    with torch.no_grad():
+        for q in blk.parameters():
+            q.mul_(1.05)                                                       # in-place, like an optimiser step
+        blk.bn1.running_mean.add_(0.3)
+        blk.transformer2.linear_w[0].running_var.mul_(1.2)
+    a2, b2 = both()
+    assert (a2 - a).abs().max().item() > 1e-3                                  # the outputs did change
+    close(a2.cpu().numpy(), b2.cpu().numpy(), "after in-place updates", tol=2e-5)
+    sd = {k: (v * 0.9 if v.is_floating_point() else v) for k, v in blk.state_dict().items()}
+    blk.load_state_dict(sd)
+    a3, b3 = both()
+    close(a3.cpu().numpy(), b3.cpu().numpy(), "after load_state_dict", tol=2e-5)

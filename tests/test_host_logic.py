@@ -199,3 +199,40 @@ def test_fused_plan_shapes_and_algorithmic_bytes():
     # level 3, both branches: indices + inputs + centres + the (S, 1024) output each
     assert per[2]["group"] == sum(4 * 256 * k + 4 * 512 * 1027 + 12 * 256 + 4 * 256 * 1024 for k in (32, 64))
     assert total == 15687936
+
+
+def test_derived_operand_memo_follows_the_parameters():
+    """_derived.cached: the folded operands of the fused eval paths are rebuilt exactly when a source tensor is written in place
+    (optimiser step, load_state_dict, BatchNorm statistics), replaced, or the shape parameters of the derivation change."""
+    import torch
+    import torch.nn as nn
+    from toothgroupnetwork_amd import _derived, point_transformer as PT
+    lin, bn = nn.Linear(8, 5, bias=False), nn.BatchNorm1d(5).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.normal_()
+        bn.bias.normal_()
+        x = torch.randn(11, 8)
+        W, b = PT.folded_linear(lin, bn)
+        assert torch.allclose(torch.nn.functional.linear(x, W, b), bn(lin(x)), atol=1e-6)
+        assert PT.folded_linear(lin, bn)[0] is W                               # hit
+        bn.running_mean.add_(1.0)                                              # in-place write: version counter
+        W2, b2 = PT.folded_linear(lin, bn)
+        assert W2 is not W and torch.allclose(torch.nn.functional.linear(x, W2, b2), bn(lin(x)), atol=1e-6)
+        lin.load_state_dict({"weight": torch.randn(5, 8)})                     # copy_ into the parameter
+        W3, b3 = PT.folded_linear(lin, bn)
+        assert W3 is not W2 and torch.allclose(torch.nn.functional.linear(x, W3, b3), bn(lin(x)), atol=1e-6)
+        lin.weight = nn.Parameter(lin.weight.detach().clone() * 2)             # replaced: identity
+        W4, b4 = PT.folded_linear(lin, bn)
+        assert W4 is not W3 and torch.allclose(torch.nn.functional.linear(x, W4, b4), bn(lin(x)), atol=1e-5)
+    calls = []
+    build = lambda: calls.append(1) or len(calls)
+    assert _derived.cached(bn, "t", [bn.weight], 3, build) == 1 and _derived.cached(bn, "t", [bn.weight], 3, build) == 1
+    assert _derived.cached(bn, "t", [bn.weight], 4, build) == 2                # other shape parameters
+    with torch.inference_mode():
+        t = torch.ones(3)                                                      # no version counter: not memoised
+        assert _derived.cached(bn, "u", [t], None, build) == 3 and _derived.cached(bn, "u", [t], None, build) == 4
+    seq = nn.Sequential(nn.Linear(8, 8), nn.BatchNorm1d(8), nn.ReLU(inplace=True), nn.Linear(8, 4)).eval()
+    with torch.no_grad():
+        assert torch.allclose(PT.mlp_eval(seq, x.clone()), seq(x.clone()), atol=1e-6)
