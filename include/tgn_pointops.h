@@ -317,6 +317,23 @@ int tgn_sa_mlp2_max(int B, int N, int S, int K, int D, int C1p, int C2, const fl
 long long tgn_linear_wgrad_slices(long long rows);
 int tgn_linear_wgrad_partials(long long rows, int cin, int cout, const float *x, const float *gy, float *part, float *bpart,
                               tgn_stream_t stream);
+
+/*
+ * Training-mode BatchNorm1d over the rows of x (rows, C), optionally fused with the ReLU that follows it: the normalisations of
+ * the Point-Transformer training path (blocks.py:37,40 via nn.BatchNorm1d; this package normalises the flattened (n * nsample, c)
+ * rows).  forward: batch statistics in double, y = [relu]((x - mean) * invstd * gamma + beta), save_mean / save_invstd for the
+ * backward pass, running statistics updated like nn.BatchNorm1d (running = (1 - momentum) running + momentum batch, variance
+ * unbiased; NULL running pointers: not tracked), *num_batches_tracked += 1 when given.  backward: dx, dgamma, dbeta; with relu
+ * the mask is y > 0 (y = the forward output).  workspace: tgn_bn_rows_workspace_bytes(C) bytes, ZERO before the first use -- the
+ * kernels leave it zeroed, so one buffer serves every call of a layer on one stream.  rows >= 2, 1 <= C <= 1024, fp32, contiguous.
+ */
+size_t tgn_bn_rows_workspace_bytes(int C);
+int tgn_bn_rows_forward(long long rows, int C, const float *x, const float *gamma, const float *beta, float eps, float momentum,
+                        float *running_mean, float *running_var, long long *num_batches_tracked, int relu, float *y,
+                        float *save_mean, float *save_invstd, void *workspace, tgn_stream_t stream);
+int tgn_bn_rows_backward(long long rows, int C, const float *x, const float *y, const float *dy, const float *gamma,
+                         const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma, float *dbeta,
+                         void *workspace, tgn_stream_t stream);
 /* index_points (pointnet2_utils.py:44-61): out[b,j,:] = points[b, idx[b,j], :], idx flattened to (B,M). */
 int tgn_gather_points(int B, int N, int M, int C, const float *points, const void *idx, int idx_is_int64, float *out,
                       tgn_stream_t stream);

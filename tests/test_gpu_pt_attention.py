@@ -273,3 +273,47 @@ def test_fused_eval_block_follows_weight_updates(dev):
     blk.load_state_dict(sd)
     a3, b3 = both()
     close(a3.cpu().numpy(), b3.cpu().numpy(), "after load_state_dict", tol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,C,relu", [(2, 3, True), (7, 4, False), (1000, 3, True), (4097, 32, True), (100000, 32, False),
+                                         (864000, 4, True), (375, 512, True), (93, 1000, False), (5000, 100, True)])
+def test_fused_batchnorm_rows_matches_torch(dev, rows, C, relu):
+    """csrc/bnorm.hip (training-mode BatchNorm1d over rows, optionally with the ReLU behind it) against nn.BatchNorm1d + F.relu in
+    float64: output, the three gradients, the running statistics and the batch counter."""
+    from toothgroupnetwork_amd import point_transformer as PT
+    torch.manual_seed(rows + C)
+    x = (torch.randn(rows, C, device=dev) * torch.linspace(0.5, 3.0, C, device=dev) + torch.linspace(-2.0, 5.0, C, device=dev)).contiguous()
+    dy = torch.randn(rows, C, device=dev)
+    bn = torch.nn.BatchNorm1d(C).to(dev).train()
+    ref = torch.nn.BatchNorm1d(C).to(dev).double().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2.0)
+        ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    for step in range(2):                                                     # twice: the workspace must come back zeroed
+        xg = x.clone().requires_grad_(True)
+        y = PT.bn_rows(bn, xg, relu=relu)
+        assert y.grad_fn is not None and type(y.grad_fn).__name__ == "_BNRowsBackward"
+        y.backward(dy)
+        xr = x.double().requires_grad_(True)
+        yr = ref(xr)
+        yr = torch.relu(yr) if relu else yr
+        yr.backward(dy.double())
+        tol = dict(atol=2e-5, rtol=2e-5)
+        assert torch.allclose(y.double(), yr, **tol), (y.double() - yr).abs().max().item()
+        assert torch.allclose(xg.grad.double(), xr.grad, atol=5e-5 * max(1.0, xr.grad.abs().max().item()), rtol=1e-4)
+        scale = max(1.0, ref.weight.grad.abs().max().item(), ref.bias.grad.abs().max().item())
+        assert torch.allclose(bn.weight.grad.double(), ref.weight.grad, atol=1e-5 * scale * rows ** 0.5, rtol=1e-4)
+        assert torch.allclose(bn.bias.grad.double(), ref.bias.grad, atol=1e-5 * scale * rows ** 0.5, rtol=1e-4)
+        assert torch.allclose(bn.running_mean.double(), ref.running_mean, atol=1e-6, rtol=1e-6)
+        assert torch.allclose(bn.running_var.double(), ref.running_var, atol=1e-6, rtol=1e-5)
+        assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == step + 1
+        bn.zero_grad()
+        ref.zero_grad()
+    assert int(bn.__dict__["_tgn_bn_ws"].to(torch.int32).abs().sum()) == 0    # left zeroed
+    v0 = bn.running_mean._version
+    PT.bn_rows(bn, x, relu=relu)
+    assert bn.running_mean._version > v0                                      # raw-pointer update made visible to torch

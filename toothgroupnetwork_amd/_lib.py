@@ -81,6 +81,9 @@ SIGNATURES = {
     "tgn_sa_mlp2_direct_supported": (c_int, [c_int, c_int]),
     "tgn_linear_wgrad_slices": (ctypes.c_longlong, [ctypes.c_longlong]),
     "tgn_linear_wgrad_partials": (c_int, [ctypes.c_longlong, c_int, c_int, _P, _P, _P, _P, _P]),
+    "tgn_bn_rows_workspace_bytes": (c_size_t, [c_int]),
+    "tgn_bn_rows_forward": (c_int, [ctypes.c_longlong, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
+    "tgn_bn_rows_backward": (c_int, [ctypes.c_longlong, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "tgn_sa_mlp2_max": (c_int, [c_int] * 7 + [_P] * 7 + [c_int, _P, _P, _P, c_int, _P]),
     "tgn_sa_direct_max": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "tgn_gather_points": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P]),

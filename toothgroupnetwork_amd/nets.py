@@ -73,7 +73,7 @@ class _LatentMLP(nn.Module):
     def forward(self, x):
         if PT._frozen(self, x) and x.dtype == torch.float32:
             return PT.mlp_eval(self.infer, x)
-        return self.infer(x)
+        return PT.mlp_train(self.infer, x)
 
 
 class MultiHead(nn.Module):

@@ -18,6 +18,8 @@ Same constructor signatures, sub-module and parameter names as the reference cla
 ``PointTransformerUNet`` strings them together the way ``PointTransformerSeg.forward`` does
 (cbl_point_transformer_module.py:93-160) for the forward benchmark of BASELINE.json config 4 (tools/pt_forward_bench.py).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -122,6 +124,58 @@ class _LinearSplitK(Function):
 SPLITK_MIN_ROWS = 4096
 
 
+class _BNRows(Function):
+    """Training-mode nn.BatchNorm1d over the rows of x (rows, C) [+ ReLU]: two launches forward, two backward
+    (csrc/bnorm.hip) instead of torch's five-odd per normalisation and direction -- the tgnet_fps step has 124 of them, most on
+    small deep-stage tensors.  Running statistics and num_batches_tracked are updated by the kernel like the module would."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, relu):
+        rows, C = x.shape
+        y = torch.empty_like(x)
+        stat = torch.empty(2, C, dtype=torch.float32, device=x.device)             # batch mean, 1 / sqrt(var + eps)
+        mean, invstd = stat[0], stat[1]
+        ws = bn.__dict__.get("_tgn_bn_ws")
+        if ws is None or ws.device != x.device:
+            ws = bn.__dict__["_tgn_bn_ws"] = torch.zeros(int(lib().tgn_bn_rows_workspace_bytes(C)), dtype=torch.uint8, device=x.device)
+        track = bn.track_running_stats and bn.running_mean is not None
+        check(lib().tgn_bn_rows_forward(rows, C, ptr(x), ptr(weight), ptr(bias), float(bn.eps), float(bn.momentum),
+                                        ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                                        ptr(bn.num_batches_tracked) if track and bn.num_batches_tracked is not None else None,
+                                        int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(ws), stream()), "bn_rows_forward")
+        if track:   # written through raw pointers: tell torch (the fold memo of the eval paths keys on these counters)
+            for t in (bn.running_mean, bn.running_var, bn.num_batches_tracked):
+                if t is not None:
+                    torch.autograd.graph.increment_version(t)
+        ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
+        ctx.relu, ctx.ws = bool(relu), ws
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        rows, C = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dwb = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        dgamma, dbeta = dwb[0], dwb[1]
+        check(lib().tgn_bn_rows_backward(rows, C, ptr(x), ptr(y), ptr(dy), ptr(weight), ptr(mean), ptr(invstd), int(ctx.relu),
+                                         ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ctx.ws), stream()), "bn_rows_backward")
+        return dx, dgamma, dbeta, None, None
+
+
+BN_ROWS = os.environ.get("TGN_BN_ROWS", "1") != "0"
+
+
+def bn_rows(bn, x, relu=False):
+    """[relu](bn(x)) for x (rows, C): the fused kernels in training mode on fp32 CUDA rows, the module otherwise."""
+    if (BN_ROWS and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 2 and x.shape[1] <= 1024
+            and bn.affine and bn.momentum is not None and x.is_contiguous() and not torch.is_autocast_enabled()):
+        return _BNRows.apply(x, bn.weight, bn.bias, bn, relu)
+    y = bn(x)
+    return F.relu(y) if relu else y
+
+
 def _lin(mod, x):
     """nn.Linear `mod` applied to x; tall inputs in training take the split-K weight gradient."""
     if torch.is_grad_enabled() and x.numel() // x.shape[-1] >= SPLITK_MIN_ROWS and max(mod.in_features, mod.out_features) <= 256:
@@ -134,10 +188,26 @@ def _mlp_rows(seq, t):
     all n * nsample rows -- what the reference gets by transposing to (n, c, nsample) and back (blocks.py:37, 40) -- on the
     FLATTENED (n * nsample, c) view, without the two transposed copies per BatchNorm."""
     n, ns = t.shape[0], t.shape[1]
-    t = t.reshape(n * ns, -1)
-    for layer in seq:
-        t = _lin(layer, t) if isinstance(layer, nn.Linear) else layer(t)
-    return t.view(n, ns, -1)
+    return mlp_train(seq, t.reshape(n * ns, -1)).view(n, ns, -1)
+
+
+def mlp_train(seq, t):
+    """nn.Sequential of Linear / BatchNorm1d / ReLU on rows t (rows, c): tall linears through the split-K weight gradient, every
+    BatchNorm (with the ReLU behind it) through the fused row kernels."""
+    layers = list(seq)
+    i = 0
+    while i < len(layers):
+        m = layers[i]
+        if isinstance(m, nn.Linear):
+            t = _lin(m, t)
+        elif isinstance(m, nn.BatchNorm1d):
+            fuse = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)
+            t = bn_rows(m, t, relu=fuse)
+            i += 1 if fuse else 0
+        else:
+            t = m(t)
+        i += 1
+    return t
 
 
 def _bn_scale_shift(bn):
@@ -282,7 +352,7 @@ class TransitionDown(nn.Module):
         if self.stride == 1:
             if _frozen(self, x) and x.dtype == torch.float32:
                 return [p, torch.relu_(F.linear(x, *folded_linear(self.linear, self.bn))), o]
-            return [p, self.relu(self.bn(_lin(self.linear, x))), o]
+            return [p, bn_rows(self.bn, _lin(self.linear, x), relu=True), o]
         pre, self._presampled = getattr(self, "_presampled", None), None
         if pre is not None and pre[0] is p and pre[1] is o:
             # sampled ahead on a side stream (PointTransformerUNet._presample): sampling depends on the coordinates only
@@ -314,7 +384,7 @@ class TransitionDown(nn.Module):
             return [n_p, out, n_o]
         x = pointops.queryandgroup(self.nsample, p, n_p, x, None, o, n_o, use_xyz=True)  # (m, nsample, 3+c)
         m = x.shape[0]
-        x = self.relu(self.bn(_lin(self.linear, x.reshape(m * self.nsample, -1))))       # BatchNorm over all m * nsample rows (blocks.py:72)
+        x = bn_rows(self.bn, _lin(self.linear, x.reshape(m * self.nsample, -1)), relu=True)   # BatchNorm over all m * nsample rows (blocks.py:72)
         x = x.view(m, self.nsample, -1).max(1)[0]                                        # MaxPool1d(nsample) (:73) -> (m, c)
         return [n_p, x, n_o]
 
@@ -339,12 +409,12 @@ class TransitionUp(nn.Module):
             mean = torch.zeros(o.shape[0], x.shape[1], dtype=x.dtype, device=x.device).index_add_(0, seg, x) / cnt
             if _frozen(self, x) and x.dtype == torch.float32:
                 return mlp_eval(self.linear1, torch.cat((x, mlp_eval(self.linear2, mean)[seg]), 1))
-            return self.linear1(torch.cat((x, self.linear2(mean)[seg]), 1))
+            return mlp_train(self.linear1, torch.cat((x, mlp_train(self.linear2, mean)[seg]), 1))
         p1, x1, o1 = pxo1
         p2, x2, o2 = pxo2
         if _frozen(self, x1, x2) and x1.dtype == torch.float32 and x2.dtype == torch.float32:
             return mlp_eval(self.linear1, x1).add_(pointops.interpolation(p2, p1, mlp_eval(self.linear2, x2).contiguous(), o2, o1))
-        return self.linear1(x1) + pointops.interpolation(p2, p1, self.linear2(x2).contiguous(), o2, o1)
+        return mlp_train(self.linear1, x1) + pointops.interpolation(p2, p1, mlp_train(self.linear2, x2).contiguous(), o2, o1)
 
 
 class PointTransformerBlock(nn.Module):
@@ -369,9 +439,9 @@ class PointTransformerBlock(nn.Module):
             x = torch.relu_(self.bn2(self.transformer2([p, x, o])))
             x = F.linear(x, *folded_linear(self.linear3, self.bn3)).add_(identity)
             return [p, torch.relu_(x), o]
-        x = self.relu(self.bn1(_lin(self.linear1, x)))
-        x = self.relu(self.bn2(self.transformer2([p, x, o])))
-        x = self.bn3(_lin(self.linear3, x))
+        x = bn_rows(self.bn1, _lin(self.linear1, x), relu=True)
+        x = bn_rows(self.bn2, self.transformer2([p, x, o]), relu=True)
+        x = bn_rows(self.bn3, _lin(self.linear3, x))
         x = x + identity
         return [p, self.relu(x), o]
 
