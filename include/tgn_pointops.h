@@ -308,15 +308,17 @@ int tgn_sa_mlp2_max(int B, int N, int S, int K, int D, int C1p, int C2, const fl
                     const float *points, const float *new_xyz, const float *W1, const float *b1, const void *idx,
                     int idx_is_int64, const float *W2f, const float *b2, float *out, int out_stride, tgn_stream_t stream);
 /*
- * Weight gradient of a tall, narrow linear layer (training path of the Point-Transformer mirrors; blocks.py:19-30 declares the
- * layers): the rows are cut into tgn_linear_wgrad_slices(rows) slices, slice s contributes
- *   part[s][o][i] = sum_{r in slice} gy[r][o] * x[r][i]      (slices, cout, cin)
- *   bpart[s][o]   = sum_{r in slice} gy[r][o]                (slices, cout), optional (NULL to skip)
- * on the fp32 matrix cores straight from global memory; the caller sums over s.  x (rows, cin), gy (rows, cout), row-major fp32.
+ * Weight gradient of a linear layer with few columns and many (or not so many) rows -- the training path of the Point-Transformer
+ * mirrors; blocks.py:19-30 declares the layers:
+ *   dW[o][i] = sum_r gy[r][o] * x[r][i]      (cout, cin)         db[o] = sum_r gy[r][o]   (optional, NULL to skip)
+ * a contraction over the ROWS with a small result, which the BLAS libraries walk with one or two tiles (94 us for a 256 x 256
+ * gradient over 375 rows).  One wave per (row slice, 32 x 32 output tile) on the fp32 matrix cores straight from global memory,
+ * then one reduction over the slices.  x (rows, cin), gy (rows, cout), row-major fp32; workspace of
+ * tgn_linear_wgrad_workspace_bytes(rows, cin, cout) bytes.
  */
-long long tgn_linear_wgrad_slices(long long rows);
-int tgn_linear_wgrad_partials(long long rows, int cin, int cout, const float *x, const float *gy, float *part, float *bpart,
-                              tgn_stream_t stream);
+size_t tgn_linear_wgrad_workspace_bytes(long long rows, int cin, int cout);
+int tgn_linear_wgrad(long long rows, int cin, int cout, const float *x, const float *gy, float *dW, float *db, void *workspace,
+                     size_t workspace_bytes, tgn_stream_t stream);
 
 /*
  * Training-mode BatchNorm1d over the rows of x (rows, C), optionally fused with the ReLU that follows it: the normalisations of

@@ -220,10 +220,11 @@ def test_transition_down_survives_graph_replays_with_eager_work_in_between(dev):
 
 
 @pytest.mark.parametrize("rows,cin,cout", [(24000, 32, 32), (864000, 32, 4), (6000, 64, 64), (9001, 256, 32), (4097, 3, 3), (50000, 3, 64),
-                                            (12345, 35, 64), (70001, 128, 100)])
+                                            (12345, 35, 64), (70001, 128, 100), (375, 256, 256), (1500, 128, 128), (257, 200, 130),
+                                            (64, 32, 32), (3, 5, 7), (1, 40, 33)])
 def test_tall_narrow_weight_gradient_kernel(dev, rows, cin, cout):
-    """tgn_linear_wgrad_partials (row slices contracted on the fp32 matrix cores straight from global memory) through
-    _LinearSplitK: dW, db and dx against torch's own linear backward in float64."""
+    """tgn_linear_wgrad (one wave per row slice and 32 x 32 output tile on the fp32 matrix cores straight from global memory, then
+    one reduction over the slices) through _LinearSplitK: dW, db and dx against torch's own linear backward in float64."""
     from toothgroupnetwork_amd import point_transformer as PT
     g = torch.Generator(device="cpu").manual_seed(rows + cin)
     x = torch.randn(rows, cin, generator=g).to(dev).requires_grad_(True)

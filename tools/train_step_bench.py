@@ -35,6 +35,8 @@ class FirstStage(nn.Module):
 
     def forward(self, feat):   # (B, 6, N)
         x = self.unet(feat)
+        if self.training:   # heads through the same training helpers as the U-Net's MLPs (fused BatchNorm rows, sliced weight gradients)
+            return PT.mlp_train(self.offset_head, x), PT.mlp_train(self.sem_head, x)
         return self.offset_head(x), self.sem_head(x)
 
 

@@ -79,8 +79,8 @@ SIGNATURES = {
     "tgn_sa_gather_act": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "tgn_sa_direct_supported": (c_int, [c_int, c_int, c_int]),
     "tgn_sa_mlp2_direct_supported": (c_int, [c_int, c_int]),
-    "tgn_linear_wgrad_slices": (ctypes.c_longlong, [ctypes.c_longlong]),
-    "tgn_linear_wgrad_partials": (c_int, [ctypes.c_longlong, c_int, c_int, _P, _P, _P, _P, _P]),
+    "tgn_linear_wgrad_workspace_bytes": (c_size_t, [ctypes.c_longlong, c_int, c_int]),
+    "tgn_linear_wgrad": (c_int, [ctypes.c_longlong, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "tgn_bn_rows_workspace_bytes": (c_size_t, [c_int]),
     "tgn_bn_rows_forward": (c_int, [ctypes.c_longlong, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "tgn_bn_rows_backward": (c_int, [ctypes.c_longlong, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),

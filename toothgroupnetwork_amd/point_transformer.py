@@ -99,15 +99,16 @@ class _LinearSplitK(Function):
                 # one pass over gy and x on the fp32 matrix cores, a (cout, cin) partial per row slice (csrc/linear.hip); the bias
                 # gradient comes out of the same pass
                 gyc, xc = gy2.contiguous(), x2.contiguous()
-                slices = int(lib().tgn_linear_wgrad_slices(rows))
-                part = torch.empty(slices, gyc.shape[1], xc.shape[1], dtype=torch.float32, device=gy2.device)
+                cout, cin = gyc.shape[1], xc.shape[1]
+                nbytes = int(lib().tgn_linear_wgrad_workspace_bytes(rows, cin, cout))
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=gy2.device)
+                gw = torch.empty(cout, cin, dtype=torch.float32, device=gy2.device)
                 want_b = ctx.has_bias and ctx.needs_input_grad[2]
-                bpart = torch.empty(slices, gyc.shape[1], dtype=torch.float32, device=gy2.device) if want_b else None
-                check(lib().tgn_linear_wgrad_partials(rows, xc.shape[1], gyc.shape[1], ptr(xc), ptr(gyc), ptr(part), ptr(bpart), stream()),
-                      "linear_wgrad")
-                gw = part.sum(0).to(weight.dtype)
+                gb = torch.empty(cout, dtype=torch.float32, device=gy2.device) if want_b else None
+                check(lib().tgn_linear_wgrad(rows, cin, cout, ptr(xc), ptr(gyc), ptr(gw), ptr(gb), ptr(ws), nbytes, stream()), "linear_wgrad")
+                gw = gw.to(weight.dtype)
                 if want_b:
-                    gb = bpart.sum(0).to(weight.dtype)
+                    gb = gb.to(weight.dtype)
             else:                                                  # bf16 under autocast: sliced batch GEMM
                 slices = max(1, min(512, rows // 1024))
                 per = rows // slices
@@ -121,7 +122,7 @@ class _LinearSplitK(Function):
         return gx, gw, gb
 
 
-SPLITK_MIN_ROWS = 4096
+SPLITK_MIN_ROWS = 256    # (the BLAS pick for a 256 x 256 gradient over 375 rows is one 256 x 256 tile: 94 us)
 
 
 class _BNRows(Function):
