@@ -121,3 +121,41 @@ def test_label_transfer_matches_the_kdtree(dev, golden_r3):
     assert int((got != want).sum()) <= int((~unique).sum())
     one = preprocess.transfer_labels(sampled, labels, full, candidates=1)        # fp32 only: may differ at float-level near-ties
     assert (one != want).sum() <= (golden_r3["lt_gap"] < 1e-5).sum() + 2
+
+
+@pytest.mark.gpu
+def test_inference_pipeline_end_to_end(dev, tmp_path):
+    """inference.InferencePipeLine (inference_pipeline_sem.py:8-60): a synthetic 45 000-vertex OBJ through reader, normalisation,
+    FPS to 24 000, the Point-Transformer network, relabelling and label transfer.  The certificate the resampling leaves behind must
+    turn the network's first sampling level into the identity (FPS of an FPS sequence) WITHOUT changing a single label, and the
+    labels must be what the stages give when composed by hand."""
+    from toothgroupnetwork_amd import inference, nets, pointops, preprocess, resample, synth
+    path = tmp_path / "scan.obj"
+    path.write_text(synth.obj_text(300, 150, 11, "plain", with_tail=False))
+    torch.manual_seed(3)
+    net = nets.PointTransformerSeg().to(dev).eval()
+    pipe = inference.InferencePipeLine(net)
+    keep = pointops.FPS_PREFIX
+    try:
+        pointops.FPS_PREFIX = None
+        pointops.fps_prefix_clear()
+        before = dict(pointops.fps_prefix_stats)
+        with_cert = pipe(str(path))
+        assert pointops.fps_prefix_stats["offered"] > before["offered"]       # the network's first level was offered the certificate
+        pointops.FPS_PREFIX = False
+        pointops.fps_prefix_clear()
+        without = pipe(str(path))
+    finally:
+        pointops.FPS_PREFIX = keep
+    assert with_cert["sem"].shape == (45000,) and np.array_equal(with_cert["sem"], without["sem"])
+    assert set(np.unique(with_cert["sem"]).tolist()) <= set([0] + list(range(11, 19)) + list(range(21, 29)))
+    # by hand
+    feats, mesh = preprocess.read_txt_obj_ls(str(path), ret_mesh=True)
+    v = inference.normalise_for_inference(mesh["vertices"])
+    org = np.concatenate([v, mesh["vertex_normals"]], 1)
+    idx = resample.fps(org[:, :3], 24000)
+    sampled = org[idx]
+    with torch.no_grad():
+        cls = net([torch.from_numpy(sampled.astype("float32")[None]).to(dev).permute(0, 2, 1)])[0].argmax(1).reshape(-1).cpu().numpy()
+    want = preprocess.transfer_labels(sampled[:, :3], inference.fdi_from_classes(cls), org[:, :3])
+    assert np.array_equal(with_cert["sem"], want)

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""One scan through the semantic inference pipeline (toothgroupnetwork_amd/inference.py = inference_pipeline_sem.py): OBJ of ~108 000
+vertices -> labels per vertex, with a seeded Point-Transformer network; stage times, with and without the FPS-of-an-FPS-result
+shortcut between the resampling and the network's first level."""
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from toothgroupnetwork_amd import inference, nets, pointops, synth
+
+dev = torch.device("cuda")
+torch.manual_seed(0)
+path = os.path.join(tempfile.gettempdir(), "tgn_infer_scan.obj")
+with open(path, "w") as f:
+    f.write(synth.obj_text(360, 300, 7, "plain", with_tail=False))
+net = nets.PointTransformerSeg().to(dev).eval()
+pipe = inference.InferencePipeLine(net)
+for shortcut in (True, False):
+    pointops.FPS_PREFIX = None if shortcut else False
+    pointops.fps_prefix_clear()
+    out = pipe(path)                                    # warm-up (code objects, fold memo, allocator)
+    runs = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        out = pipe(path)
+        torch.cuda.synchronize()
+        runs.append((time.perf_counter() - t0, dict(pipe.times)))
+    best = min(runs, key=lambda r: r[0])
+    print(f"FPS identity between resampling and the network {'on ' if shortcut else 'off'}: {best[0] * 1e3:7.1f} ms per scan  "
+          + "  ".join(f"{k} {v * 1e3:.1f}" for k, v in best[1].items()) + f"   ({out['sem'].shape[0]} vertices, {len(np.unique(out['sem']))} labels)")

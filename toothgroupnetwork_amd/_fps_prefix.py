@@ -50,6 +50,21 @@ class PrefixBook:
                 return cert, ref
         return None, None
 
+    def adopt(self, device, from_stream, to_stream):
+        """`to_stream` has just been made to wait for `from_stream` (wait_stream / an event): results recorded on the latter may be
+        offered on the former from now on.  The copies are marked as in use on `to_stream` for the caching allocator."""
+        src, dst = from_stream.cuda_stream, to_stream.cuda_stream
+        if src == dst:
+            return
+        have = {(k, id(ref)) for k, dev, st, ref, cert in self.entries if dev == device and st == dst}
+        for k, dev, st, ref, cert in list(self.entries):
+            if dev == device and st == src and (k, id(ref)) not in have:
+                for t in (ref, cert):
+                    if t is not None:
+                        t.record_stream(to_stream)
+                self.entries.append((k, dev, dst, ref, cert))
+        del self.entries[:-2 * self.cap]
+
     def record(self, key, device, new_xyz, cert, shared):
         """Remember a result.  shared: the caller holds `new_xyz` too -- the book keeps its own copy."""
         if shared:

@@ -1,0 +1,72 @@
+"""The semantic inference pipeline around the network (inference_pipelines/inference_pipeline_sem.py:8-60), end to end on this
+package's operators: OBJ -> vertices + normals (native reader), the pipeline's own normalisation (:21-22), farthest-point sampling
+to 24 000 points (:28, "#TODO slow processing speed" there), the model, the FDI relabelling (:32-34) and the nearest-sample label
+transfer back onto every vertex (:37-39).
+
+The sampled points reach the model in FPS order, and the Point-Transformer network's first transition-down level samples them
+AGAIN (24 000 -> 6000): farthest-point sampling of an FPS sequence is the identity, so with the certificate the first launch leaves
+behind (`resample.fps(prefix=True)`) that level costs the GPU a comparison instead of its 4.8 ms chain.  (On the wall clock of ONE
+eager call nothing changes -- 11.2 against 11.5 ms for the model stage, `profiles/r03_inference_pipeline.txt`: the forward of a
+single scan is bound by the host enqueuing its ~350 launches; the saving is the GPU's, for whatever shares it.)
+
+Not covered: meshes with fewer than 24 000 vertices, which the reference subdivides with open3d (:25-26)."""
+import time
+
+import numpy as np
+import torch
+
+from . import preprocess, resample
+
+N_POINTS = 24000
+
+
+def normalise_for_inference(vertices, scaler=1.8, shifter=0.8):
+    """inference_pipeline_sem.py:21-22: centre, then map the mesh's OWN y range to [-shifter, scaler - shifter] on every axis."""
+    v = np.array(vertices, dtype=np.float64)
+    v[:, :3] -= np.mean(v[:, :3], axis=0)
+    lo, hi = np.min(v[:, 1]), np.max(v[:, 1])
+    v[:, :3] = ((v[:, :3] - lo) / (hi - lo)) * scaler - shifter
+    return v
+
+
+def fdi_from_classes(cls):
+    """classes 0..16 -> FDI-style numbers as the pipeline writes them (:32-34): 1..8 -> 11..18, 9..16 -> 21..28."""
+    cls = np.array(cls, dtype=np.int64)
+    cls[cls >= 9] += 2
+    cls[cls > 0] += 10
+    return cls
+
+
+class InferencePipeLine:
+    """Same constructor and call as the reference class: pipeline(path) -> {"sem": labels per vertex, "ins": the same}.
+    `model` maps [features (1, 6, 24000)] to a dict with "cls_pred" (the reference's model wrappers) or to a list whose first
+    entry is the class logits (B, 17, N) (nets.PointTransformerSeg).  `times` holds the stage times of the last call."""
+
+    def __init__(self, model):
+        self.model = model
+        self.scaler = 1.8
+        self.shifter = 0.8
+        self.times = {}
+
+    def __call__(self, stl_path):
+        t = [time.perf_counter()]
+        feats, mesh = preprocess.read_txt_obj_ls(stl_path, ret_mesh=True)
+        t.append(time.perf_counter())
+        vertices = normalise_for_inference(mesh["vertices"], self.scaler, self.shifter)
+        org_feats = np.concatenate([vertices, mesh["vertex_normals"]], axis=1)
+        if org_feats.shape[0] < N_POINTS:
+            raise NotImplementedError("meshes below 24 000 vertices are subdivided with open3d in the reference (inference_pipeline_sem.py:25-26)")
+        idx = resample.fps(org_feats[:, :3], N_POINTS, prefix=True)               # gen_utils.resample_pcd(..., "fps")
+        sampled_feats = org_feats[idx[:N_POINTS]]
+        t.append(time.perf_counter())
+        with torch.no_grad():
+            inp = torch.from_numpy(np.ascontiguousarray(sampled_feats.astype("float32"))[None]).cuda().permute(0, 2, 1)
+            out = self.model([inp])
+            cls_pred = out["cls_pred"] if isinstance(out, dict) else out[0]
+            cls_pred = cls_pred.argmax(dim=1).reshape(-1).cpu().numpy()
+        t.append(time.perf_counter())
+        labels = fdi_from_classes(cls_pred)
+        result = preprocess.transfer_labels(sampled_feats[:, :3], labels, org_feats[:, :3])
+        t.append(time.perf_counter())
+        self.times = dict(zip(("load", "sample", "model", "transfer"), np.diff(t).tolist()))
+        return {"sem": result.reshape(-1), "ins": result.reshape(-1)}

@@ -481,6 +481,7 @@ class PointTransformerUNet(nn.Module):
         if side is None or side.device != p.device:
             side = self._side_stream = torch.cuda.Stream(device=p.device)
         side.wait_stream(cur)
+        pointops.fps_prefix_adopt(cur, side)      # an FPS result made on `cur` (the resampling in front of the network) counts here
         with torch.cuda.stream(side):
             pp, oo = p, o
             for e in self.enc:

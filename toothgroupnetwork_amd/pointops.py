@@ -100,6 +100,12 @@ def fps_prefix_clear():
     _fps_book.clear()
 
 
+def fps_prefix_adopt(from_stream, to_stream):
+    """After `to_stream` has been made to wait for `from_stream`: FPS results recorded on the latter may serve the
+    FPS-of-an-FPS-result shortcut on the former (the side-stream sampling pyramid of the Point-Transformer U-Net)."""
+    _fps_book.adopt(from_stream.device, from_stream, to_stream)
+
+
 def fps_with_coords(xyz, offset, new_offset, cuda_compat=False, prefix=False):
     """furthestsampling that also returns the sampled coordinates xyz[idx] straight from the kernel
     (what blocks.py:69-70 computes with a second gather).  Returns (idx int32 (m,), new_xyz (m,3)).

@@ -16,8 +16,10 @@ from . import pointops
 _staging = threading.local()
 
 
-def fps(xyz, npoint):
-    """(N,>=3) array -> (npoint,) int32 indices; raises if N <= npoint like gen_utils.py:136-137."""
+def fps(xyz, npoint, prefix=False):
+    """(N,>=3) array -> (npoint,) int32 indices; raises if N <= npoint like gen_utils.py:136-137.
+    prefix=True: leave the FPS-of-an-FPS-result certificate behind (pointops.fps_with_coords) -- a network that samples the
+    returned points again (the inference pipelines feed them straight to the model) then gets its first level for free."""
     xyz = np.asarray(xyz)
     if xyz.shape[0] <= npoint:
         raise ValueError("new fps error")  # the reference does `raise "new fps error"` (a TypeError in py3)
@@ -25,7 +27,7 @@ def fps(xyz, npoint):
     pts = torch.from_numpy(np.ascontiguousarray(xyz[:, :3], dtype=np.float32)).to(dev)
     offset = torch.tensor([pts.shape[0]], dtype=torch.int32, device=dev)
     new_offset = torch.tensor([int(npoint)], dtype=torch.int32, device=dev)
-    idx = pointops.furthestsampling(pts, offset, new_offset)
+    idx = pointops.fps_with_coords(pts, offset, new_offset, prefix=True)[0] if prefix else pointops.furthestsampling(pts, offset, new_offset)
     return idx.cpu().numpy().reshape(-1)
 
 
