@@ -159,3 +159,25 @@ def test_inference_pipeline_end_to_end(dev, tmp_path):
         cls = net([torch.from_numpy(sampled.astype("float32")[None]).to(dev).permute(0, 2, 1)])[0].argmax(1).reshape(-1).cpu().numpy()
     want = preprocess.transfer_labels(sampled[:, :3], inference.fdi_from_classes(cls), org[:, :3])
     assert np.array_equal(with_cert["sem"], want)
+
+
+@pytest.mark.gpu
+def test_batched_inference_equals_the_single_scan_pipeline(dev, tmp_path):
+    """inference.infer_scans (loader threads, one FPS launch per batch, batched forward, threaded label transfer) gives every scan the
+    labels InferencePipeLine gives it alone; a ragged last batch included."""
+    from toothgroupnetwork_amd import inference, nets, synth
+    paths = []
+    for i, (nu, nv) in enumerate(((300, 150), (260, 120), (310, 100), (250, 130), (280, 140))):
+        p = tmp_path / f"scan{i}.obj"
+        p.write_text(synth.obj_text(nu, nv, 20 + i, "plain", with_tail=False))
+        paths.append(str(p))
+    torch.manual_seed(4)
+    net = nets.PointTransformerSeg().to(dev).eval()
+    one = inference.InferencePipeLine(net)
+    want = [one(p)["sem"] for p in paths]
+    got = inference.infer_scans(paths, net, batch=2, workers=3)
+    assert len(got) == len(paths)
+    for w, g in zip(want, got):
+        # batched and single forwards differ in fp32 summation order only where BatchNorm-free reductions span the batch: none do,
+        # but allow a handful of argmax flips at float-level ties
+        assert g["sem"].shape == w.shape and (g["sem"] != w).mean() < 1e-3

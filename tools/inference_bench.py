@@ -33,3 +33,19 @@ for shortcut in (True, False):
     best = min(runs, key=lambda r: r[0])
     print(f"FPS identity between resampling and the network {'on ' if shortcut else 'off'}: {best[0] * 1e3:7.1f} ms per scan  "
           + "  ".join(f"{k} {v * 1e3:.1f}" for k, v in best[1].items()) + f"   ({out['sem'].shape[0]} vertices, {len(np.unique(out['sem']))} labels)")
+
+# throughput form: many scans, overlapped stages
+paths = []
+for i in range(48):
+    pth = os.path.join(tempfile.gettempdir(), f"tgn_infer_scan_{i}.obj")
+    if not os.path.exists(pth):
+        with open(pth, "w") as f:
+            f.write(synth.obj_text(330 + (i % 7) * 10, 300, 100 + i, "plain", with_tail=False))
+    paths.append(pth)
+pointops.FPS_PREFIX = None
+inference.infer_scans(paths[:8], net, batch=8)
+for b in (8, 16):
+    t0 = time.perf_counter()
+    res = inference.infer_scans(paths, net, batch=b)
+    dt = time.perf_counter() - t0
+    print(f"infer_scans, {len(paths)} scans, batch {b}: {dt * 1e3 / len(paths):6.1f} ms per scan = {len(paths) / dt:6.1f} scans/s")
