@@ -123,9 +123,10 @@ int tgn_furthestsampling_dense_ws(int B, int N, int S, const float *xyz, void *w
  * (canonical first-index tie order, same arithmetic flags), sampling it again returns positions 0, 1, 2, ... -- which
  * is what the reference's set-abstraction / transition-down chains compute at every level after the first
  * (pointnet2_utils.py:160 on the previous level's new_xyz; blocks.py:69-70).  It holds as long as every winning
- * distance of the producing run was > 0 and < 1e10 (no exhausted cloud, no NaN/Inf point); each kernel records the
- * first iteration that breaks it.
- *   prefix_out[b] (int32 per cloud, optional): this result's samples 0 .. prefix_out[b]-1 carry the property.
+ * distance of the producing run was > 0 and < 1e10 (no exhausted cloud, no NaN/Inf point); the winning distance never
+ * increases, so the first and the last one decide.
+ *   prefix_out[b] (int32 per cloud, optional): this result's samples 0 .. prefix_out[b]-1 carry the property -- the
+ *                 requested sample count when the run stayed inside (0, 1e10), 1 (nothing claimed) otherwise.
  *   prefix_in[b]  (int32 per cloud, optional): cloud b of xyz is such a sequence up to prefix_in[b] samples; when that
  *                 covers the requested sample count (and TGN_FPS_TREE_TIES is not set) the kernel writes the identity
  *                 (indices, new_xyz, prefix_out) and returns -- decided on the device, per cloud, no host sync.

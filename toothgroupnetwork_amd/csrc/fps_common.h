@@ -62,20 +62,22 @@ __device__ __forceinline__ void fps_emit(const FpsArgs &a, int row, int start_n,
 // the tree tie order) emits the identity without running; with prefix_ref the kernel first checks that the cloud
 // really is the sequence the certificate was issued for.  vbits = bit pattern of d_j (>= 0: ordered like unsigned).
 // The winning distance never increases from one iteration to the next (every running minimum only shrinks), so the
-// first violating iteration follows from two wave-uniform accumulators -- two or three scalar instructions per
-// iteration: the largest d_j seen (= d_1; >= 1e10 means a NaN/Inf point) and the number of iterations with d_j > 0.
+// property follows from two wave-uniform values: the largest d_j seen (= d_1; >= 1e10 means a NaN/Inf point or a clamped tie) and the
+// last one (> 0: no iteration was exhausted).
 // Kernels are instantiated with MODE bit 2 (kFpsModeCert) only when a certificate is wanted: even these few scalar
 // instructions (and two more live SGPRs) cost the 24 000-point kernel 2 % per iteration.
 constexpr int kFpsModeCert = 4;
+// (Round 3: the count of iterations with d_j > 0 is not kept any more -- d_j never increases, so the LAST winning distance being
+// positive says all of them were; a launch that ran into exhaustion claims nothing instead of its exact prefix length.  One scalar
+// max per iteration is left.)
 struct FpsPrefixCert {
-    unsigned mx = 0u, pos = 0u;
+    unsigned mx = 0u, last = 0u;
     __device__ __forceinline__ void update(unsigned vbits) {
         mx = vbits > mx ? vbits : mx;
-        pos += vbits != 0u ? 1u : 0u;
+        last = vbits;
     }
     __device__ __forceinline__ int value(int m) const {
-        const int c = mx >= 0x501502F9u /* 1e10f */ ? 1 : 1 + (int)pos;
-        return c < m ? c : m;
+        return (m <= 1 || (mx < 0x501502F9u /* 1e10f */ && last != 0u)) ? m : 1;
     }
 };
 template <int NT>
