@@ -181,3 +181,20 @@ def test_batched_inference_equals_the_single_scan_pipeline(dev, tmp_path):
         # batched and single forwards differ in fp32 summation order only where BatchNorm-free reductions span the batch: none do,
         # but allow a handful of argmax flips at float-level ties
         assert g["sem"].shape == w.shape and (g["sem"] != w).mean() < 1e-3
+
+
+@pytest.mark.gpu
+def test_inference_pipeline_matches_the_reference_class(dev, tmp_path):
+    """tests/golden/make_golden_r3_pipeline.py ran the REFERENCE's InferencePipeLine.__call__ (inference_pipeline_sem.py:14-60) on CPU
+    -- its normalisation, stage order, resample_pcd, relabelling and sklearn KDTree; the mesh loader, FPS and .cuda() served -- with a
+    fixed exactly-rounded model.  The drop-in pipeline on the GPU, same OBJ, same model: the same label on every vertex."""
+    from pipeline_model import MESH, fixed_model
+    from toothgroupnetwork_amd import inference, synth
+    gold = np.load(os.path.join(GOLDEN, "reference_cpu_r3_pipeline.npz"))
+    assert tuple(gold["mesh"].tolist()) == MESH
+    path = tmp_path / "scan.obj"
+    path.write_text(synth.obj_text(MESH[0], MESH[1], MESH[2], "plain", with_tail=False))
+    got = inference.InferencePipeLine(fixed_model)(str(path))
+    assert got["sem"].shape == gold["sem"].shape
+    assert np.array_equal(got["sem"], gold["sem"].astype(got["sem"].dtype)), int((got["sem"] != gold["sem"]).sum())
+    assert np.array_equal(got["ins"], got["sem"])

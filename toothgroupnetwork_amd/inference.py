@@ -9,6 +9,8 @@ behind (`resample.fps(prefix=True)`) that level costs the GPU a comparison inste
 eager call nothing changes -- 11.2 against 11.5 ms for the model stage, `profiles/r03_inference_pipeline.txt`: the forward of a
 single scan is bound by the host enqueuing its ~350 launches; the saving is the GPU's, for whatever shares it.)
 
+Pinned against the reference's own class executed on CPU (tests/golden/make_golden_r3_pipeline.py: loader, FPS and .cuda() served,
+everything else the reference's code): the same label on every vertex.
 Not covered: meshes with fewer than 24 000 vertices, which the reference subdivides with open3d (:25-26)."""
 import time
 
