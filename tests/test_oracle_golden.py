@@ -1,8 +1,12 @@
 """CPU: the oracle (oracle/pointops_oracle.c) against the golden fixtures produced by the reference's
 own torch functions, and against independent brute-force definitions for the CUDA-only operators."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
+from conftest import GOLDEN
 from toothgroupnetwork_amd import synth
 
 
@@ -215,3 +219,27 @@ def test_fps_of_an_fps_result_is_the_identity(oracle):
     seq = oracle.index_points(c, oracle.farthest_point_sample(c, 12))
     again = oracle.farthest_point_sample(seq, 12)[0]
     assert np.array_equal(again[:5], np.arange(5)) and not np.array_equal(again, np.arange(12))
+
+
+def test_inference_pipeline_golden_from_the_oracle_side(oracle, tmp_path):
+    """tests/golden/reference_cpu_r3_pipeline.npz (the reference's InferencePipeLine.__call__ run on CPU) restated on the CPU from the
+    oracle's pieces -- OBJ reader, normals, FPS -- the pipeline's host arithmetic (normalisation, relabelling) and scipy's float64
+    nearest sample: the same label on every vertex.  (The GPU test replays it through the kernels.)"""
+    import torch
+    sys.path.insert(0, GOLDEN)
+    from oracle import meshio as OM
+    from pipeline_model import MESH, fixed_model
+    from toothgroupnetwork_amd import inference, synth
+    gold = np.load(os.path.join(GOLDEN, "reference_cpu_r3_pipeline.npz"))
+    path = tmp_path / "scan.obj"
+    path.write_text(synth.obj_text(MESH[0], MESH[1], MESH[2], "plain", with_tail=False))
+    v, f = OM.read_obj(str(path))
+    org = np.concatenate([inference.normalise_for_inference(v), OM.vertex_normals(v, f - 1)], axis=1)
+    idx = oracle.furthestsampling(np.ascontiguousarray(org[:, :3], dtype=np.float32), [org.shape[0]], [24000]).reshape(-1)
+    sampled = org[idx]
+    inp = torch.from_numpy(sampled.astype("float32")[None]).permute(0, 2, 1)
+    cls = fixed_model([inp])["cls_pred"].argmax(dim=1).reshape(-1).numpy()
+    labels = inference.fdi_from_classes(cls)
+    from scipy.spatial import cKDTree
+    near = cKDTree(sampled[:, :3]).query(org[:, :3], k=1)[1]                   # float64 nearest sample (scipy, not the reference's sklearn)
+    assert np.array_equal(labels[near], gold["sem"].astype(np.int64))
