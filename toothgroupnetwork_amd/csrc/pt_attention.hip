@@ -142,10 +142,14 @@ __global__ __launch_bounds__(256) void pt_softmax_aggregate_fwd_kernel(int n, in
             float mx = -INFINITY;
             for (int j = 0; j < nsample; ++j) mx = fmaxf(mx, lrow[j * g_ + g0]);
             float s = 0.0f;
-            for (int j = 0; j < nsample; ++j) s += expf(lrow[j * g_ + g0] - mx);   // expf, not __expf: the training path tracks torch.exp
+            for (int j = 0; j < nsample; ++j) {
+                const float e = expf(lrow[j * g_ + g0] - mx);   // expf, not __expf: the training path tracks torch.exp
+                sw[j * g_ + g0] = e;                            // (parked: one exponential per weight, not two)
+                s += e;
+            }
             const float inv = 1.0f / s;
             for (int j = 0; j < nsample; ++j) {
-                const float w = expf(lrow[j * g_ + g0] - mx) * inv;
+                const float w = sw[j * g_ + g0] * inv;
                 sw[j * g_ + g0] = w;
                 srow[j * g_ + g0] = w;   // kept for the backward pass
             }
@@ -155,11 +159,27 @@ __global__ __launch_bounds__(256) void pt_softmax_aggregate_fwd_kernel(int n, in
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the point's neighbour indices once, one per lane (nsample <= 64): the loop below then has no load that depends on a load,
+        // and four neighbours' rows are requested before the first is used (deep stages: 93 points x 512 channels were 192 dependent
+        // round trips per wave, 56 us a launch)
+        const int nbv = lane < (unsigned)nsample ? idx[(size_t)pt * nsample + lane] : 0;
         for (int ch = (int)lane; ch < c; ch += 64) {
             const int g = ch % g_;
             float acc = 0.0f;
-            for (int j = 0; j < nsample; ++j) {
-                const int nb = idx[(size_t)pt * nsample + j];
+            int j = 0;
+            for (; nsample <= 64 && j + 4 <= nsample; j += 4) {
+                float a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int nb = __builtin_amdgcn_readlane(nbv, j + u);
+                    a[u] = xv[(size_t)nb * c + ch];
+                    b[u] = pr[((size_t)pt * nsample + j + u) * c + ch];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc += (a[u] + b[u]) * sw[(j + u) * g_ + g];
+            }
+            for (; j < nsample; ++j) {   // (the tail, and every neighbour when there are more than a wave has lanes)
+                const int nb = nsample <= 64 ? __builtin_amdgcn_readlane(nbv, j) : idx[(size_t)pt * nsample + j];
                 acc += (xv[(size_t)nb * c + ch] + pr[((size_t)pt * nsample + j) * c + ch]) * sw[j * g_ + g];
             }
             out[(size_t)pt * c + ch] = acc;
