@@ -205,8 +205,49 @@ __global__ __launch_bounds__(256) void pt_softmax_aggregate_bwd_kernel(int n, in
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float *dsm = dsm_s + (size_t)wv * nsample * g_;
     const int s_ = c / g_;
+    // merged form: needs a lane's weight channel to be lane % g_ in every 64-channel chunk (g_ divides 64) and one index per lane
+    const bool merged = nsample <= 64 && (64 % g_) == 0;
     for (int pt = blockIdx.x * 4 + wv; pt < n; pt += gridDim.x * 4) {
         const float *__restrict__ srow = sm + (size_t)pt * nsample * g_;
+        if (merged) {
+            // ONE pass over (neighbour, channel): d_pr, the scatter into d_xv, and -- from the same loads of xv and pr -- the products
+            // go * (xv + pr), summed over the channels that share a weight (lanes l, l + g_, l + 2 g_, ...: xor shuffles) into d_sm.
+            // (The two-pass form read xv and pr a second time, 16 bytes at a time: lanes over (j, g) pairs.)
+            const int nbv = lane < (unsigned)nsample ? idx[(size_t)pt * nsample + lane] : 0;
+            for (int e = (int)lane; e < nsample * g_; e += 64) dsm[e] = 0.0f;
+            for (int c0 = 0; c0 < c; c0 += 64) {   // wave-uniform trip count: the shuffles need every lane
+                const int ch = c0 + (int)lane;
+                const bool in = ch < c;
+                const int g = (int)lane % g_;
+                const float gch = in ? go[(size_t)pt * c + ch] : 0.0f;
+                for (int j0 = 0; j0 < nsample; j0 += 4) {
+                    float a[4], b[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = j0 + u;
+                        const bool ok = in && j < nsample;
+                        const int nb = __builtin_amdgcn_readlane(nbv, j < nsample ? j : 0);
+                        a[u] = ok ? xv[(size_t)nb * c + ch] : 0.0f;
+                        b[u] = ok ? pr[((size_t)pt * nsample + j) * c + ch] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = j0 + u;
+                        if (j < nsample) {   // wave-uniform
+                            const int nb = __builtin_amdgcn_readlane(nbv, j);
+                            if (in) {
+                                const float w = gch * srow[j * g_ + g];
+                                d_pr[((size_t)pt * nsample + j) * c + ch] = w;
+                                atomicAdd(d_xv + (size_t)nb * c + ch, w);
+                            }
+                            float t = gch * (a[u] + b[u]);
+                            for (int off = g_; off < 64; off <<= 1) t += __shfl_xor(t, off);
+                            if ((int)lane < g_) dsm[j * g_ + (int)lane] += t;
+                        }
+                    }
+                }
+            }
+        } else {
         for (int ch = (int)lane; ch < c; ch += 64) {
             const int g = ch % g_;
             const float gch = go[(size_t)pt * c + ch];
@@ -227,6 +268,7 @@ __global__ __launch_bounds__(256) void pt_softmax_aggregate_bwd_kernel(int n, in
                 acc += go[(size_t)pt * c + ch] * (xv[(size_t)nb * c + ch] + pr[((size_t)pt * nsample + j) * c + ch]);
             }
             dsm[e] = acc;
+        }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // dsm crosses lanes: see the forward kernel
         __builtin_amdgcn_wave_barrier();
