@@ -745,6 +745,29 @@ class PointNetFeaturePropagation(nn.Module):
             D2 = points2.shape[2]
             D1 = W.shape[1] - D2
             dist, idx = three_nn(xyz1, xyz2)
+            if _can_fuse(self, xyz1, xyz2, points1, points2):
+                # eval: every BatchNorm folded into its 1x1 convolution (memoised), the whole stack on channel-last rows -- one GEMM
+                # with bias + an in-place ReLU per layer, no normalisation kernels and no (B,N,C) <-> (B,C,N) copies in between; the
+                # result goes out as the channel-first VIEW of the channel-last tensor
+                def fold():
+                    out = []
+                    for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+                        sc = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).float()
+                        sh = (bn.bias.detach() - bn.running_mean * sc).float()
+                        Wc = conv.weight.detach().squeeze(-1).float()
+                        bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros_like(sh)
+                        out.append(((Wc * sc[:, None]).contiguous(), (bias * sc + sh).contiguous()))
+                    return out
+                srcs = _derived.sources(*self.mlp_convs, *self.mlp_bns)
+                layers = _derived.cached(self.mlp_bns[0], "fp_eval", srcs, None, fold)
+                W0, b0 = layers[0]
+                y = three_interpolate(F.linear(points2, W0[:, D1:]), dist, idx)  # (B, N, C1)
+                if points1 is not None:
+                    y = y + F.linear(points1.permute(0, 2, 1), W0[:, :D1])
+                y = torch.relu_(y.add_(b0))
+                for Wi, bi in layers[1:]:
+                    y = torch.relu_(F.linear(y, Wi, bi))
+                return y.permute(0, 2, 1)
             y = three_interpolate(F.linear(points2, W[:, D1:]), dist, idx)      # (B, N, C1)
             if points1 is not None:
                 y = y + F.linear(points1.permute(0, 2, 1), W[:, :D1])
