@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import point_transformer as PT, pointops
+from . import _derived, point_transformer as PT, pointops
 from .pointnet2_utils import PointNetFeaturePropagation, PointNetSetAbstractionMsg
 
 
@@ -41,8 +41,19 @@ class PointNetPPSeg(nn.Module):
         self.conv1, self.bn1 = nn.Conv1d(32, 16, 1), nn.BatchNorm1d(16)     # declared and unused in the reference too (:38-40)
 
     def _head(self, name, x):
-        y = F.relu(getattr(self, f"{name}_bn_1")(getattr(self, f"{name}_conv_1")(x)))
-        return getattr(self, f"{name}_conv_2")(y)
+        conv1, bn1, conv2 = getattr(self, f"{name}_conv_1"), getattr(self, f"{name}_bn_1"), getattr(self, f"{name}_conv_2")
+        if PT._frozen(self, x) and x.dtype == torch.float32:
+            # eval: on channel-last rows (x arrives as the channel-first view of a channel-last tensor, so the permute is free), the
+            # BatchNorm folded into the first 1x1 convolution (memoised): two GEMMs with bias, no layout copies of the (B, C, N) features
+            def fold():
+                s, t = PT._bn_scale_shift(bn1)
+                W1 = (conv1.weight.detach().squeeze(-1).float() * s[:, None]).contiguous()
+                b1 = (conv1.bias.detach().float() * s + t).contiguous()
+                return W1, b1, conv2.weight.detach().squeeze(-1).float().contiguous(), conv2.bias.detach().float().contiguous()
+            W1, b1, W2, b2 = _derived.cached(bn1, "head_eval", _derived.sources(conv1, bn1, conv2), None, fold)
+            y = torch.relu_(F.linear(x.permute(0, 2, 1), W1, b1))
+            return F.linear(y, W2, b2).permute(0, 2, 1)
+        return conv2(F.relu(bn1(conv1(x))))
 
     def forward(self, xyz_in):
         """xyz_in: [features (B, C, N)] with xyz in the first three channels -> the reference's output list
