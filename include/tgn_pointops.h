@@ -193,6 +193,8 @@ int tgn_aggregation_backward(int n, int nsample, int c, int w_c, const float *in
  *                                                     (Ww1, bw1), ReLU, Linear(g,g) = (Ww2, bw2);  g = c / share_planes
  *     out = sum_j (x_v[idx_j] + p_r_j) * softmax_j(w)[.., ch % g]
  *   p (n,3), x_q / x_k / x_v (n,c), idx (n,nsample) int32 neighbour rows (the kNN of p among p), out (n,c).
+ *   post_scale / post_shift (c each, or both NULL): out = relu(out * post_scale + post_shift) -- the BatchNorm + ReLU the block
+ *   applies to the layer's output (blocks.py:151), folded.
  *   One kernel, nothing of size n*nsample*c is written.  nsample <= 64, c % 4 == 0, g in {4,8,16,32,64}.
  * tgn_pt_softmax_aggregate_{forward,backward}: the trainable tail alone (blocks.py:41-43): softmax over the
  *   neighbours of logit (n,nsample,g) -> sm (kept for backward), out[n,ch] = sum_j (x_v[idx[n,j],ch] + p_r[n,j,ch]) *
@@ -203,7 +205,8 @@ int tgn_aggregation_backward(int n, int nsample, int c, int w_c, const float *in
 int tgn_pt_attention_forward(int n, int nsample, int c, int g, const float *p, const float *xq, const float *xk,
                              const float *xv, const int *idx, const float *Wp1, const float *bp1, const float *Wp2,
                              const float *bp2, const float *a1, const float *t1, const float *Ww1, const float *bw1,
-                             const float *Ww2, const float *bw2, float *out, tgn_stream_t stream);
+                             const float *Ww2, const float *bw2, const float *post_scale, const float *post_shift, float *out,
+                             tgn_stream_t stream);
 int tgn_pt_softmax_aggregate_forward(int n, int nsample, int c, int g, const float *xv, const float *pr, const float *logit,
                                      const int *idx, float *sm, float *out, tgn_stream_t stream);
 int tgn_pt_softmax_aggregate_backward(int n, int nsample, int c, int g, const float *xv, const float *pr, const float *sm,

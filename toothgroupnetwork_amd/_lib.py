@@ -61,7 +61,7 @@ SIGNATURES = {
     "tgn_subtraction_backward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "tgn_aggregation_forward": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "tgn_aggregation_backward": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "tgn_pt_attention_forward": (c_int, [c_int, c_int, c_int, c_int] + [_P] * 16 + [_P]),
+    "tgn_pt_attention_forward": (c_int, [c_int, c_int, c_int, c_int] + [_P] * 18 + [_P]),
     "tgn_pt_softmax_aggregate_forward": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "tgn_pt_softmax_aggregate_backward": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     # section 3

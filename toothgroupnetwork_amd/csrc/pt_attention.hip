@@ -51,6 +51,7 @@ struct PtParams {   // folded parameters of one PointTransformerLayer (device po
     const float *a1, *t1;     // (c), (c): linear_w[0] (BatchNorm1d(c)) as scale / shift
     const float *Ww1, *bw1;   // (g,c), (g): linear_w[2] with linear_w[3] (BatchNorm1d(g)) folded
     const float *Ww2, *bw2;   // (g,g), (g): linear_w[5]
+    const float *post_s, *post_t;   // optional (c), (c): out = relu(out * post_s + post_t) -- the block's bn2 + ReLU (blocks.py:151)
 };
 
 // One wave per point, lane j = neighbour j (nsample <= 64), G = c / share_planes weight channels.
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void pt_attention_fwd_kernel(int n, int nsampl
                     const int cc = ch0 + g + i;
                     const float pr = ((P.Wp2[cc * 3 + 0] * h[0] + P.Wp2[cc * 3 + 1] * h[1]) + P.Wp2[cc * 3 + 2] * h[2]) + P.bp2[cc];
                     const float s = wave_sum_f32(act ? (v4[i] + pr) * sm[g + i] : 0.0f);
-                    if (lane == 0) out[(size_t)pt * c + cc] = s;
+                    if (lane == 0) out[(size_t)pt * c + cc] = P.post_s ? fmaxf(s * P.post_s[cc] + P.post_t[cc], 0.0f) : s;
                 }
             }
         }
@@ -290,8 +291,13 @@ using namespace tgn;
 TGN_API int tgn_pt_attention_forward(int n, int nsample, int c, int g, const float *p, const float *xq, const float *xk,
                                      const float *xv, const int *idx, const float *Wp1, const float *bp1, const float *Wp2,
                                      const float *bp2, const float *a1, const float *t1, const float *Ww1, const float *bw1,
-                                     const float *Ww2, const float *bw2, float *out, tgn_stream_t stream) {
+                                     const float *Ww2, const float *bw2, const float *post_scale, const float *post_shift, float *out,
+                                     tgn_stream_t stream) {
     if (n <= 0) return TGN_OK;
+    if (!post_scale != !post_shift) {
+        set_error("tgn_pt_attention_forward: post_scale and post_shift come together");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
     if (!p || !xq || !xk || !xv || !idx || !out || !Wp1 || !bp1 || !Wp2 || !bp2 || !a1 || !t1 || !Ww1 || !bw1 || !Ww2 || !bw2) {
         set_error("tgn_pt_attention_forward: null pointer");
         return TGN_ERR_INVALID_ARGUMENT;
@@ -301,7 +307,7 @@ TGN_API int tgn_pt_attention_forward(int n, int nsample, int c, int g, const flo
                   "16-byte aligned x_k / x_v");
         return TGN_ERR_UNSUPPORTED;
     }
-    const PtParams P{Wp1, bp1, Wp2, bp2, a1, t1, Ww1, bw1, Ww2, bw2};
+    const PtParams P{Wp1, bp1, Wp2, bp2, a1, t1, Ww1, bw1, Ww2, bw2, post_scale, post_shift};
     long long blocks = ((long long)n + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipStream_t st = (hipStream_t)stream;

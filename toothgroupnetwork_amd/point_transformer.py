@@ -263,8 +263,9 @@ def _fold_pt_layer(lp0, bnp, lp3, bnw0, lw2, bnw3, lw5):
                 a1=f(a1), t1=f(t1), Ww1=f(lw2.weight * s3[:, None]), bw1=f(lw2.bias * s3 + t3), Ww2=f(lw5.weight), bw2=f(lw5.bias))
 
 
-def pt_attention(p, x_q, x_k, x_v, idx, params):
-    """The fused eval-mode layer: p (n,3), x_q/x_k/x_v (n,c), idx (n,nsample) int32 -> (n,c)."""
+def pt_attention(p, x_q, x_k, x_v, idx, params, post=None):
+    """The fused eval-mode layer: p (n,3), x_q/x_k/x_v (n,c), idx (n,nsample) int32 -> (n,c).
+    post = (scale, shift): relu(out * scale + shift) on the way out (the block's bn2 + ReLU, folded)."""
     n, c = x_q.shape
     nsample = idx.shape[1]
     g = params["Ww2"].shape[0]
@@ -272,7 +273,8 @@ def pt_attention(p, x_q, x_k, x_v, idx, params):
     P = params
     check(lib().tgn_pt_attention_forward(n, nsample, c, g, ptr(p), ptr(x_q), ptr(x_k), ptr(x_v), ptr(idx), ptr(P["Wp1"]),
                                          ptr(P["bp1"]), ptr(P["Wp2"]), ptr(P["bp2"]), ptr(P["a1"]), ptr(P["t1"]), ptr(P["Ww1"]),
-                                         ptr(P["bw1"]), ptr(P["Ww2"]), ptr(P["bw2"]), ptr(out), stream()), "pt_attention")
+                                         ptr(P["bw1"]), ptr(P["Ww2"]), ptr(P["bw2"]), ptr(post[0]) if post else None,
+                                         ptr(post[1]) if post else None, ptr(out), stream()), "pt_attention")
     return out
 
 
@@ -298,7 +300,9 @@ class PointTransformerLayer(nn.Module):
                                       nn.Linear(out_planes // share_planes, out_planes // share_planes))
         self.softmax = nn.Softmax(dim=1)
 
-    def forward(self, pxo):
+    def forward(self, pxo, post_bn=None):
+        """post_bn: the BatchNorm1d the caller applies (followed by ReLU) to this layer's output (PointTransformerBlock.bn2): done here
+        -- folded into the fused kernel's epilogue in eval, by the fused rows kernel in training."""
         p, x, o = pxo  # (n, 3), (n, c), (b)
         x_q, x_k, x_v = _lin(self.linear_q, x), _lin(self.linear_k, x), _lin(self.linear_v, x)
         idx = pointops.knn_indices(self.nsample, p, p, o, o)            # one search for both groupings of blocks.py:34-35 (read-only)
@@ -309,7 +313,11 @@ class PointTransformerLayer(nn.Module):
         deep = self.out_planes * g >= 8192 and p.shape[0] < 4096
         if (_frozen(self, p, x) and not deep and self.nsample <= 64 and self.out_planes % 4 == 0 and g in (4, 8, 16, 32, 64)
                 and x_q.dtype == torch.float32):
-            return pt_attention(p.contiguous(), x_q.contiguous(), x_k.contiguous(), x_v.contiguous(), idx, fold_pt_layer(self))
+            post = None
+            if post_bn is not None:
+                post = _derived.cached(post_bn, "scale_shift", _derived.sources(post_bn), None,
+                                       lambda: tuple(t.contiguous() for t in _bn_scale_shift(post_bn)))
+            return pt_attention(p.contiguous(), x_q.contiguous(), x_k.contiguous(), x_v.contiguous(), idx, fold_pt_layer(self), post)
         # training: the reference's composition with the softmax + weighted sum as one differentiable kernel pair.
         # Under autocast this section stays in fp32: it is bandwidth-bound over (n, nsample, c) tensors that the gather
         # kernels produce and consume as fp32, its learned layers are 3- to c/8-wide, and letting autocast flip every other
@@ -321,7 +329,8 @@ class PointTransformerLayer(nn.Module):
             p_r, x_kg = x_kg[:, :, 0:3], x_kg[:, :, 3:]
             p_r = _mlp_rows(self.linear_p, p_r)
             w = _mlp_rows(self.linear_w, x_kg - x_q.unsqueeze(1) + p_r)
-            return pt_softmax_aggregate(x_v.contiguous(), p_r.contiguous(), w.contiguous(), idx)
+            out = pt_softmax_aggregate(x_v.contiguous(), p_r.contiguous(), w.contiguous(), idx)
+        return out if post_bn is None else bn_rows(post_bn, out, relu=True)
 
 
 class TransitionDown(nn.Module):
@@ -437,11 +446,11 @@ class PointTransformerBlock(nn.Module):
         if _frozen(self, x) and x.dtype == torch.float32:
             # eval: bn1 / bn3 folded into their linears (a GEMM with bias each), bn2 one fused normalisation kernel
             x = torch.relu_(F.linear(x, *folded_linear(self.linear1, self.bn1)))
-            x = torch.relu_(self.bn2(self.transformer2([p, x, o])))
+            x = self.transformer2([p, x, o], post_bn=self.bn2)
             x = F.linear(x, *folded_linear(self.linear3, self.bn3)).add_(identity)
             return [p, torch.relu_(x), o]
         x = bn_rows(self.bn1, _lin(self.linear1, x), relu=True)
-        x = bn_rows(self.bn2, self.transformer2([p, x, o]), relu=True)
+        x = self.transformer2([p, x, o], post_bn=self.bn2)
         x = bn_rows(self.bn3, _lin(self.linear3, x))
         x = x + identity
         return [p, self.relu(x), o]
