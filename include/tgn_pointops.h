@@ -312,6 +312,20 @@ int tgn_sa_mlp2_max(int B, int N, int S, int K, int D, int C1p, int C2, const fl
                     const float *points, const float *new_xyz, const float *W1, const float *b1, const void *idx,
                     int idx_is_int64, const float *W2f, const float *b2, float *out, int out_stride, tgn_stream_t stream);
 /*
+ * tgn_sa_all_mlp2_max: PointNetSetAbstraction with group_all=True -- the only form of that module a reference model builds
+ * (models/modules/tsg_seg_module.py:28: 515 -> [256, 512] over the 256 points of the last level) -- eval mode, BatchNorms folded:
+ *   out[b,:] = max_n relu(W2 * relu(W1 * [x_n, f_n] + b1) + b2)     (pointnet2_utils.py:178-195 + 229-236)     (B,C2)
+ * The whole cloud is one group, there is no centre and no index tensor: chunks of 64 consecutive points run through the
+ * two-layer kernel of tgn_sa_mlp2_max, a second small launch takes the maximum over a cloud's chunks.  Operands as for
+ * tgn_sa_mlp2_max, with the group_all channel order [x, y, z, features] (pointnet2_utils.py:190): commuted form A1 (B,N,C1p) =
+ * tgn_sa_point_transform (Wd unused, may be NULL), direct form A1 == NULL with xyz, points, Wd (16,C1p).
+ * part: workspace of tgn_sa_all_chunks(N) * B * C2 floats (may be NULL when tgn_sa_all_chunks(N) == 1).
+ */
+int tgn_sa_all_chunks(int N);
+int tgn_sa_all_mlp2_max(int B, int N, int D, int C1p, int C2, const float *A1, const float *xyz, const float *points,
+                        const float *Wd, const float *b1, const float *W2f, const float *b2, float *part, float *out,
+                        int out_stride, tgn_stream_t stream);
+/*
  * Weight gradient of a linear layer with few columns and many (or not so many) rows -- the training path of the Point-Transformer
  * mirrors; blocks.py:19-30 declares the layers:
  *   dW[o][i] = sum_r gy[r][o] * x[r][i]      (cout, cin)         db[o] = sum_r gy[r][o]   (optional, NULL to skip)

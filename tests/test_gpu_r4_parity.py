@@ -1,0 +1,219 @@
+"""Round-4 parity cases against the REFERENCE's own Python run on CPU (tests/golden/make_golden_r4.py -> reference_cpu_r4.npz):
+
+  * PointNetSetAbstraction(group_all=True) -- the only form of that module a reference model builds (tsg_seg_module.py:28,
+    515 -> [256, 512] over 256 points), eval mode, on the fused kernel path (no torch convolution) and on the plain path;
+  * the WHOLE networks of BASELINE configs 2 and 4 at the configs' own size, one 24 000-point scan (the deep Point-Transformer
+    stages then run on 93 / 375 points and leave the wave-per-point attention kernel);
+  * BASELINE config 3 at step level: the reference's PointTransformerSeg in TRAIN mode, forward + the loss terms
+    FpsGroupingNetworkModel.get_loss applies (tgn_loss.tooth_class_loss, batch_center_offset_loss) + backward: loss terms, outputs and
+    the gradient of every parameter.
+
+Tolerances.  Every comparison is against the float64 evaluation of the reference (`*_64`: the exact value of the same function on
+the same indices) and is elementwise |got - want| <= tol * (1 + |want|).  tol = 1e-5 wherever the reference's own float32 run stays
+inside 1e-5 of the exact value; where it does not (23 residual blocks in fp32; training-mode BatchNorm over 93-point stages) the
+bound is 2x the reference's OWN float32 distance from the exact value, measured on the same entries."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+sys.path.insert(0, GOLDEN)
+from seeded import seeded_fill  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def golden_r4():
+    return dict(np.load(os.path.join(GOLDEN, "reference_cpu_r4.npz")))
+
+
+def _err(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return float(np.max(np.abs(got - want) / (1.0 + np.abs(want))))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# a16: PointNetSetAbstraction(group_all=True)
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,D,mlp,seed", [("tsg", 512, [256, 512], 41), ("ragged", 5, [16, 32], 42)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_set_abstraction_group_all_matches_the_reference_module(dev, golden_r4, monkeypatch, tag, D, mlp, seed, fused):
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    monkeypatch.setattr(U, "FUSED_SA", fused)
+    calls = {"conv2d": 0, "all": 0}
+    real_conv, real_all = torch.nn.Conv2d.forward, U.sa_all_mlp2_max
+    monkeypatch.setattr(torch.nn.Conv2d, "forward", lambda self, x: calls.__setitem__("conv2d", calls["conv2d"] + 1) or real_conv(self, x))
+    monkeypatch.setattr(U, "sa_all_mlp2_max", lambda *a, **k: calls.__setitem__("all", calls["all"] + 1) or real_all(*a, **k))
+    mod = U.PointNetSetAbstraction(None, None, None, D + 3, mlp, True)
+    seeded_fill(mod, seed)
+    mod = mod.to(dev).eval()
+    xyz, pts = torch.from_numpy(golden_r4[f"ga_{tag}_xyz"]).to(dev), torch.from_numpy(golden_r4[f"ga_{tag}_pts"]).to(dev)
+    with torch.no_grad():
+        new_xyz, y = mod(xyz, pts)
+    B = xyz.shape[0]
+    assert tuple(new_xyz.shape) == (B, 3, 1) and not bool(new_xyz.any())                      # pointnet2_utils.py:188: zeros
+    want = golden_r4[f"ga_{tag}_out_64"]
+    e, own = _err(y.cpu().numpy(), want), _err(golden_r4[f"ga_{tag}_out_32"], want)
+    print(f"\ngroup_all[{tag}] fused={fused}: drop-in vs exact {e:.2e}; reference fp32 vs exact {own:.2e}")
+    assert e <= 1e-5
+    # fused: per-point transform + tgn_sa_all_mlp2_max, no torch convolution; plain: the reference's two Conv2d
+    assert calls == ({"conv2d": 0, "all": 1} if fused else {"conv2d": 2, "all": 0}), calls
+
+
+def test_group_all_kernel_equals_the_plain_path_at_odd_sizes(dev):
+    """Chunking edge cases of tgn_sa_all_mlp2_max: N below / at / just above 32, 64 and a multiple of 64, direct and commuted first
+    layers, widths that need padding; against the module's plain path (sample_and_group_all + Conv2d) evaluated in float64."""
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    for N, D, mlp in ((1, 0, [16, 8]), (31, 3, [20, 24]), (32, 13, [16, 40]), (33, 14, [36, 130]), (64, 40, [64, 64]), (65, 40, [196, 96]),
+                      (128, 7, [16, 16]), (257, 70, [72, 260])):
+        g = torch.Generator().manual_seed(N)
+        xyz = (torch.rand(3, 3, N, generator=g) * 2 - 1).to(dev)
+        pts = torch.randn(3, D, N, generator=g).to(dev) if D else None
+        mod = U.PointNetSetAbstraction(None, None, None, D + 3, mlp, True)
+        seeded_fill(mod, 7)
+        mod = mod.to(dev).eval()
+        with torch.no_grad():
+            _, got = mod(xyz, pts)
+            keep = U.FUSED_SA
+            try:
+                U.FUSED_SA = False
+                _, want = mod.double()(xyz.double(), None if pts is None else pts.double())
+            finally:
+                U.FUSED_SA = keep
+        assert got.dtype == torch.float32 and _err(got.cpu().numpy(), want.cpu().numpy()) <= 1e-5, (N, D, mlp)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# whole networks at 24 000 points
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_pointnet_pp_whole_network_at_24000_points(dev, golden_r4):
+    from toothgroupnetwork_amd import nets, synth
+    net = nets.PointNetPPSeg()
+    seeded_fill(net, 31)
+    net = net.to(dev).eval()
+    scans = synth.scan_batch(1, 24000, "arch", seed=int(golden_r4["pnpp24_seed"][0]))
+    feats = torch.from_numpy(np.ascontiguousarray(scans.transpose(0, 2, 1))).to(dev)
+    with torch.no_grad():
+        y = [t.cpu().numpy() for t in net([feats])]
+    got = dict(zip(["l0_points", "l3_points", "l0_xyz", "l3_xyz", "offset", "dist", "cls"], y))
+    assert np.array_equal(got["l3_xyz"], golden_r4["pnpp24_l3_xyz_32"])                       # three chained FPS levels: exact
+    got["l0_points"], got["l3_points"] = got["l0_points"][:, ::8, ::16], got["l3_points"][:, ::8]
+    for n_ in ("offset", "dist", "cls"):
+        got[n_] = got[n_][:, :, ::4]
+    worst = {n_: _err(got[n_], golden_r4[f"pnpp24_{n_}_64"]) for n_ in ("l0_points", "l3_points", "offset", "dist", "cls")}
+    own = {n_: _err(golden_r4[f"pnpp24_{n_}_32"], golden_r4[f"pnpp24_{n_}_64"]) for n_ in ("cls", "offset")}
+    print(f"\npointnet_pp whole net at 24 000 points: drop-in vs exact {worst}; reference fp32 vs exact {own}")
+    for n_, e in worst.items():
+        assert e <= 1e-5, (n_, e)
+
+
+def test_point_transformer_whole_network_at_24000_points(dev, golden_r4):
+    from toothgroupnetwork_amd import nets, synth
+    net = nets.PointTransformerSeg()
+    seeded_fill(net, 32)
+    net = net.to(dev).eval()
+    scans = synth.scan_batch(1, 24000, "arch", seed=int(golden_r4["pt24_seed"][0]))
+    feats = torch.from_numpy(np.ascontiguousarray(scans.transpose(0, 2, 1))).to(dev)
+    with torch.no_grad():
+        cls, offset, _, x1 = net([feats])
+    got = {"cls": cls.cpu().numpy()[:, :, ::4], "offset": offset.cpu().numpy()[:, :, ::4], "x1": x1.cpu().numpy()[::4]}
+    report = {}
+    for n_ in ("cls", "offset", "x1"):
+        want = golden_r4[f"pt24_{n_}_64"]
+        e, own = _err(got[n_], want), _err(golden_r4[f"pt24_{n_}_32"], want)
+        report[n_] = (e, own)
+        assert e <= max(1e-5, 2.0 * own), (n_, e, own)
+    print(f"\nPointTransformerSeg at 24 000 points: (drop-in vs exact, reference fp32 vs exact) {report}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# BASELINE config 3 at step level: training-mode forward, the reference's loss terms, backward
+# ---------------------------------------------------------------------------------------------------------------------------
+def reference_loss_terms(sem, offset, xyz, gt):
+    """models/tgn_loss.py:355-372 `tooth_class_loss` and :6-60 `batch_center_offset_loss` on (1,17,N) / (1,3,N) / (1,3,N) and raw
+    labels gt (N,) in -1..15, term by term as the reference writes them (the golden pins this restatement: the three values must
+    equal the reference's)."""
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    ce = torch.nn.functional.cross_entropy(sem, (gt + 1).view(1, -1))
+    off, pts = offset.permute(0, 2, 1)[0], xyz.permute(0, 2, 1)[0]
+    cen = dirl = 0.0
+    n_cen = n_dir = 0
+    for tooth in range(16):
+        m = gt == tooth
+        if int(m.sum()) < 5:
+            continue
+        n_cen += 1
+        p, o = pts[m][None], off[m][None]
+        c = p.mean(1).view(1, 1, 3)
+        cen = cen + U.square_distance(p + o, c).sum() / p.shape[1]
+        on = o.norm(dim=2).view(1, -1, 1)
+        od = o / on
+        pc = c - p
+        pc = pc / pc.norm(dim=2).view(1, -1, 1)
+        keep = on.view(1, -1) > 0.0002
+        od, pc = od[keep], pc[keep]
+        if od.shape[0]:
+            n_dir += 1
+            dot = (pc * od).sum(1) - 1
+            dirl = dirl + (dot * dot).sum() / od.shape[0]
+    return ce, cen / n_cen, dirl / n_dir
+
+
+def test_training_step_gradients_match_the_reference_network(dev, golden_r4):
+    from toothgroupnetwork_amd import nets, synth
+    N = int(golden_r4["train_points"][0])
+    net = nets.PointTransformerSeg()
+    assert seeded_fill(net, 33) == golden_r4["train_params"].tolist()
+    net = net.to(dev).train()
+    scans = synth.scan_batch(1, N, "arch", seed=403)
+    feats = torch.from_numpy(np.ascontiguousarray(scans.transpose(0, 2, 1))).to(dev)
+    gt = torch.from_numpy(golden_r4["train_label"].astype(np.int64)).to(dev)
+    sem, offset, _, _ = net([feats])
+    ce, cen, dirl = reference_loss_terms(sem, offset, feats[:, :3, :], gt)
+    loss = 1.0 * ce + 0.03 * cen + 0.03 * dirl                                                # train_configs/tgnet_fps.py:16-24
+    loss.backward()
+    t64, t32 = golden_r4["train_terms_64"], golden_r4["train_terms_32"]
+    got_terms = np.array([float(loss), float(ce), float(cen), float(dirl)])
+    print(f"\nloss terms (loss, ce, centroid, dir): drop-in {got_terms}, reference fp64 {t64}, reference fp32 {t32}")
+    for g, a, b in zip(got_terms, t64, t32):
+        assert abs(g - a) <= max(2.0 * abs(b - a), 2e-5 * abs(a)), (got_terms, t64, t32)
+    for n_, t in (("sem", sem), ("offset", offset)):
+        want = golden_r4[f"train_{n_}_64"]
+        e, own = _err(t.detach().cpu().numpy()[:, :, ::16], want), _err(golden_r4[f"train_{n_}_32"], want)
+        print(f"train-mode {n_}: drop-in vs exact {e:.2e}, reference fp32 vs exact {own:.2e}")
+        assert e <= max(1e-5, 2.0 * own), (n_, e, own)
+    # gradients: every parameter the reference gives a gradient gets one (and the mask head, unused by the outputs, gets none)
+    grads = {n: p.grad for n, p in net.named_parameters()}
+    names = golden_r4["train_grad_names"].tolist()
+    none = [n for n in golden_r4["train_grad_none"].tolist() if n]
+    assert sorted(n for n, g in grads.items() if g is not None) == names
+    assert sorted(n for n, g in grads.items() if g is None) == sorted(none)
+    norms, samples = golden_r4["train_grad_norms"], golden_r4["train_grad_samples"]
+    K = samples.shape[2]
+    rows = []
+    for i, n in enumerate(names):
+        g = grads[n].detach().double().reshape(-1).cpu().numpy()
+        pick = np.linspace(0, g.size - 1, min(K, g.size)).astype(np.int64)
+        s64, s32 = samples[i, 0, :pick.size], samples[i, 1, :pick.size]
+        d_got, d_own = np.linalg.norm(g[pick] - s64), np.linalg.norm(s32 - s64)
+        rows.append((n, norms[i, 0], np.linalg.norm(g), d_got, d_own, np.linalg.norm(s64)))
+    tot_got = np.sqrt(sum(r[3] ** 2 for r in rows))
+    tot_own = np.sqrt(sum(r[4] ** 2 for r in rows))
+    tot_ref = np.sqrt(sum(r[5] ** 2 for r in rows))
+    ratios = np.array([r[3] / max(r[4], 1e-12 * (1 + r[5])) for r in rows])
+    print(f"gradient samples ({len(rows)} parameters x <= {K} entries): |drop-in - exact| = {tot_got:.3e}, |reference fp32 - exact| = "
+          f"{tot_own:.3e}, |exact| = {tot_ref:.3e}; per-parameter ratio median {np.median(ratios):.2f}, 95 % {np.quantile(ratios, 0.95):.2f}, "
+          f"max {ratios.max():.2f} ({rows[int(ratios.argmax())][0]})")
+    # whole gradient: within 2x the reference's own fp32 distance from the exact gradient
+    assert tot_got <= 2.0 * tot_own, (tot_got, tot_own)
+    # per parameter: fp32 noise is a random variable, so the per-parameter bound is the larger of 4x the reference's own distance
+    # on the same entries and 2 % of the parameter's gradient (the reference's own median relative distance is 1 %)
+    for n, n64, ng, d_got, d_own, s_ref in rows:
+        assert d_got <= max(4.0 * d_own, 0.02 * s_ref, 1e-7), (n, d_got, d_own, s_ref)
+        assert abs(ng - n64) <= max(4.0 * abs(norms[names.index(n), 1] - n64), 0.02 * n64, 1e-7), (n, ng, n64)

@@ -77,6 +77,25 @@ def test_reference_models_import_our_operators_unchanged():
         "from external_libs.pointops.functions import pointops\n"
         "import toothgroupnetwork_amd.pointops as P\n"
         "assert pointops.queryandgroup is P.queryandgroup\n"
+        # the tsegnet consumers north_star names (models/tsegnet_model.py -> modules/tsegnet.py -> tsg_centroid_module / tsg_seg_module)
+        # and the loss / utility modules that import square_distance etc. (tgn_loss.py:4, tsg_loss.py:2, ops_utils.py:5)
+        # (open3d / trimesh / wandb -- mesh I/O and logging, absent from this image and outside the path -- are stubbed)
+        "import types\n"
+        "for n in ('open3d', 'trimesh', 'wandb'): sys.modules[n] = types.ModuleType(n)\n"
+        "import models.modules.tsg_centroid_module as cm, models.modules.tsg_seg_module as sm, models.modules.tsegnet as tn\n"
+        "import models.tgn_loss as tl, models.tsg_loss as sl, ops_utils as ou\n"
+        "assert tl.square_distance is U.square_distance and sl.square_distance is U.square_distance\n"
+        "assert ou.square_distance is U.square_distance\n"
+        "c = cm.get_model(); s = sm.get_model()\n"
+        "assert type(c.sa1) is U.PointNetSetAbstractionMsg and type(c.fp1) is U.PointNetFeaturePropagation\n"
+        "assert type(s.flatten_sa) is U.PointNetSetAbstraction and s.flatten_sa.group_all is True\n"
+        "assert [m.out_channels for m in s.flatten_sa.mlp_convs] == [256, 512] and s.flatten_sa.mlp_convs[0].in_channels == 515\n"
+        "assert tn.get_centroid_module is cm.get_model and tn.get_seg_module is sm.get_model and tn.square_distance is U.square_distance\n"
+        # the three model wrappers north_star names import unchanged, and the preprocess resampler calls this repo's FPS
+        "import models.pointnet_pp_model, models.transformer_model, models.tsegnet_model as tm, models.fps_grouping_network_model\n"
+        "assert tm.square_distance is U.square_distance\n"
+        "import gen_utils as gu\n"
+        "assert gu.pointops is pointops and gu.pointops.furthestsampling is P.furthestsampling\n"
         "print('ok')\n" % REPO)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp",
                          env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})

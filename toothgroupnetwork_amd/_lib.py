@@ -85,6 +85,8 @@ SIGNATURES = {
     "tgn_bn_rows_forward": (c_int, [ctypes.c_longlong, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "tgn_bn_rows_backward": (c_int, [ctypes.c_longlong, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "tgn_sa_mlp2_max": (c_int, [c_int] * 7 + [_P] * 7 + [c_int, _P, _P, _P, c_int, _P]),
+    "tgn_sa_all_chunks": (c_int, [c_int]),
+    "tgn_sa_all_mlp2_max": (c_int, [c_int] * 5 + [_P] * 9 + [c_int, _P]),
     "tgn_sa_direct_max": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "tgn_gather_points": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P]),
     "tgn_scatter_add_points": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P]),

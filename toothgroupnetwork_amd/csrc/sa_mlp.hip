@@ -71,28 +71,40 @@ __global__ __launch_bounds__(256, 2) void sa_mlp2_max_kernel(long long Q, int N,
     const int b = (int)(q / S);
     int kk = ar & (Kp - 1);
     if (kk >= K) kk = 0;
-    long long v = (long long)idx[q * K + kk];
-    if (v < 0) v += N;
-    bool bad = false;
-    if (v < 0 || v >= N) {
-        bad = true;
-        v = 0;
+    long long v;
+    if (idx) {
+        v = (long long)idx[q * K + kk];
+        if (v < 0) v += N;
+        bool bad = false;
+        if (v < 0 || v >= N) {
+            bad = true;
+            v = 0;
+        }
+        if (err && col0 == 0 && bad) atomicOr(err, 1);
+    } else {
+        // group_all (pointnet2_utils.py:178-195): "query" s of a cloud owns the points s*Kp .. s*Kp + Kp-1, no centre; a short
+        // last chunk repeats its first point, which a max does not see
+        const long long first = (q - (long long)b * S) * Kp;
+        v = first + kk < N ? first + kk : first;
     }
-    if (err && col0 == 0 && bad) atomicOr(err, 1);
     const float *__restrict__ arow = A1 + ((size_t)b * N + (size_t)v) * C1p + ah * 8;
     float g[16];
     if (DIRECT) {
         const float *__restrict__ px = xyz + ((size_t)b * N + (size_t)v) * 3;
         const float *__restrict__ pf = points + ((size_t)b * N + (size_t)v) * D;
-        g[0] = px[0] - new_xyz[q * 3 + 0];
-        g[1] = px[1] - new_xyz[q * 3 + 1];
-        g[2] = px[2] - new_xyz[q * 3 + 2];
+        g[0] = px[0] - (new_xyz ? new_xyz[q * 3 + 0] : 0.0f);
+        g[1] = px[1] - (new_xyz ? new_xyz[q * 3 + 1] : 0.0f);
+        g[2] = px[2] - (new_xyz ? new_xyz[q * 3 + 2] : 0.0f);
 #pragma unroll
         for (int j = 3; j < 16; ++j) g[j] = j - 3 < D ? pf[j - 3] : 0.0f;
     } else {
         for (int l = 0; l < QPT; ++l) {   // cst[l][c] = b1[c] - Wxs[:,c] . centre of query l
             long long qq = q0 + l;
             if (qq >= Q) qq = Q - 1;
+            if (!new_xyz) {
+                for (int c = tid; c < C1p; c += 256) cst[l * C1p + c] = b1[c];
+                continue;
+            }
             const float cx = new_xyz[qq * 3 + 0], cy = new_xyz[qq * 3 + 1], cz = new_xyz[qq * 3 + 2];
             for (int c = tid; c < C1p; c += 256)
                 cst[l * C1p + c] = b1[c] - ((W1[c] * cx + W1[C1p + c] * cy) + W1[2 * C1p + c] * cz);
@@ -215,6 +227,18 @@ __global__ __launch_bounds__(256, 2) void sa_mlp2_max_kernel(long long Q, int N,
     }
 }
 
+// out[b, c] = max_s part[b, s, c]: the chunks of a group_all level (post-ReLU values, so the order of the two maxima is free)
+__global__ __launch_bounds__(256) void sa_chunks_max_kernel(int B, int S, int C, int ostride, const float *__restrict__ part,
+                                                            float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * C) return;
+    const int b = (int)(i / C), c = (int)(i - (long long)b * C);
+    const float *p = part + (size_t)b * S * C + c;
+    float m = p[0];
+    for (int s = 1; s < S; ++s) m = fmaxf(m, p[(size_t)s * C]);
+    out[(size_t)b * ostride + c] = m;
+}
+
 }  // namespace tgn
 
 using namespace tgn;
@@ -222,36 +246,35 @@ using namespace tgn;
 // 1 if tgn_sa_mlp2_max takes the direct form for this first layer (the caller then passes xyz / points / Wd, no A1)
 TGN_API int tgn_sa_mlp2_direct_supported(int K, int D) { return (D >= 0 && 3 + D <= 16 && K >= 1 && K <= 64) ? 1 : 0; }
 
-TGN_API int tgn_sa_mlp2_max(int B, int N, int S, int K, int D, int C1p, int C2, const float *A1, const float *xyz,
-                            const float *points, const float *new_xyz, const float *W1, const float *b1, const void *idx,
-                            int idx_is_int64, const float *W2f, const float *b2, float *out, int out_stride, tgn_stream_t stream) {
+// shared launcher: idx == nullptr selects the group_all form (chunks of 32 / 64 consecutive points, new_xyz may be null)
+static int sa_mlp2_launch(const char *who, int B, int N, int S, int K, int D, int C1p, int C2, const float *A1, const float *xyz,
+                          const float *points, const float *new_xyz, const float *W1, const float *b1, const void *idx,
+                          int idx_is_int64, const float *W2f, const float *b2, float *out, int out_stride, tgn_stream_t stream) {
     const long long Q = (long long)B * S;
-    if (Q <= 0 || C2 <= 0) return TGN_OK;
     const bool direct = A1 == nullptr;
-    if (out_stride <= 0) out_stride = C2;
-    if (!new_xyz || !W1 || !b1 || !idx || !W2f || !b2 || !out || (direct && (!xyz || (D > 0 && !points)))) {
-        set_error("tgn_sa_mlp2_max: null pointer");
+    if (!b1 || !W2f || !b2 || !out || (direct && (!xyz || !W1 || (D > 0 && !points))) || (!direct && new_xyz && !W1)) {
+        set_error("%s: null pointer", who);
         return TGN_ERR_INVALID_ARGUMENT;
     }
     if (K < 1 || K > 64 || C1p < 16 || (C1p & 15) || N < 1 || out_stride < C2 || (direct && !tgn_sa_mlp2_direct_supported(K, D)) ||
         (((uintptr_t)A1 | (uintptr_t)W2f | (uintptr_t)W1 | (uintptr_t)b1) & 15)) {
-        set_error("tgn_sa_mlp2_max: needs 1 <= nsample <= 64, a first-layer width padded to a multiple of 16, 16-byte aligned "
-                  "operands, and 3+D <= 16 for the direct form");
+        set_error("%s: needs 1 <= nsample <= 64, a first-layer width padded to a multiple of 16, 16-byte aligned "
+                  "operands, and 3+D <= 16 for the direct form", who);
         return TGN_ERR_UNSUPPORTED;
     }
     const int qpt = K > 32 ? 2 : 4;
     const size_t lds = (size_t)(4 * kFrag + (direct ? 0 : qpt * C1p)) * sizeof(float);
     if (lds > 80 * 1024) {   // two workgroups per CU
-        set_error("tgn_sa_mlp2_max: first-layer width %d needs %zu bytes of LDS per workgroup (limit 80 KiB)", C1p, lds);
+        set_error("%s: first-layer width %d needs %zu bytes of LDS per workgroup (limit 80 KiB)", who, C1p, lds);
         return TGN_ERR_UNSUPPORTED;
     }
     const long long mtiles = (Q + qpt - 1) / qpt, ntiles = (C2 + kMlpNT - 1) / kMlpNT;
     const long long blocks = (mtiles * ntiles + 7) / 8 * 8;
     if (blocks > 0x7FFFFFFFLL) {
-        set_error("tgn_sa_mlp2_max: too many tiles");
+        set_error("%s: too many tiles", who);
         return TGN_ERR_UNSUPPORTED;
     }
-    int *err = index_error_word();
+    int *err = idx ? index_error_word() : nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (direct && !points) points = xyz;   // D == 0: never read
 #define TGN_MLP2(IT, DIR)                                                                                                 \
@@ -275,4 +298,48 @@ TGN_API int tgn_sa_mlp2_max(int B, int N, int S, int K, int D, int C1p, int C2, 
     }
 #undef TGN_MLP2
     return check_launch("sa_mlp2_max_kernel");
+}
+
+TGN_API int tgn_sa_mlp2_max(int B, int N, int S, int K, int D, int C1p, int C2, const float *A1, const float *xyz,
+                            const float *points, const float *new_xyz, const float *W1, const float *b1, const void *idx,
+                            int idx_is_int64, const float *W2f, const float *b2, float *out, int out_stride, tgn_stream_t stream) {
+    if ((long long)B * S <= 0 || C2 <= 0) return TGN_OK;
+    if (out_stride <= 0) out_stride = C2;
+    if (!new_xyz || !W1 || !idx) {
+        set_error("tgn_sa_mlp2_max: null pointer");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    return sa_mlp2_launch("tgn_sa_mlp2_max", B, N, S, K, D, C1p, C2, A1, xyz, points, new_xyz, W1, b1, idx, idx_is_int64, W2f, b2, out,
+                          out_stride, stream);
+}
+
+// group_all set abstraction (pointnet2_utils.py:178-195 + 214-239 with group_all=True; tsg_seg_module.py:28 is the one
+// instantiation): out[b,:] = max over ALL N points of relu(bn2(W2 * relu(bn1(W1 * [x, f] + bias1)) + bias2)), no centre, no
+// index tensor.  The cloud is cut into chunks of 64 (N <= 32: one chunk of 32) consecutive points, every chunk runs through the
+// two-layer kernel above as if it were a ball, and a second small launch takes the maximum over a cloud's chunks.
+//   A1 (B,N,C1p): per-point first layer before bias (tgn_sa_point_transform), or NULL for the direct form (3+D <= 16: xyz,
+//   points, Wd (16,C1p)); part: workspace of tgn_sa_all_chunks(N) * B * C2 floats (unused when a cloud is one chunk).
+TGN_API int tgn_sa_all_chunks(int N) { return N <= 64 ? 1 : (N + 63) / 64; }
+
+TGN_API int tgn_sa_all_mlp2_max(int B, int N, int D, int C1p, int C2, const float *A1, const float *xyz, const float *points,
+                                const float *Wd, const float *b1, const float *W2f, const float *b2, float *part, float *out,
+                                int out_stride, tgn_stream_t stream) {
+    if (B <= 0 || C2 <= 0) return TGN_OK;
+    if (N < 1) {
+        set_error("tgn_sa_all_mlp2_max: empty clouds");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    if (out_stride <= 0) out_stride = C2;
+    const int S = tgn_sa_all_chunks(N), K = N < 64 ? N : 64;
+    if (S > 1 && !part) {
+        set_error("tgn_sa_all_mlp2_max: null workspace");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    int rc = sa_mlp2_launch("tgn_sa_all_mlp2_max", B, N, S, K, D, C1p, C2, A1, xyz, points, nullptr, Wd, b1, nullptr, 0, W2f, b2,
+                            S > 1 ? part : out, S > 1 ? C2 : out_stride, stream);
+    if (rc != TGN_OK || S == 1) return rc;
+    const long long n = (long long)B * C2;
+    hipLaunchKernelGGL(sa_chunks_max_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, S, C2, out_stride,
+                       part, out);
+    return check_launch("sa_chunks_max_kernel");
 }

@@ -566,6 +566,34 @@ def sa_level_mlp2_max(xyz, new_xyz, points, idx, convs, bns, xyz_first, out=None
     return out
 
 
+def sa_all_mlp2_max(xyz, points, convs, bns):
+    """PointNetSetAbstraction(group_all=True) with a two-layer shared MLP, eval mode (pointnet2_utils.py:178-195 + 229-236; the one
+    instantiation is tsg_seg_module.py:28, 515 -> [256, 512] over 256 points):
+        max_n relu(bn2(conv2(relu(bn1(conv1([xyz_n, points_n]))))))  ->  (B, C2)
+    The first layer runs once per point on the fp32 matrix cores (tgn_sa_point_transform; 3+D <= 16: inside the kernel), the second
+    layer and the maximum over the cloud in tgn_sa_all_mlp2_max: no (B,1,N,.) tensor, no torch convolution."""
+    B, N, _ = xyz.shape
+    D = 0 if points is None else points.shape[2]
+    L = lib()
+    direct = bool(L.tgn_sa_mlp2_direct_supported(min(N, 64), D))
+
+    def operands():
+        f = fold_first_layer(convs[0], bns[0], D, True)
+        C1p = (f["C1"] + 15) // 16 * 16
+        W2f, b2 = fold_second_layer(convs[1], bns[1], C1p)
+        return dict(C1p=C1p, W2f=W2f, b2=b2, b1=_pad_cols(f["b2"], C1p), Wd=_pad_cols(f["Wd"], C1p) if direct else None,
+                    Wt=None if direct else _pad_cols(f["Wt"], C1p))
+    ops = _derived.cached(bns[1], "all_mlp2", _derived.sources(convs[0], bns[0], convs[1], bns[1]), (D, direct), operands)
+    C2 = ops["b2"].shape[0]
+    out = torch.empty(B, C2, dtype=torch.float32, device=xyz.device)
+    chunks = int(L.tgn_sa_all_chunks(N))
+    part = torch.empty(B, chunks, C2, dtype=torch.float32, device=xyz.device) if chunks > 1 else None
+    A1 = None if direct else sa_point_transform(xyz, points, ops["Wt"])
+    check(L.tgn_sa_all_mlp2_max(B, N, D, ops["C1p"], C2, ptr(A1), ptr(xyz), ptr(points), ptr(ops["Wd"]), ptr(ops["b1"]),
+                                ptr(ops["W2f"]), ptr(ops["b2"]), ptr(part), ptr(out), C2, stream()), "sa_all_mlp2_max")
+    return out
+
+
 def _mlp2_shape_ok(K, C1):
     """tgn_sa_mlp2_max keeps the per-query constants of its 4 (K <= 32) or 2 queries in LDS next to the tile buffers."""
     return 1 <= K <= 64 and (4 if K <= 32 else 2) * ((C1 + 15) // 16 * 16) <= 8192
@@ -636,6 +664,11 @@ class PointNetSetAbstraction(nn.Module):
                 new_points = _mlp_tail_and_max(group_points(xyz_c, new_xyz, points_c, idx, xyz_first=True), self.mlp_convs,
                                                self.mlp_bns, 0)
             return new_xyz.permute(0, 2, 1), new_points
+        if (self.group_all and len(self.mlp_convs) == 2 and xyz.shape[1] >= 1 and _can_fuse(self, xyz, points)
+                and _mlp2_shape_ok(min(xyz.shape[1], 64), self.mlp_convs[0].out_channels)):
+            # eval fast path of the form the reference builds (tsg_seg_module.py:28): the whole cloud is one group
+            y = sa_all_mlp2_max(_f32c(xyz), None if points is None else _f32c(points), self.mlp_convs, self.mlp_bns)
+            return xyz.new_zeros(xyz.shape[0], xyz.shape[2], 1), y.unsqueeze(2)
         if self.group_all:
             new_xyz, new_points = sample_and_group_all(xyz, points)
         else:
