@@ -59,6 +59,23 @@ void tgn_set_default_stream(tgn_stream_t stream);
  */
 void tgn_set_fps_mode(int flags);
 int tgn_get_fps_mode(void);
+/*
+ * Kernel-variant switches for experiments, A/B runs and the parity tests that must reach every variant.  One table of
+ * atomics inside the library, read with a relaxed load on the launch paths (no getenv there); the legacy TGN_* environment
+ * names seed it once, when the library is loaded.  Thread-safe; a change applies to launches enqueued after the call.
+ *   "fps_plain"          1 = plain register-resident / streaming FPS kernels, no bucket skipping        (TGN_FPS_V1)
+ *   "fps_config"         NT * 256 + P forces an instantiated plain-kernel shape, 0 = pick               (TGN_FPS_CONFIG=NT,P)
+ *   "fps_bucket_config"  NT * 256 + P forces a bucket-kernel shape, 0 = pick                            (TGN_FPS_BUCKET_CONFIG=NT,P)
+ *   "fps_cell_bits"      4 (default) or 5: bits per axis of the bucket kernel's Z-order cell code       (TGN_FPS_CELL_BITS)
+ *   "fps_bucket_min"     smallest cloud the bucket kernel takes, -1 = built-in thresholds               (TGN_FPS_BUCKET_MIN)
+ *   "ball_bitmap"        0 = rank-select ball-query kernel instead of the bitmap one                    (TGN_BALL_BITMAP)
+ *   "ball_pair"          0 = one query per wave in the bitmap ball query, 1 (default) = two             (TGN_BALL_PAIR)
+ *   "knn_memset"         1 = clear the kNN redo counter with hipMemsetAsync (reproduces a graph fault)  (TGN_KNN_MEMSET)
+ *   "knn_grid_scale"     kNN grid cell, per mille of the estimated k-neighbour radius (1000)            (TGN_KNN_GRID_SCALE)
+ * tgn_set_tuning returns TGN_ERR_INVALID_ARGUMENT for an unknown key; tgn_get_tuning returns `fallback` for one.
+ */
+int tgn_set_tuning(const char *key, int value);
+int tgn_get_tuning(const char *key, int fallback);
 
 /* ------------------------------------------------------------------------------------------
  * 1. The reference's C ABI, verbatim (each line cites the declaration it replaces).
@@ -373,8 +390,9 @@ int tgn_three_interpolate(int B, int N, int S, int C, const float *points2, cons
  * Gather indices follow torch's advanced indexing (pointnet2_utils.py:56-60): negative values wrap (k + N); an
  * index still outside [0,N) -- where the reference raises, e.g. an empty ball yields index N -- makes
  * tgn_gather_points write a zero row and tgn_group_points / tgn_sa_* read point 0, and latches a flag in the
- * current device's memory.  This returns 1 and clears the flag if that happened on the current device since the
- * last call; it synchronises `stream`.  (The Python operators call it and raise IndexError.)
+ * current device's memory -- one flag per (device, stream), so host threads that drive different streams do not see or
+ * clear each other's.  This returns 1 and clears the flag if that happened in a launch on `stream` since the last call;
+ * it synchronises `stream`.  (The Python operators call it and raise IndexError.)
  */
 int tgn_take_index_error(tgn_stream_t stream);
 /* Clears the flag in stream order without synchronising: what a checked operator issues in front of its own launch, so

@@ -17,10 +17,14 @@
  *     semantics, start index 0): PINNED against outputs of the reference's own
  *     torch functions executed on CPU in the build container
  *     (tests/golden/make_golden.py -> tests/golden/ npz files).
- *   - kNN, grouping, interpolation, subtraction, aggregation and the "cuda-compat"
- *     FPS mode restate CUDA-only kernels that cannot run here (no nvcc, no CUDA
- *     device, reference ships no tests or vectors): PARITY UNPINNED for those;
- *     they are cross-checked against independent brute-force numpy definitions.
+ *   - kNN, grouping, interpolation, subtraction, aggregation and the tree tie order
+ *     of FPS restate CUDA-only kernels: PINNED on the GPU box against the reference's
+ *     own kernels, compiled for gfx950 where they lie (oracle/Makefile `ref` ->
+ *     oracle/_ref/libpointops_ref.so; tests/test_gpu_parity.py::*_vs_reference_kernel*),
+ *     and against independent brute-force numpy definitions on the CPU.
+ *   - PARITY UNPINNED: only nvcc's own FMA contraction of the FPS / kNN distance
+ *     (the TGN_FPS_FMA flag of the "cuda-compat" mode) -- there is no nvcc and no
+ *     CUDA device here, and hipcc contracts the same source line differently.
  *
  * Arithmetic contract (build with -ffp-contract=off; fused ops are written as
  * fmaf() explicitly so the compiler never chooses):

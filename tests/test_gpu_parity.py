@@ -31,25 +31,24 @@ def test_fps_dense_matches_golden(dev, golden):
 @pytest.mark.parametrize("n,m", [(1, 1), (2, 2), (63, 10), (64, 64), (65, 30), (1000, 256), (1024, 256), (1025, 100),
                                  (2047, 300), (2048, 512), (2049, 300), (4096, 1024), (6000, 1500), (8193, 400),
                                  (12288, 300), (16385, 200), (24000, 2048), (28000, 300)])
-@pytest.mark.parametrize("bucket_min", ["2048", "1000000"])
-def test_fps_every_kernel_shape_vs_oracle(dev, oracle, n, m, bucket_min, monkeypatch):
+@pytest.mark.parametrize("bucket_min", [2048, 1000000])
+def test_fps_every_kernel_shape_vs_oracle(dev, oracle, n, m, bucket_min):
     """One cloud per launch configuration (threads x points-per-lane), incl. exact-capacity edges; every shape
     of the bucket-skipping kernel (bucket_min=2048) and of the plain kernel (bucket_min huge)."""
-    from toothgroupnetwork_amd import pointops as P
-    monkeypatch.setenv("TGN_FPS_BUCKET_MIN", bucket_min)
+    from toothgroupnetwork_amd import _lib, pointops as P
     xyz = synth.uniform_cloud(n, seed=n)
     off, noff = np.array([n], np.int32), np.array([m], np.int32)
-    got = P.furthestsampling(T(xyz, dev), T(off, dev), T(noff, dev))
+    with _lib.tuning(fps_bucket_min=bucket_min):
+        got = P.furthestsampling(T(xyz, dev), T(off, dev), T(noff, dev))
     assert got.dtype == torch.int32
     assert np.array_equal(got.cpu().numpy(), oracle.furthestsampling(xyz, off, noff))
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
-def test_fps_bucket_kernel_ties_nan_and_modes(dev, oracle, mode, monkeypatch):
+def test_fps_bucket_kernel_ties_nan_and_modes(dev, oracle, mode):
     """Clouds large enough for the bucket-skipping kernel: exact ties (lattice + duplicated vertices), NaN
     coordinates, ragged packed batch, all four arithmetic / tie-order modes, against the oracle."""
     from toothgroupnetwork_amd import _lib
-    monkeypatch.setenv("TGN_FPS_BUCKET_MIN", "2048")              # force the bucket kernel for these small clouds
     flags = (_lib.FPS_FMA if mode & 1 else 0) | (_lib.FPS_TREE_TIES if mode & 2 else 0)
     lat = synth.lattice_cloud(16, dup=300, seed=7)                 # 4396 points, many exact ties
     arch = synth.arch_cloud(9000, 3, False)
@@ -60,17 +59,18 @@ def test_fps_bucket_kernel_ties_nan_and_modes(dev, oracle, mode, monkeypatch):
     noff_np = np.cumsum([1500, 1200, 2500]).astype(np.int32)       # last cloud: every point gets sampled
     xyz, off, noff = T(xyz_np, dev), T(off_np, dev), T(noff_np, dev)
     out = torch.empty(int(noff_np[-1]), dtype=torch.int32, device=dev)
-    _lib.check(_lib.lib().tgn_furthestsampling(3, 9000, _lib.ptr(xyz), _lib.ptr(off), _lib.ptr(noff), None,
-                                               _lib.ptr(out), None, flags, _lib.stream()))
+    with _lib.tuning(fps_bucket_min=2048):                          # force the bucket kernel for these small clouds
+        _lib.check(_lib.lib().tgn_furthestsampling(3, 9000, _lib.ptr(xyz), _lib.ptr(off), _lib.ptr(noff), None,
+                                                   _lib.ptr(out), None, flags, _lib.stream()))
     assert np.array_equal(out.cpu().numpy(), oracle.furthestsampling(xyz_np, off_np, noff_np, mode=mode))
 
 
-def test_fps_bucket_kernel_equals_plain_kernel(dev, monkeypatch):
-    from toothgroupnetwork_amd import pointnet2_utils as U
+def test_fps_bucket_kernel_equals_plain_kernel(dev):
+    from toothgroupnetwork_amd import _lib, pointnet2_utils as U
     xyz = T(np.stack([synth.arch_cloud(24000, s, False) for s in (40, 41)]), dev)
     a = U.farthest_point_sample(xyz, 4096)
-    monkeypatch.setenv("TGN_FPS_V1", "1")
-    b = U.farthest_point_sample(xyz, 4096)
+    with _lib.tuning(fps_plain=1):
+        b = U.farthest_point_sample(xyz, 4096)
     assert torch.equal(a, b)
 
 

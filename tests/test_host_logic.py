@@ -255,3 +255,42 @@ def test_derived_operand_memo_follows_the_parameters():
     seq = nn.Sequential(nn.Linear(8, 8), nn.BatchNorm1d(8), nn.ReLU(inplace=True), nn.Linear(8, 4)).eval()
     with torch.no_grad():
         assert torch.allclose(PT.mlp_eval(seq, x.clone()), seq(x.clone()), atol=1e-6)
+
+
+def test_derived_operand_memo_follows_storage_swaps_and_copies():
+    """toothgroupnetwork_amd/_derived.py: a memoised operand must be rebuilt when a source parameter is written in place (version),
+    when its storage is swapped under the same Parameter object (`module.double()`, `.to(device)`, `p.data = ...`: same object, same
+    version -- the storage address / device / dtype part of the key), and must not travel with a deep copy of the module."""
+    import copy
+
+    import torch
+
+    from toothgroupnetwork_amd import _derived
+    lin = torch.nn.Linear(4, 3)
+    builds = []
+
+    def build():
+        builds.append(1)
+        return lin.weight.detach().clone() * 2
+
+    def get(m=lin):
+        return _derived.cached(m, "w2", _derived.sources(m), None, build)
+    a = get()
+    assert get() is a and len(builds) == 1                                   # memo hit
+    with torch.no_grad():
+        lin.weight.mul_(3.0)                                                 # in-place write: version counter
+    b = get()
+    assert len(builds) == 2 and torch.equal(b, lin.weight.detach() * 2)
+    w, v = lin.weight, lin.weight._version
+    lin.double()                                                             # same Parameter object, same version, new storage
+    assert lin.weight is w and lin.weight._version == v
+    c = get()
+    assert len(builds) == 3 and c.dtype == torch.float64
+    lin.weight.data = torch.ones(3, 4, dtype=torch.float64)                  # storage swapped by hand
+    d = get()
+    assert len(builds) == 4 and torch.equal(d, torch.full((3, 4), 2.0, dtype=torch.float64))
+    twin = copy.deepcopy(lin)
+    assert not twin.__dict__.get("_tgn_derived")                             # the copy starts with an empty memo
+    _derived.invalidate(lin)
+    get()
+    assert len(builds) == 5

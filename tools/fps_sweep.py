@@ -2,7 +2,7 @@
 """Time the FPS kernel shapes (threads x points-per-lane) on the GPU box: us per iteration and ms per launch.
 
     python tools/fps_sweep.py [--batch 256]
-Forces each instantiated shape with TGN_FPS_CONFIG and times it with HIP events on the launch stream."""
+Forces each instantiated shape with _lib.set_tuning("fps_config", (nt, p)) and times it with HIP events on the launch stream."""
 import argparse
 import os
 import sys
@@ -22,10 +22,7 @@ def time_fps(B, N, S, cfg, flags=0, reps=3):
     xyz = torch.from_numpy(np.stack([synth.arch_cloud(N, s, False) for s in range(min(B, 4))])).to(dev)
     xyz = xyz.repeat((B + 3) // 4, 1, 1)[:B].contiguous()
     idx = torch.empty(B, S, dtype=torch.int32, device=dev)
-    if cfg:
-        os.environ["TGN_FPS_CONFIG"] = f"{cfg[0]},{cfg[1]}"
-    else:
-        os.environ.pop("TGN_FPS_CONFIG", None)
+    _lib.set_tuning("fps_config", cfg if cfg else 0)
     L = _lib.lib()
     ts = []
     for r in range(reps + 1):
@@ -44,20 +41,17 @@ def bucket_sweep(batch):
     """bucket-skipping kernel (fps_bucket.hip) per shape vs the plain kernel."""
     shapes = [(256, 8), (256, 16), (512, 16), (512, 24), (512, 32), (512, 48), (512, 56)]
     for (N, S) in [(24000, 4096), (4096, 1024), (6000, 1500), (3072, 768)]:
-        os.environ["TGN_FPS_V1"] = "1"
-        ms1, ref = time_fps(batch, N, S, None)
-        os.environ.pop("TGN_FPS_V1")
+        with _lib.tuning(fps_plain=1):
+            ms1, ref = time_fps(batch, N, S, None)
         print(f"N={N:6d} S={S:5d} B={batch:4d} plain            {ms1:9.3f} ms {1e3 * ms1 / (S - 1):7.3f} us/iter", flush=True)
         for nt, p in shapes:
             if nt * p < N or nt * p > 4 * N:
                 continue
-            os.environ["TGN_FPS_BUCKET_CONFIG"] = f"{nt},{p}"
-            os.environ["TGN_FPS_BUCKET_MIN"] = "0"
-            for B in sorted({1, batch}):
-                ms, idx = time_fps(B, N, S, None)
-                print(f"N={N:6d} S={S:5d} B={B:4d} bucket {nt:4d}x{p:<2d}   {ms:9.3f} ms {1e3 * ms / (S - 1):7.3f} us/iter  "
-                      f"same_idx={bool(torch.equal(idx[0], ref[0]))}", flush=True)
-            os.environ.pop("TGN_FPS_BUCKET_CONFIG")
+            with _lib.tuning(fps_bucket_config=(nt, p), fps_bucket_min=0):
+                for B in sorted({1, batch}):
+                    ms, idx = time_fps(B, N, S, None)
+                    print(f"N={N:6d} S={S:5d} B={B:4d} bucket {nt:4d}x{p:<2d}   {ms:9.3f} ms {1e3 * ms / (S - 1):7.3f} us/iter  "
+                          f"same_idx={bool(torch.equal(idx[0], ref[0]))}", flush=True)
 
 
 def main():
@@ -67,7 +61,7 @@ def main():
     args = ap.parse_args()
     if args.bucket:
         return bucket_sweep(args.batch)
-    os.environ["TGN_FPS_V1"] = "1"
+    _lib.set_tuning("fps_plain", 1)
     for (N, S) in [(4096, 1024), (1024, 256), (6000, 1500), (3072, 768), (1500, 375)]:
         ref = None
         for cfg in CONFIGS:

@@ -7,7 +7,7 @@ import torch
 from toothgroupnetwork_amd import _lib, hotpath, synth
 import numpy as np
 dev = torch.device("cuda"); L = _lib.lib(); B = 256
-os.environ.setdefault("TGN_FPS_BUCKET_CONFIG", "512,47")
+_lib.set_tuning("fps_bucket_config", (512, 47))
 scans = synth.scan_batch(4, 24000, "arch", 5)
 xyz = torch.from_numpy(np.concatenate([scans[:, :, :3]] * 64)).to(dev).contiguous()
 idx = torch.empty(B, 4096, dtype=torch.int32, device=dev); nx = torch.empty(B, 4096, 3, device=dev)

@@ -28,6 +28,8 @@ SIGNATURES = {
     "tgn_set_default_stream": (None, [_P]),
     "tgn_set_fps_mode": (None, [c_int]),
     "tgn_get_fps_mode": (c_int, []),
+    "tgn_set_tuning": (c_int, [ctypes.c_char_p, c_int]),
+    "tgn_get_tuning": (c_int, [ctypes.c_char_p, c_int]),
     # section 1: the reference's launchers
     "furthestsampling_cuda_launcher": (None, [c_int, c_int, _P, _P, _P, _P, _P]),
     "knnquery_cuda_launcher": (None, [c_int, c_int, _P, _P, _P, _P, _P, _P]),
@@ -141,6 +143,35 @@ def set_fps_mode(ties=None, fma=None):
 
 def get_fps_mode():
     return _fps_mode["ties"], _fps_mode["fma"]
+
+
+def set_tuning(key, value):
+    """Select a kernel variant inside the library (include/tgn_pointops.h: tgn_set_tuning; keys "fps_plain", "fps_config",
+    "fps_bucket_config", "fps_cell_bits", "fps_bucket_min", "ball_bitmap", "ball_pair", "knn_memset", "knn_grid_scale").
+    (nt, p) pairs are given as tuples.  Returns the previous value.  Experiments and parity tests only."""
+    if isinstance(value, (tuple, list)):
+        value = int(value[0]) * 256 + int(value[1])
+    k = key.encode()
+    prev = lib().tgn_get_tuning(k, 0)
+    check(lib().tgn_set_tuning(k, int(value)), "tgn_set_tuning")
+    return prev
+
+
+class tuning:
+    """`with tuning(fps_plain=1, fps_bucket_min=2048): ...` -- kernel-variant switches for the duration of a block."""
+
+    def __init__(self, **kv):
+        self.kv, self.prev = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.prev[k] = set_tuning(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            set_tuning(k, v)
+        return False
 
 
 def fps_flags(cuda_compat=False):

@@ -697,7 +697,7 @@ static int ball_query_impl(int B, int N, int S, int nsample, float r2, const flo
             if (int rc = check_launch("ball_grid_build_kernel")) return rc;
         }
         if (!query) return TGN_OK;
-        static const int bitmap_ok = getenv("TGN_BALL_BITMAP") ? atoi(getenv("TGN_BALL_BITMAP")) : 1;   // 0: the rank-select kernel (experiments)
+        const int bitmap_ok = tuning(kTuneBallBitmap);   // 0: the rank-select kernel (experiments)
         if (bitmap_ok && N <= kBmMaxN) {
             const int nquad = (N + 8191) >> 13;
             const size_t lds = (size_t)4 * (nquad * 256 + nquad * 64 + kBmHitCap) * sizeof(unsigned);   // <= 24 KiB per workgroup

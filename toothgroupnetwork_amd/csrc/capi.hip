@@ -1,10 +1,13 @@
 // capi.hip -- library-wide state of libtgn_pointops.so: version string, per-thread error text, the per-thread
-// stream used by the reference-signature entry points (which have no stream argument) and the per-device
-// index-error word of the gather family.
+// stream used by the reference-signature entry points (which have no stream argument), the per-(device, stream)
+// index-error words of the gather family and the kernel-variant switches.
 #include "tgn_common.h"
 
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
 
+#include <atomic>
 #include <mutex>
 
 namespace tgn {
@@ -22,38 +25,100 @@ void set_error(const char *fmt, ...) {
 
 hipStream_t default_stream() { return g_default_stream; }
 
-// One error word per device, created on first use under a lock (the kernels of a device OR into the word that
-// lives in that device's memory; a single static would be written across GPUs with two devices in one process).
-constexpr int kMaxDevices = 64;
-static int *g_err_word[kMaxDevices] = {};
+// One error word per (device, stream), created on first use under a lock: the kernels launched on a stream OR into that
+// stream's word, which lives in that device's memory.  (One word per device was shared by every host thread: a loader thread's
+// tgn_clear_index_error could erase the bit another stream had just latched.)  Words are carved from one 1-KiB block per
+// device; the 257th stream of a device shares word 0.
+constexpr int kMaxDevices = 64, kWordsPerDevice = 256;
+struct ErrWords {
+    int *block = nullptr;
+    int used = 0;
+    hipStream_t owner[kWordsPerDevice];
+};
+static ErrWords g_err[kMaxDevices];
 static std::mutex g_err_mutex;
 
-int *index_error_word() {
+int *index_error_word(hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
     std::lock_guard<std::mutex> lock(g_err_mutex);
-    if (!g_err_word[dev]) {
+    ErrWords &e = g_err[dev];
+    if (!e.block) {
         int *w = nullptr;
-        if (hipMalloc((void **)&w, sizeof(int)) != hipSuccess) return nullptr;
-        if (hipMemset(w, 0, sizeof(int)) != hipSuccess) {
+        if (hipMalloc((void **)&w, kWordsPerDevice * sizeof(int)) != hipSuccess) return nullptr;
+        if (hipMemset(w, 0, kWordsPerDevice * sizeof(int)) != hipSuccess) {
             (void)hipFree(w);
             return nullptr;
         }
-        g_err_word[dev] = w;
+        e.block = w;
     }
-    return g_err_word[dev];
+    for (int i = 0; i < e.used; ++i)
+        if (e.owner[i] == stream) return e.block + i;
+    if (e.used == kWordsPerDevice) return e.block;
+    e.owner[e.used] = stream;
+    return e.block + e.used++;
 }
 
+// ---- kernel-variant switches ------------------------------------------------------------------------------------------
+struct TuneEntry {
+    const char *key, *env;   // env: the legacy environment name that seeds the entry when the library is loaded
+    int def;
+};
+static const TuneEntry kTune[kTuneCount] = {
+    {"fps_plain", "TGN_FPS_V1", 0},           {"fps_config", "TGN_FPS_CONFIG", 0},       {"fps_bucket_config", "TGN_FPS_BUCKET_CONFIG", 0},
+    {"fps_cell_bits", "TGN_FPS_CELL_BITS", 4}, {"fps_bucket_min", "TGN_FPS_BUCKET_MIN", -1}, {"ball_bitmap", "TGN_BALL_BITMAP", 1},
+    {"knn_memset", "TGN_KNN_MEMSET", 0},      {"knn_grid_scale", "TGN_KNN_GRID_SCALE", 1000}, {"ball_pair", "TGN_BALL_PAIR", 1},
+};
+static std::atomic<int> g_tune[kTuneCount];
+static const bool g_tune_seeded = [] {   // runs once, at load time, before any launch can read the table
+    for (int i = 0; i < kTuneCount; ++i) {
+        int v = kTune[i].def;
+        if (const char *e = getenv(kTune[i].env)) {
+            int a = 0, b = 0;
+            if (i == kTuneFpsConfig || i == kTuneFpsBucketConfig)
+                v = sscanf(e, "%d,%d", &a, &b) == 2 ? a * 256 + b : 0;
+            else if (i == kTuneKnnGridScale)
+                v = (int)(atof(e) * 1000.0 + 0.5);
+            else
+                v = atoi(e);
+        }
+        g_tune[i].store(v, std::memory_order_relaxed);
+    }
+    return true;
+}();
+
+int tuning(Tuning t) { return g_tune[t].load(std::memory_order_relaxed); }
+
 }  // namespace tgn
+
+// Select a kernel variant (experiments, A/B runs, the parity tests that must reach every variant).  Thread-safe; takes effect
+// for launches enqueued after the call.  Returns TGN_ERR_INVALID_ARGUMENT for an unknown key.
+TGN_API int tgn_set_tuning(const char *key, int value) {
+    if (key)
+        for (int i = 0; i < tgn::kTuneCount; ++i)
+            if (!strcmp(key, tgn::kTune[i].key)) {
+                tgn::g_tune[i].store(value, std::memory_order_relaxed);
+                return TGN_OK;
+            }
+    tgn::set_error("tgn_set_tuning: unknown key '%s'", key ? key : "(null)");
+    return TGN_ERR_INVALID_ARGUMENT;
+}
+// Current value of a switch; `fallback` for an unknown key.
+TGN_API int tgn_get_tuning(const char *key, int fallback) {
+    if (key)
+        for (int i = 0; i < tgn::kTuneCount; ++i)
+            if (!strcmp(key, tgn::kTune[i].key)) return tgn::tuning((tgn::Tuning)i);
+    return fallback;
+}
 
 TGN_API const char *tgn_version(void) { return "tgn_pointops 0.3.0 (gfx950)"; }
 TGN_API const char *tgn_last_error(void) { return tgn::g_error; }
 TGN_API void tgn_set_default_stream(tgn_stream_t stream) { tgn::g_default_stream = (hipStream_t)stream; }
 
-// Returns the OR of the error bits latched on the current device since the last call (and clears them):
+// Returns the OR of the error bits latched by launches on `stream` of the current device since the last call (and clears them):
 // bit 0 = a gather / grouping saw an index outside [-N, N).  Synchronises `stream`.
 TGN_API int tgn_take_index_error(tgn_stream_t stream) {
-    int *w = tgn::index_error_word();
+    int *w = tgn::index_error_word((hipStream_t)stream);
     if (!w) return 0;
     int h = 0;
     if (hipMemcpyAsync(&h, w, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return 0;
@@ -66,7 +131,7 @@ TGN_API int tgn_take_index_error(tgn_stream_t stream) {
 // its own launch so that a bit left by an UNCHECKED launch (a planner, a captured graph, TGN_INDEX_CHECK=off sections) is not
 // blamed on it.
 TGN_API int tgn_clear_index_error(tgn_stream_t stream) {
-    int *w = tgn::index_error_word();
+    int *w = tgn::index_error_word((hipStream_t)stream);
     if (!w) return TGN_OK;
     return hipMemsetAsync(w, 0, sizeof(int), (hipStream_t)stream) == hipSuccess ? TGN_OK : TGN_ERR_LAUNCH;
 }

@@ -208,15 +208,14 @@ static int fps_capacity() {
 }
 
 static bool fps_pick(int n_max, FpsConfig &out) {
-    // experiments: TGN_FPS_CONFIG="NT,P" forces an instantiated shape when it is large enough
-    if (const char *e = getenv("TGN_FPS_CONFIG")) {
-        int nt = 0, p = 0;
-        if (sscanf(e, "%d,%d", &nt, &p) == 2)
-            for (int i = 0; i < kNumConfigs; ++i)
-                if (kConfigs[i].nt == nt && kConfigs[i].p == p && nt * p >= n_max) {
-                    out = kConfigs[i];
-                    return true;
-                }
+    // experiments: tgn_set_tuning("fps_config", NT * 256 + P) forces an instantiated shape when it is large enough
+    if (const int forced = tuning(kTuneFpsConfig)) {
+        const int nt = forced >> 8, p = forced & 255;
+        for (int i = 0; i < kNumConfigs; ++i)
+            if (kConfigs[i].nt == nt && kConfigs[i].p == p && nt * p >= n_max) {
+                out = kConfigs[i];
+                return true;
+            }
     }
     int best = -1;
     for (int i = 0; i < kNumConfigs; ++i) {
@@ -232,8 +231,7 @@ template <int MODE>
 static int fps_launch(int b, int n_max, const FpsArgs &a, hipStream_t stream) {
     FpsConfig cfg;
     {
-        const char *v1 = getenv("TGN_FPS_V1");  // experiments: force the plain (no skipping) kernels
-        if (!(v1 && v1[0] == '1')) {
+        if (!tuning(kTuneFpsPlain)) {   // experiments: "fps_plain" forces the plain (no skipping) kernels
             const int rc = fps_bucket_launch(MODE, b, n_max, a, stream);
             if (rc >= 0) return rc;
         }

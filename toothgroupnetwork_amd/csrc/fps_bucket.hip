@@ -924,8 +924,9 @@ int fps_bucket_stream_launch(int mode, int b, int n_max, const FpsArgs &a, hipSt
 template <int MODE>
 static int bucket_launch_mode(int b, int n_max, const FpsArgs &a, hipStream_t stream) {
     int nt = 0, p = 0;
-    if (const char *e = getenv("TGN_FPS_BUCKET_CONFIG")) {  // experiments: force a shape
-        if (sscanf(e, "%d,%d", &nt, &p) != 2 || nt * p < n_max) nt = p = 0;
+    if (const int forced = tuning(kTuneFpsBucketConfig)) {  // experiments: force a shape
+        nt = forced >> 8, p = forced & 255;
+        if (nt * p < n_max) nt = p = 0;
     }
     if (!nt) {
         int best = 1 << 30;
@@ -938,8 +939,8 @@ static int bucket_launch_mode(int b, int n_max, const FpsArgs &a, hipStream_t st
         TGN_FPS_BUCKET_CONFIGS(X)
 #undef X
     }
-    if constexpr (MODE == 0) {   // experiments: TGN_FPS_CELL_BITS=5 selects the 15-bit cell codes of round 1 (116 KiB of LDS)
-        static const int cell_bits = getenv("TGN_FPS_CELL_BITS") ? atoi(getenv("TGN_FPS_CELL_BITS")) : 4;
+    if constexpr (MODE == 0) {   // experiments: "fps_cell_bits" = 5 selects the 15-bit cell codes of round 1 (116 KiB of LDS)
+        const int cell_bits = tuning(kTuneFpsCellBits);
 #define X(NT_, P_)                                                                                              \
     if (cell_bits == 5 && nt == NT_ && p == P_ && !(a.flags & 0x100)) {                                          \
         hipLaunchKernelGGL((fps_bucket_kernel<NT_, P_, MODE, false, 5>), dim3(b), dim3(NT_), 0, stream, a);     \
@@ -967,9 +968,9 @@ static int bucket_launch_mode(int b, int n_max, const FpsArgs &a, hipStream_t st
 int fps_bucket_launch(int mode, int b, int n_max, const FpsArgs &a, hipStream_t stream) {
     // Measured (profiles/r01_fps_bucket_sweep.txt): 24 000 points 0.89 vs 2.25 us per iteration, 6000 points 0.79 vs
     // 0.98, 4096 points 0.78 vs 0.72 -- there the plain kernel wins (8 points per lane: its whole iteration is already
-    // fixed cost).  TGN_FPS_BUCKET_MIN overrides.
+    // fixed cost).  tgn_set_tuning("fps_bucket_min") overrides.
     int min_n = (a.flags & TGN_FPS_LOW_VALU) ? 2048 : 4097;
-    if (const char *e = getenv("TGN_FPS_BUCKET_MIN")) min_n = atoi(e);
+    if (const int forced = tuning(kTuneFpsBucketMin); forced >= 0) min_n = forced;
     if (n_max < min_n) return -1;
     switch (mode) {  // bit 0 FMA, bit 1 tree ties, bit 2 certificate tracking (never with tree ties)
         case 0: return bucket_launch_mode<0>(b, n_max, a, stream);

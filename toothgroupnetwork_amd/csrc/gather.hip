@@ -396,7 +396,7 @@ static int sa_first_layer_launch(int B, int N, int S, int K, int C, const float 
         set_error("tgn_sa_first_layer: nsample %d / channels %d out of the supported range", K, C);
         return TGN_ERR_UNSUPPORTED;
     }
-    int *err = index_error_word();
+    int *err = index_error_word(st);
     if (C == 1) {  // e / C as umulhi(e, ceil(2^32 / C)) needs the magic to fit 32 bits
         set_error("tgn_sa_first_layer: a single output channel is not supported by the fused kernel");
         return TGN_ERR_UNSUPPORTED;
@@ -429,7 +429,7 @@ TGN_API int tgn_gather_points(int B, int N, int M, int C, const float *points, c
                               float *out, tgn_stream_t stream) {
     const long long rows = (long long)B * M;
     if (rows <= 0 || C <= 0) return TGN_OK;
-    int *err = index_error_word();
+    int *err = index_error_word((hipStream_t)stream);
     const RowShape s = row_shape(rows, C);
     if (idx_is_int64)
         hipLaunchKernelGGL((gather_points_kernel<long long>), dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, N,

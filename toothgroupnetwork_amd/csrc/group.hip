@@ -663,7 +663,7 @@ TGN_API int tgn_group_points_ex(int B, int N, int S, int K, int D, const float *
         return TGN_ERR_INVALID_ARGUMENT;
     }
     if (max_blocks < 0) max_blocks = 0;
-    int *err = index_error_word();
+    int *err = index_error_word((hipStream_t)stream);
     const int C = 3 + D;
     const unsigned magicC = (unsigned)((0x100000000ULL + C - 1) / C);
     const float *pts = points ? points : xyz;

@@ -714,8 +714,7 @@ __global__ void knn_zero_word_kernel(int *w) { *w = 0; }
 // memset node of the HIP graph, and replays of graphs holding such a node on a block of torch's private pool faulted on
 // ROCm 7.2 whenever an eager allocation happened between two replays (tools/experiments/pt_capture_parts.py).
 static int zero_redo(int *redo, hipStream_t st) {
-    static const int use_memset = getenv("TGN_KNN_MEMSET") ? atoi(getenv("TGN_KNN_MEMSET")) : 0;
-    if (use_memset) return hipMemsetAsync(redo, 0, sizeof(int), st) == hipSuccess ? 0 : 1;
+    if (tuning(kTuneKnnMemset)) return hipMemsetAsync(redo, 0, sizeof(int), st) == hipSuccess ? 0 : 1;
     hipLaunchKernelGGL(knn_zero_word_kernel, dim3(1), dim3(1), 0, st, redo);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -769,8 +768,7 @@ TGN_API int tgn_knnquery_grid(int b, int n, int m, int nsample, const float *xyz
         set_error("tgn_knnquery_grid: clearing the redo counter failed");
         return TGN_ERR_LAUNCH;
     }
-    float scale = 1.0f;  // cell size relative to the estimated k-neighbour radius (TGN_KNN_GRID_SCALE: experiments)
-    if (const char *e = getenv("TGN_KNN_GRID_SCALE")) scale = (float)atof(e);
+    const float scale = 0.001f * (float)tuning(kTuneKnnGridScale);  // cell size relative to the estimated k-neighbour radius
     hipLaunchKernelGGL(knn_grid_build_kernel, dim3(b), dim3(kKnnBuildThreads), 0, st, b, m, nsample, scale, xyz, offset,
                        (unsigned char *)workspace);
     if (int rc = check_launch("knn_grid_build_kernel")) return rc;

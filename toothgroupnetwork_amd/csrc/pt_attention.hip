@@ -216,6 +216,10 @@ __global__ __launch_bounds__(256) void pt_softmax_aggregate_bwd_kernel(int n, in
             // (The two-pass form read xv and pr a second time, 16 bytes at a time: lanes over (j, g) pairs.)
             const int nbv = lane < (unsigned)nsample ? idx[(size_t)pt * nsample + lane] : 0;
             for (int e = (int)lane; e < nsample * g_; e += 64) dsm[e] = 0.0f;
+            // lanes e % 64 zero the entries, lanes < g_ accumulate into them: a cross-lane LDS hand-off like the ones below
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (int c0 = 0; c0 < c; c0 += 64) {   // wave-uniform trip count: the shuffles need every lane
                 const int ch = c0 + (int)lane;
                 const bool in = ch < c;

@@ -323,7 +323,7 @@ TGN_API int tgn_sa_gather_max(int B, int N, int S, int K, int C1, const float *A
         set_error("tgn_sa_gather_max: needs nsample <= 64, C1 %% 4 == 0, N*C1 < 2^30, 16-byte aligned tensors");
         return TGN_ERR_UNSUPPORTED;
     }
-    int *err = index_error_word();
+    int *err = index_error_word((hipStream_t)stream);
     const long long items = queries * ((C1 + 127) / 128);
     if ((long long)S * ((C1 + 127) / 128) >= (1LL << 31)) {
         set_error("tgn_sa_gather_max: too many queries per scan");
@@ -358,7 +358,7 @@ TGN_API int tgn_sa_direct_max(int B, int N, int S, int K, int D, int C1, const f
         set_error("tgn_sa_direct_max: needs 3+D <= 16, C1 a multiple of 32 up to 256, nsample <= 64");
         return TGN_ERR_UNSUPPORTED;
     }
-    int *err = index_error_word();
+    int *err = index_error_word((hipStream_t)stream);
     long long blocks = ((queries + 3) / 4 + 7) / 8 * 8;
     if (blocks > 256 * 8) blocks = 256 * 8;
     const int ks = (3 + D + 1) / 2, nt = C1 / 32;
@@ -469,7 +469,7 @@ TGN_API int tgn_sa_gather_act(int B, int N, int S, int K, int C1, const float *A
         set_error("tgn_sa_gather_act: needs nsample <= 64, C1 %% 4 == 0, N*C1 < 2^30, 16-byte aligned tensors");
         return TGN_ERR_UNSUPPORTED;
     }
-    int *err = index_error_word();
+    int *err = index_error_word((hipStream_t)stream);
     long long blocks = ((queries + 3) / 4 + 7) / 8 * 8;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (idx_is_int64)

@@ -274,8 +274,8 @@ static int sa_mlp2_launch(const char *who, int B, int N, int S, int K, int D, in
         set_error("%s: too many tiles", who);
         return TGN_ERR_UNSUPPORTED;
     }
-    int *err = idx ? index_error_word() : nullptr;
     hipStream_t st = (hipStream_t)stream;
+    int *err = idx ? index_error_word(st) : nullptr;
     if (direct && !points) points = xyz;   // D == 0: never read
 #define TGN_MLP2(IT, DIR)                                                                                                 \
     if (lds > 48 * 1024)                                                                                                  \

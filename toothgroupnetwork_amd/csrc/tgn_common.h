@@ -17,7 +17,25 @@ constexpr int kWave = 64;
 
 void set_error(const char *fmt, ...);
 hipStream_t default_stream();
-int *index_error_word();  // per-device error word of the gather family (capi.hip); nullptr if it cannot be allocated
+// error word of the gather family for launches on `stream` of the current device (capi.hip): one word per (device, stream), so
+// that host threads driving different streams never clear or take each other's bits; nullptr if it cannot be allocated
+int *index_error_word(hipStream_t stream);
+
+// Kernel-variant switches (capi.hip; include/tgn_pointops.h: tgn_set_tuning).  One table of atomics, read with a relaxed load on
+// the launch paths -- no getenv() there.  The legacy TGN_* environment names seed the table ONCE, when the library is loaded.
+enum Tuning {
+    kTuneFpsPlain = 0,      // "fps_plain": 1 = the plain register-resident / streaming FPS kernels, no bucket skipping
+    kTuneFpsConfig,         // "fps_config": NT * 256 + P forces an instantiated plain-kernel shape (0 = pick)
+    kTuneFpsBucketConfig,   // "fps_bucket_config": NT * 256 + P forces a bucket-kernel shape (0 = pick)
+    kTuneFpsCellBits,       // "fps_cell_bits": 4 (12-bit cell codes, default) or 5 (round 1's 15-bit codes)
+    kTuneFpsBucketMin,      // "fps_bucket_min": smallest cloud the bucket kernel takes (-1 = the built-in thresholds)
+    kTuneBallBitmap,        // "ball_bitmap": 0 = the rank-select ball-query kernel
+    kTuneKnnMemset,         // "knn_memset": 1 = clear the redo counter with hipMemsetAsync (reproduces the graph-replay fault)
+    kTuneKnnGridScale,      // "knn_grid_scale": kNN grid cell size, per mille of the estimated k-neighbour radius (1000)
+    kTuneBallPair,          // "ball_pair": 0 = one query per wave in the level-1 ball query (default 1: two)
+    kTuneCount
+};
+int tuning(Tuning t);
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

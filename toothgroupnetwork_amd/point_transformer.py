@@ -113,12 +113,13 @@ class _LinearSplitK(Function):
                 slices = max(1, min(512, rows // 1024))
                 per = rows // slices
                 main = slices * per
-                gw = torch.bmm(gy2[:main].reshape(slices, per, -1).transpose(1, 2), x2[:main].reshape(slices, per, -1)).sum(0, dtype=torch.float32)
+                acc = torch.promote_types(gy2.dtype, torch.float32)          # bf16 / fp16 slices summed in fp32, float64 stays float64
+                gw = torch.bmm(gy2[:main].reshape(slices, per, -1).transpose(1, 2), x2[:main].reshape(slices, per, -1)).sum(0, dtype=acc)
                 if main < rows:
-                    gw = gw + (gy2[main:].t() @ x2[main:]).float()
+                    gw = gw + (gy2[main:].t() @ x2[main:]).to(acc)
                 gw = gw.to(weight.dtype)
         if gb is None and ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy2.sum(0, dtype=torch.float32).to(weight.dtype)
+            gb = gy2.sum(0, dtype=torch.promote_types(gy2.dtype, torch.float32)).to(weight.dtype)
         return gx, gw, gb
 
 
@@ -136,9 +137,13 @@ class _BNRows(Function):
         y = torch.empty_like(x)
         stat = torch.empty(2, C, dtype=torch.float32, device=x.device)             # batch mean, 1 / sqrt(var + eps)
         mean, invstd = stat[0], stat[1]
-        ws = bn.__dict__.get("_tgn_bn_ws")
-        if ws is None or ws.device != x.device:
-            ws = bn.__dict__["_tgn_bn_ws"] = torch.zeros(int(lib().tgn_bn_rows_workspace_bytes(C)), dtype=torch.uint8, device=x.device)
+        # accumulators + ticket, left zeroed by the kernels: one per (module, device, stream), so that two streams (or DataParallel
+        # replicas, which share the module's __dict__ entries) never meet in one workspace
+        wss = bn.__dict__.setdefault("_tgn_bn_ws", {})
+        wkey = (x.device.index, torch.cuda.current_stream().cuda_stream)
+        ws = wss.get(wkey)
+        if ws is None:
+            ws = wss[wkey] = torch.zeros(int(lib().tgn_bn_rows_workspace_bytes(C)), dtype=torch.uint8, device=x.device)
         track = bn.track_running_stats and bn.running_mean is not None
         check(lib().tgn_bn_rows_forward(rows, C, ptr(x), ptr(weight), ptr(bias), float(bn.eps), float(bn.momentum),
                                         ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
@@ -168,9 +173,16 @@ class _BNRows(Function):
 BN_ROWS = os.environ.get("TGN_BN_ROWS", "1") != "0"
 
 
+def _plain_batchnorm(bn):
+    """Exactly nn.BatchNorm1d, nothing hooked onto it: a subclass (SyncBatchNorm after convert_sync_batchnorm, whose statistics
+    span the ranks) or a module with forward hooks must run its own forward."""
+    return (type(bn) is nn.BatchNorm1d and not bn._forward_hooks and not bn._forward_pre_hooks and not bn._backward_hooks
+            and not bn._backward_pre_hooks)
+
+
 def bn_rows(bn, x, relu=False):
     """[relu](bn(x)) for x (rows, C): the fused kernels in training mode on fp32 CUDA rows, the module otherwise."""
-    if (BN_ROWS and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 2 and x.shape[1] <= 1024
+    if (BN_ROWS and bn.training and _plain_batchnorm(bn) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 2 and x.shape[1] <= 1024
             and bn.affine and bn.momentum is not None and x.is_contiguous() and not torch.is_autocast_enabled()):
         return _BNRows.apply(x, bn.weight, bn.bias, bn, relu)
     y = bn(x)
@@ -179,7 +191,8 @@ def bn_rows(bn, x, relu=False):
 
 def _lin(mod, x):
     """nn.Linear `mod` applied to x; tall inputs in training take the split-K weight gradient."""
-    if torch.is_grad_enabled() and x.numel() // x.shape[-1] >= SPLITK_MIN_ROWS and max(mod.in_features, mod.out_features) <= 256:
+    if (torch.is_grad_enabled() and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
+            and x.numel() // x.shape[-1] >= SPLITK_MIN_ROWS and max(mod.in_features, mod.out_features) <= 256):
         return _LinearSplitK.apply(x, mod.weight, mod.bias)
     return mod(x)
 
