@@ -11,7 +11,8 @@
 Tolerances.  Every comparison is against the float64 evaluation of the reference (`*_64`: the exact value of the same function on
 the same indices) and is elementwise |got - want| <= tol * (1 + |want|).  tol = 1e-5 wherever the reference's own float32 run stays
 inside 1e-5 of the exact value; where it does not (23 residual blocks in fp32; training-mode BatchNorm over 93-point stages) the
-bound is 2x the reference's OWN float32 distance from the exact value, measured on the same entries."""
+bound is the reference's OWN float32 distance from the exact value on the same entries: 2x in the root mean square, 4x in the
+maximum (`_within_reference_noise`)."""
 import os
 import sys
 
@@ -36,6 +37,24 @@ def _err(got, want):
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     assert got.shape == want.shape, (got.shape, want.shape)
     return float(np.max(np.abs(got - want) / (1.0 + np.abs(want))))
+
+
+def _rms(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return float(np.sqrt(np.mean(((got - want) / (1.0 + np.abs(want))) ** 2)))
+
+
+def _within_reference_noise(name, got, ref32, exact):
+    """For outputs whose float32 evaluation is itself far from exact (fp32 through 23 residual blocks): the drop-in's distance from
+    the exact value against the reference's OWN float32 distance, on the same entries.  Both are one draw of rounding noise (ours
+    changes from run to run: atomically accumulated sums), so the comparison uses the root mean square over all entries (a stable
+    statistic: within 2x) and the maximum (the tail of ~10^5 draws: within 4x); anything structural -- a wrong neighbour, a missing
+    term -- is orders of magnitude above either."""
+    e_max, own_max = _err(got, exact), _err(ref32, exact)
+    e_rms, own_rms = _rms(got, exact), _rms(ref32, exact)
+    assert e_rms <= max(1e-6, 2.0 * own_rms), (name, "rms", e_rms, own_rms)
+    assert e_max <= max(1e-5, 4.0 * own_max), (name, "max", e_max, own_max)
+    return dict(max=(e_max, own_max), rms=(e_rms, own_rms))
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -123,12 +142,7 @@ def test_point_transformer_whole_network_at_24000_points(dev, golden_r4):
     with torch.no_grad():
         cls, offset, _, x1 = net([feats])
     got = {"cls": cls.cpu().numpy()[:, :, ::4], "offset": offset.cpu().numpy()[:, :, ::4], "x1": x1.cpu().numpy()[::4]}
-    report = {}
-    for n_ in ("cls", "offset", "x1"):
-        want = golden_r4[f"pt24_{n_}_64"]
-        e, own = _err(got[n_], want), _err(golden_r4[f"pt24_{n_}_32"], want)
-        report[n_] = (e, own)
-        assert e <= max(1e-5, 2.0 * own), (n_, e, own)
+    report = {n_: _within_reference_noise(n_, got[n_], golden_r4[f"pt24_{n_}_32"], golden_r4[f"pt24_{n_}_64"]) for n_ in ("cls", "offset", "x1")}
     print(f"\nPointTransformerSeg at 24 000 points: (drop-in vs exact, reference fp32 vs exact) {report}")
 
 
@@ -179,15 +193,13 @@ def test_training_step_gradients_match_the_reference_network(dev, golden_r4):
     loss = 1.0 * ce + 0.03 * cen + 0.03 * dirl                                                # train_configs/tgnet_fps.py:16-24
     loss.backward()
     t64, t32 = golden_r4["train_terms_64"], golden_r4["train_terms_32"]
-    got_terms = np.array([float(loss), float(ce), float(cen), float(dirl)])
+    got_terms = np.array([float(loss.detach()), float(ce.detach()), float(cen.detach()), float(dirl.detach())])
     print(f"\nloss terms (loss, ce, centroid, dir): drop-in {got_terms}, reference fp64 {t64}, reference fp32 {t32}")
     for g, a, b in zip(got_terms, t64, t32):
         assert abs(g - a) <= max(2.0 * abs(b - a), 2e-5 * abs(a)), (got_terms, t64, t32)
     for n_, t in (("sem", sem), ("offset", offset)):
-        want = golden_r4[f"train_{n_}_64"]
-        e, own = _err(t.detach().cpu().numpy()[:, :, ::16], want), _err(golden_r4[f"train_{n_}_32"], want)
-        print(f"train-mode {n_}: drop-in vs exact {e:.2e}, reference fp32 vs exact {own:.2e}")
-        assert e <= max(1e-5, 2.0 * own), (n_, e, own)
+        rep = _within_reference_noise(n_, t.detach().cpu().numpy()[:, :, ::16], golden_r4[f"train_{n_}_32"], golden_r4[f"train_{n_}_64"])
+        print(f"train-mode {n_}: (drop-in vs exact, reference fp32 vs exact) {rep}")
     # gradients: every parameter the reference gives a gradient gets one (and the mask head, unused by the outputs, gets none)
     grads = {n: p.grad for n, p in net.named_parameters()}
     names = golden_r4["train_grad_names"].tolist()
@@ -213,7 +225,10 @@ def test_training_step_gradients_match_the_reference_network(dev, golden_r4):
     # whole gradient: within 2x the reference's own fp32 distance from the exact gradient
     assert tot_got <= 2.0 * tot_own, (tot_got, tot_own)
     # per parameter: fp32 noise is a random variable, so the per-parameter bound is the larger of 4x the reference's own distance
-    # on the same entries and 2 % of the parameter's gradient (the reference's own median relative distance is 1 %)
+    # on the same entries and 2 % of the parameter's gradient (the reference's own median relative distance is 1 %); the floor is
+    # fp32 resolution at the scale of the network's gradient -- the biases in front of a BatchNorm have an EXACT gradient of zero
+    # (2.6e-15 in float64) and what either fp32 run holds there is the rounding residue of a sum over all rows
+    floor = 1e-6 * (1.0 + tot_ref)
     for n, n64, ng, d_got, d_own, s_ref in rows:
-        assert d_got <= max(4.0 * d_own, 0.02 * s_ref, 1e-7), (n, d_got, d_own, s_ref)
-        assert abs(ng - n64) <= max(4.0 * abs(norms[names.index(n), 1] - n64), 0.02 * n64, 1e-7), (n, ng, n64)
+        assert d_got <= max(4.0 * d_own, 0.02 * s_ref, floor), (n, d_got, d_own, s_ref)
+        assert abs(ng - n64) <= max(4.0 * abs(norms[names.index(n), 1] - n64), 0.02 * n64, 8 * floor), (n, ng, n64)
