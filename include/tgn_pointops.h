@@ -329,6 +329,22 @@ int tgn_sa_mlp2_max(int B, int N, int S, int K, int D, int C1p, int C2, const fl
                     const float *points, const float *new_xyz, const float *W1, const float *b1, const void *idx,
                     int idx_is_int64, const float *W2f, const float *b2, float *out, int out_stride, tgn_stream_t stream);
 /*
+ * The same level with the second layer on the BF16 matrix cores at fp32 accuracy ("bf16x3").  v_mfma_f32_32x32x16_bf16 runs at
+ * 16x the rate of the fp32-input MFMA; both operands are written as sums of three bf16 numbers (24 mantissa bits) and a product is
+ * six bf16 MFMAs with fp32 accumulation -- a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1, the dropped terms are below 2^-24 of the
+ * product -- i.e. fp32-class rounding at up to 16 / 6 = 2.7x the fp32-MFMA rate.  Not bit-identical to tgn_sa_mlp2_max; held to the
+ * same elementwise 1e-5 bound against the float64 oracle.
+ *   tgn_sa_mlp2_split_bytes(C1p, C2)    size of the split weight image;
+ *   tgn_sa_mlp2_split_weights           W2f (C1p/8, C2, 8) fp32 -> image (device to device, once per weight matrix): per 128-column
+ *                                       tile and 16-wide K tile the 12 KiB the kernel's LDS tile holds, fetched by LDS-DMA;
+ *   tgn_sa_mlp2_max_bf16x3              tgn_sa_mlp2_max with W2s (the image) in place of W2f; every other argument as above.
+ */
+size_t tgn_sa_mlp2_split_bytes(int C1p, int C2);
+int tgn_sa_mlp2_split_weights(int C1p, int C2, const float *W2f, void *W2s, tgn_stream_t stream);
+int tgn_sa_mlp2_max_bf16x3(int B, int N, int S, int K, int D, int C1p, int C2, const float *A1, const float *xyz,
+                           const float *points, const float *new_xyz, const float *W1, const float *b1, const void *idx,
+                           int idx_is_int64, const void *W2s, const float *b2, float *out, int out_stride, tgn_stream_t stream);
+/*
  * tgn_sa_all_mlp2_max: PointNetSetAbstraction with group_all=True -- the only form of that module a reference model builds
  * (models/modules/tsg_seg_module.py:28: 515 -> [256, 512] over the 256 points of the last level) -- eval mode, BatchNorms folded:
  *   out[b,:] = max_n relu(W2 * relu(W1 * [x_n, f_n] + b1) + b2)     (pointnet2_utils.py:178-195 + 229-236)     (B,C2)

@@ -227,6 +227,276 @@ __global__ __launch_bounds__(256, 2) void sa_mlp2_max_kernel(long long Q, int N,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same level with the second layer on the BF16 matrix cores at fp32 accuracy ("bf16x3"): v_mfma_f32_32x32x16_bf16 runs at 16x
+// the rate of v_mfma_f32_32x32x2_f32, so an fp32 product computed as SIX bf16 products is still 16 / 6 = 2.7x faster.  Both operands
+// are written as a sum of three bf16 numbers, x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (every
+// subtraction exact in fp32; 24 bits of mantissa kept), and
+//     a * b  ~=  a1 b1 + (a1 b2 + a2 b1) + (a2 b2 + a1 b3 + a3 b1)          dropped: a2 b3 + a3 b2 + a3 b3 <= 3 * 2^-26 |a b|
+// Every bf16 x bf16 product is exact in fp32 and the matrix core accumulates in fp32: the result carries fp32-class error (measured
+// against the float64 oracle in tests/test_gpu_sa_fused.py, elementwise 1e-5 like the fp32-MFMA form).  The weights are split ONCE
+// (tgn_sa_mlp2_split_weights) into the image the kernel's LDS tiles have, so a K tile of B is 12 contiguous KiB that arrive by LDS-DMA
+// (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write); the activations are split in registers behind the ReLU
+// (v_cvt_pk_bf16_f32 + shift / mask + v_pk_add_f32: 36 vector instructions per 8 channels).
+//
+// LDS tile of one operand and K tile (16 k): [component 3][row 128][16 k as bf16 = 32 B]; a lane's MFMA fragment (row l & 31 of a
+// 32-row block, k half l >> 5: 8 consecutive k) is ONE ds_read_b128.  The two 16-B halves of a row are swapped where
+// ((row >> 2) ^ (row >> 3)) & 1: with that, ds_read_b128 (lane groups of 16, 64 banks) and ds_write_b128 (8 contiguous lanes, 32
+// banks) are both free of bank conflicts (checked by enumeration, tools/lds_swizzle_check.py).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kSplitPlane = 128 * 32;         // bytes: one bf16 component of one operand tile
+constexpr int kSplitTile = 3 * kSplitPlane;   // 12 KiB
+
+__device__ __forceinline__ int split_chunk(int row, int khalf) {
+    return row * 32 + ((khalf ^ (((row >> 2) ^ (row >> 3)) & 1)) << 4);
+}
+
+// x[0..7] -> three bf16x8 (components 1, 2, 3)
+__device__ __forceinline__ void split3(const float *x, bf16x8 &c1, bf16x8 &c2, bf16x8 &c3) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2 v = {x[i], x[i + 1]};
+        const bf16x2 p1 = __builtin_convertvector(v, bf16x2);
+        const f32x2 r1 = v - __builtin_convertvector(p1, f32x2);
+        const bf16x2 p2 = __builtin_convertvector(r1, bf16x2);
+        const f32x2 r2 = r1 - __builtin_convertvector(p2, f32x2);
+        const bf16x2 p3 = __builtin_convertvector(r2, bf16x2);
+        c1[i] = p1[0], c1[i + 1] = p1[1];
+        c2[i] = p2[0], c2[i + 1] = p2[1];
+        c3[i] = p3[0], c3[i + 1] = p3[1];
+    }
+}
+
+// W2f (C1p/8, C2, 8) fp32 -> the kernel's B image: [column tile of 128][K tile of 16][component][column][swizzled 32 B]
+__global__ __launch_bounds__(256) void sa_mlp2_split_weights_kernel(int C1p, int C2, const float *__restrict__ W2f,
+                                                                    unsigned char *__restrict__ W2s) {
+    const int T = C1p / kMlpKT;
+    const long long chunks = (long long)((C2 + kMlpNT - 1) / kMlpNT) * T * 256;   // (column, k half) pairs
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= chunks) return;
+    const int col = (int)(i & 127), khalf = (int)((i >> 7) & 1);
+    const long long tile = i >> 8;   // nt * T + t
+    const int t = (int)(tile % T), nt = (int)(tile / T);
+    const int c = nt * kMlpNT + col;
+    float w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = c < C2 ? W2f[((size_t)(2 * t + khalf) * C2 + c) * 8 + k] : 0.0f;
+    bf16x8 c1, c2, c3;
+    split3(w, c1, c2, c3);
+    unsigned char *dst = W2s + (size_t)tile * kSplitTile + split_chunk(col, khalf);
+    *(bf16x8 *)dst = c1;
+    *(bf16x8 *)(dst + kSplitPlane) = c2;
+    *(bf16x8 *)(dst + 2 * kSplitPlane) = c3;
+}
+
+template <typename IdxT, bool DIRECT>
+__global__ __launch_bounds__(256, 2) void sa_mlp2_max_split_kernel(long long Q, int N, int S, int K, int D, int C1p, int C2, int ostride,
+                                                                    const float *__restrict__ A1, const float *__restrict__ xyz,
+                                                                    const float *__restrict__ points, const float *__restrict__ new_xyz,
+                                                                    const float *__restrict__ W1, const float *__restrict__ b1,
+                                                                    const IdxT *__restrict__ idx,
+                                                                    const unsigned char *__restrict__ W2s,   // split image of W2
+                                                                    const float *__restrict__ b2, float *__restrict__ out,
+                                                                    int *__restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char *FA = smem_b, *FB = smem_b + 2 * kSplitTile;
+    float *cst = (float *)(smem_b + 4 * kSplitTile);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int kshift = K > 32 ? 6 : 5, Kp = 1 << kshift, QPT = kMlpMT >> kshift;
+    const unsigned ntiles = ((unsigned)C2 + kMlpNT - 1) / kMlpNT;
+    const long long mtiles = (Q + QPT - 1) / QPT;
+    const unsigned nb = gridDim.x;
+    const long long item = (long long)(blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
+    const long long mt = item / ntiles;
+    if (mt >= mtiles) return;
+    const int ntile = (int)(item - mt * ntiles);
+    const int col0 = ntile * kMlpNT;
+    const long long q0 = mt * QPT;
+    const int T = C1p / kMlpKT;
+
+    // ---- producer of A: thread (row ar, k half ah) makes 8 consecutive channels of one (query, neighbour) row per K tile
+    const int ar = tid & 127;
+    const int ah = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int ql = ar >> kshift;
+    long long q = q0 + ql;
+    if (q >= Q) q = Q - 1;
+    const int b = (int)(q / S);
+    int kk = ar & (Kp - 1);
+    if (kk >= K) kk = 0;
+    long long v;
+    if (idx) {
+        v = (long long)idx[q * K + kk];
+        if (v < 0) v += N;
+        bool bad = false;
+        if (v < 0 || v >= N) {
+            bad = true;
+            v = 0;
+        }
+        if (err && col0 == 0 && bad) atomicOr(err, 1);
+    } else {
+        const long long first = (q - (long long)b * S) * Kp;
+        v = first + kk < N ? first + kk : first;
+    }
+    const float *__restrict__ arow = A1 + ((size_t)b * N + (size_t)v) * C1p + ah * 8;
+    float g[16];
+    if (DIRECT) {
+        const float *__restrict__ px = xyz + ((size_t)b * N + (size_t)v) * 3;
+        const float *__restrict__ pf = points + ((size_t)b * N + (size_t)v) * D;
+        g[0] = px[0] - (new_xyz ? new_xyz[q * 3 + 0] : 0.0f);
+        g[1] = px[1] - (new_xyz ? new_xyz[q * 3 + 1] : 0.0f);
+        g[2] = px[2] - (new_xyz ? new_xyz[q * 3 + 2] : 0.0f);
+#pragma unroll
+        for (int j = 3; j < 16; ++j) g[j] = j - 3 < D ? pf[j - 3] : 0.0f;
+    } else {
+        for (int l = 0; l < QPT; ++l) {
+            long long qq = q0 + l;
+            if (qq >= Q) qq = Q - 1;
+            if (!new_xyz) {
+                for (int c = tid; c < C1p; c += 256) cst[l * C1p + c] = b1[c];
+                continue;
+            }
+            const float cx = new_xyz[qq * 3 + 0], cy = new_xyz[qq * 3 + 1], cz = new_xyz[qq * 3 + 2];
+            for (int c = tid; c < C1p; c += 256)
+                cst[l * C1p + c] = b1[c] - ((W1[c] * cx + W1[C1p + c] * cy) + W1[2 * C1p + c] * cz);
+        }
+    }
+    // ---- B: K tile t of this column tile is 12 contiguous KiB of the image; wave wv moves pieces 3 wv .. 3 wv + 2 (1 KiB each)
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(W2s + (size_t)ntile * T * kSplitTile), 0, T * kSplitTile, 0x00020000);
+    auto dma = [&](int t, int buf) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int piece = wv * 3 + p;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(FB + buf * kSplitTile + piece * 1024), 16,
+                                                     lane * 16, t * kSplitTile + piece * 1024, 0, 0);
+        }
+    };
+    f32x4 ra0, ra1;
+    auto fetch = [&](int t) {
+        if (!DIRECT) {
+            ra0 = *(const f32x4 *)(arow + t * kMlpKT);
+            ra1 = *(const f32x4 *)(arow + t * kMlpKT + 4);
+        }
+    };
+    auto stage = [&](int t, int buf) {
+        float h[8];
+        if (DIRECT) {
+            const float *__restrict__ wd = W1 + t * kMlpKT + ah * 8;   // wave-uniform: scalar loads
+            const float *__restrict__ bb = b1 + t * kMlpKT + ah * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) h[i] = bb[i];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j < 3 + D) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) h[i] = __builtin_fmaf(g[j], wd[(size_t)j * C1p + i], h[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) h[i] = fmaxf(h[i], 0.0f);
+        } else {
+            const float *cs = cst + ql * C1p + t * kMlpKT + ah * 8;
+            const f32x4 c0 = *(const f32x4 *)cs, c1 = *(const f32x4 *)(cs + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                h[i] = fmaxf(ra0[i] + c0[i], 0.0f);
+                h[4 + i] = fmaxf(ra1[i] + c1[i], 0.0f);
+            }
+        }
+        bf16x8 p1, p2, p3;
+        split3(h, p1, p2, p3);
+        unsigned char *fa = FA + buf * kSplitTile + split_chunk(ar, ah);
+        *(bf16x8 *)fa = p1;
+        *(bf16x8 *)(fa + kSplitPlane) = p2;
+        *(bf16x8 *)(fa + 2 * kSplitPlane) = p3;
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    auto compute = [&](int buf) {
+        const unsigned char *fa = FA + buf * kSplitTile, *fb = FB + buf * kSplitTile;
+        bf16x8 a[2][3], w[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ca = split_chunk(wm * 64 + i * 32 + lo, hi), cb = split_chunk(wn * 64 + i * 32 + lo, hi);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                a[i][c] = *(const bf16x8 *)(fa + c * kSplitPlane + ca);
+                w[i][c] = *(const bf16x8 *)(fb + c * kSplitPlane + cb);
+            }
+        }
+        // six products per tile, smallest first; consecutive MFMAs go to different accumulators
+#define TGN_SPLIT_STEP(CA, CB)                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][CA], w[j][CB], acc[i][j], 0, 0, 0)
+        TGN_SPLIT_STEP(2, 0);
+        TGN_SPLIT_STEP(0, 2);
+        TGN_SPLIT_STEP(1, 1);
+        TGN_SPLIT_STEP(1, 0);
+        TGN_SPLIT_STEP(0, 1);
+        TGN_SPLIT_STEP(0, 0);
+#undef TGN_SPLIT_STEP
+    };
+
+    fetch(0);
+    dma(0, 0);
+    __syncthreads();   // cst is complete
+    stage(0, 0);
+    if (T > 1) fetch(1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the LDS-DMA pieces have landed (hipcc orders no ds_read behind them)
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) {
+            dma(t + 1, (t + 1) & 1);     // FB / FA[(t+1)&1] were last read by compute(t-1): every wave is past the barrier that ended it
+            stage(t + 1, (t + 1) & 1);   // from the registers fetch(t+1) filled one iteration ago
+        }
+        if (t + 2 < T) fetch(t + 2);     // in flight under the MFMAs
+        compute(t & 1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+    }
+
+    // ---- max over the rows of a query.  Accumulator register r of lane l is row (r & 3) + 8 (r >> 2) + 4 hi, column lo of its tile.
+    float cm[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float m = acc[i][j][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
+            cm[i][j] = fmaxf(m, __shfl_xor(m, 32));
+        }
+    if (hi == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + wn * 64 + j * 32 + lo;
+            if (col >= C2) continue;
+            const float bias = b2[col];
+            if (kshift == 6) {
+                const long long qq = q0 + wm;
+                if (qq < Q) out[(size_t)qq * ostride + col] = fmaxf(fmaxf(cm[0][j], cm[1][j]) + bias, 0.0f);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const long long qq = q0 + wm * 2 + i;
+                    if (qq < Q) out[(size_t)qq * ostride + col] = fmaxf(cm[i][j] + bias, 0.0f);
+                }
+            }
+        }
+    }
+}
+
 // out[b, c] = max_s part[b, s, c]: the chunks of a group_all level (post-ReLU values, so the order of the two maxima is free)
 __global__ __launch_bounds__(256) void sa_chunks_max_kernel(int B, int S, int C, int ostride, const float *__restrict__ part,
                                                             float *__restrict__ out) {
@@ -249,7 +519,8 @@ TGN_API int tgn_sa_mlp2_direct_supported(int K, int D) { return (D >= 0 && 3 + D
 // shared launcher: idx == nullptr selects the group_all form (chunks of 32 / 64 consecutive points, new_xyz may be null)
 static int sa_mlp2_launch(const char *who, int B, int N, int S, int K, int D, int C1p, int C2, const float *A1, const float *xyz,
                           const float *points, const float *new_xyz, const float *W1, const float *b1, const void *idx,
-                          int idx_is_int64, const float *W2f, const float *b2, float *out, int out_stride, tgn_stream_t stream) {
+                          int idx_is_int64, const float *W2f, const float *b2, float *out, int out_stride, tgn_stream_t stream,
+                          bool split = false) {
     const long long Q = (long long)B * S;
     const bool direct = A1 == nullptr;
     if (!b1 || !W2f || !b2 || !out || (direct && (!xyz || !W1 || (D > 0 && !points))) || (!direct && new_xyz && !W1)) {
@@ -263,6 +534,7 @@ static int sa_mlp2_launch(const char *who, int B, int N, int S, int K, int D, in
         return TGN_ERR_UNSUPPORTED;
     }
     const int qpt = K > 32 ? 2 : 4;
+    static_assert(4 * kFrag * sizeof(float) == 4 * kSplitTile, "both forms keep four 12-KiB operand tiles");
     const size_t lds = (size_t)(4 * kFrag + (direct ? 0 : qpt * C1p)) * sizeof(float);
     if (lds > 80 * 1024) {   // two workgroups per CU
         set_error("%s: first-layer width %d needs %zu bytes of LDS per workgroup (limit 80 KiB)", who, C1p, lds);
@@ -283,6 +555,32 @@ static int sa_mlp2_launch(const char *who, int B, int N, int S, int K, int D, in
                                   80 * 1024);                                                                             \
     hipLaunchKernelGGL((sa_mlp2_max_kernel<IT, DIR>), dim3((unsigned)blocks), dim3(256), lds, st, Q, N, S, K, D, C1p, C2, out_stride, \
                        A1, xyz, points, new_xyz, W1, b1, (const IT *)idx, W2f, b2, out, err)
+#define TGN_MLP2S(IT, DIR)                                                                                                      \
+    if (lds > 48 * 1024)                                                                                                        \
+        (void)hipFuncSetAttribute((const void *)sa_mlp2_max_split_kernel<IT, DIR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  80 * 1024);                                                                                   \
+    hipLaunchKernelGGL((sa_mlp2_max_split_kernel<IT, DIR>), dim3((unsigned)blocks), dim3(256), lds, st, Q, N, S, K, D, C1p, C2,  \
+                       out_stride, A1, xyz, points, new_xyz, W1, b1, (const IT *)idx, (const unsigned char *)W2f, b2, out, err)
+    if (split) {
+        if ((long long)(C1p / kMlpKT) * kSplitTile > 0x7FFFFFFFLL || ((uintptr_t)W2f & 15)) {
+            set_error("%s: split weight image too large or misaligned", who);
+            return TGN_ERR_UNSUPPORTED;
+        }
+        if (idx_is_int64) {
+            if (direct) {
+                TGN_MLP2S(long long, true);
+            } else {
+                TGN_MLP2S(long long, false);
+            }
+        } else {
+            if (direct) {
+                TGN_MLP2S(int, true);
+            } else {
+                TGN_MLP2S(int, false);
+            }
+        }
+        return check_launch("sa_mlp2_max_split_kernel");
+    }
     if (idx_is_int64) {
         if (direct) {
             TGN_MLP2(long long, true);
@@ -297,7 +595,40 @@ static int sa_mlp2_launch(const char *who, int B, int N, int S, int K, int D, in
         }
     }
 #undef TGN_MLP2
+#undef TGN_MLP2S
     return check_launch("sa_mlp2_max_kernel");
+}
+
+// Bytes of the split (bf16 x 3) image of a second-layer weight matrix, and the one-off conversion (device to device, on `stream`).
+TGN_API size_t tgn_sa_mlp2_split_bytes(int C1p, int C2) {
+    if (C1p < 16 || (C1p & 15) || C2 < 1) return 0;
+    return (size_t)((C2 + kMlpNT - 1) / kMlpNT) * (size_t)(C1p / kMlpKT) * kSplitTile;
+}
+
+TGN_API int tgn_sa_mlp2_split_weights(int C1p, int C2, const float *W2f, void *W2s, tgn_stream_t stream) {
+    if (!W2f || !W2s || C1p < 16 || (C1p & 15) || C2 < 1 || ((uintptr_t)W2s & 15)) {
+        set_error("tgn_sa_mlp2_split_weights: needs W2f (C1p/8, C2, 8) with C1p a multiple of 16 and a 16-byte aligned image");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    const long long chunks = (long long)((C2 + kMlpNT - 1) / kMlpNT) * (C1p / kMlpKT) * 256;
+    hipLaunchKernelGGL(sa_mlp2_split_weights_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, C1p, C2,
+                       W2f, (unsigned char *)W2s);
+    return check_launch("sa_mlp2_split_weights_kernel");
+}
+
+// tgn_sa_mlp2_max with the second layer on the bf16 matrix cores at fp32 accuracy (six bf16 products per fp32 product, see the
+// kernel): W2s = tgn_sa_mlp2_split_weights(W2f).  Same arguments and results otherwise (fp32-class rounding, not bit-identical).
+TGN_API int tgn_sa_mlp2_max_bf16x3(int B, int N, int S, int K, int D, int C1p, int C2, const float *A1, const float *xyz,
+                                   const float *points, const float *new_xyz, const float *W1, const float *b1, const void *idx,
+                                   int idx_is_int64, const void *W2s, const float *b2, float *out, int out_stride, tgn_stream_t stream) {
+    if ((long long)B * S <= 0 || C2 <= 0) return TGN_OK;
+    if (out_stride <= 0) out_stride = C2;
+    if (!new_xyz || !W1 || !idx || !W2s) {
+        set_error("tgn_sa_mlp2_max_bf16x3: null pointer");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    return sa_mlp2_launch("tgn_sa_mlp2_max_bf16x3", B, N, S, K, D, C1p, C2, A1, xyz, points, new_xyz, W1, b1, idx, idx_is_int64,
+                          (const float *)W2s, b2, out, out_stride, stream, true);
 }
 
 TGN_API int tgn_sa_mlp2_max(int B, int N, int S, int K, int D, int C1p, int C2, const float *A1, const float *xyz,

@@ -217,6 +217,9 @@ class HotPath:
             W2p[:, :C1] = W2
             out.update(W2f=W2p.view(C2, C1p // 8, 8).permute(1, 0, 2).contiguous().to(device), b2=b2.to(device),
                        direct=bool(self.L.tgn_sa_mlp2_direct_supported(K, D)))
+            from . import pointnet2_utils as U
+            # second layer on the bf16 matrix cores at fp32 accuracy (tgn_sa_mlp2_max_bf16x3) unless TGN_SA_BF16X3=0
+            out["W2s"] = U.split_second_layer(out["W2f"]) if U.SA_BF16X3 else None
         out["layers"] = layers
         out["A"] = None if out["direct"] else torch.empty(self.B, N, C1p, **f32)
         return out
@@ -242,6 +245,11 @@ class HotPath:
             check(L.tgn_sa_point_transform(B * lv["N"], lv["D"], br["C1p"], ptr(cur_xyz), ptr(pts), ptr(br["Wt"]), ptr(br["A"]), st),
                   "sa_point_transform")
         out = br["out"]
+        if br["nlayers"] == 2 and br["W2s"] is not None:
+            return check(L.tgn_sa_mlp2_max_bf16x3(B, lv["N"], lv["S"], br["K"], lv["D"], br["C1p"], br["C_out"], ptr(br["A"]), ptr(cur_xyz),
+                                                  ptr(pts), ptr(lv["new_xyz"]), ptr(br["Wd"] if br["direct"] else br["Wxs"]), ptr(br["b1"]),
+                                                  ptr(br["group_idx"]), self.idx64, ptr(br["W2s"]), ptr(br["b2"]), ptr(out),
+                                                  out.stride(1), st), "sa_mlp2_max_bf16x3")
         if br["nlayers"] == 2:
             return check(L.tgn_sa_mlp2_max(B, lv["N"], lv["S"], br["K"], lv["D"], br["C1p"], br["C_out"], ptr(br["A"]), ptr(cur_xyz),
                                            ptr(pts), ptr(lv["new_xyz"]), ptr(br["Wd"] if br["direct"] else br["Wxs"]), ptr(br["b1"]),

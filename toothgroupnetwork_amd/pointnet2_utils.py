@@ -396,6 +396,9 @@ def three_interpolate(points2, dist, idx):
 # ---------------------------------------------------------------------------------------------
 FUSED_SA = os.environ.get("TGN_FUSED_SA", "1") != "0"
 COMMUTE_FP = os.environ.get("TGN_COMMUTE_FP", "1") != "0"   # feature propagation: first convolution on the coarse points (below)
+# second layer of the chained set-abstraction kernel on the bf16 matrix cores at fp32 accuracy (three-way bf16 split of both operands,
+# six products: include/tgn_pointops.h, tgn_sa_mlp2_max_bf16x3); 0: the exact-fp32 MFMA form
+SA_BF16X3 = os.environ.get("TGN_SA_BF16X3", "1") != "0"
 
 
 def _can_fuse(module, *tensors):
@@ -523,6 +526,14 @@ def _fold_second_layer(conv, bn, C1p):
     return W2f, (shift + scale * bias).contiguous()
 
 
+def split_second_layer(W2f):
+    """The bf16 x 3 image of a folded second-layer weight matrix W2f (C1p/8, C2, 8) for tgn_sa_mlp2_max_bf16x3."""
+    C1p, C2 = W2f.shape[0] * 8, W2f.shape[1]
+    img = torch.empty(int(lib().tgn_sa_mlp2_split_bytes(C1p, C2)), dtype=torch.uint8, device=W2f.device)
+    check(lib().tgn_sa_mlp2_split_weights(C1p, C2, ptr(W2f), ptr(img), stream()), "sa_mlp2_split_weights")
+    return img
+
+
 def _pad_cols(t, C1p):
     if t.shape[-1] == C1p:
         return t.contiguous()
@@ -548,10 +559,11 @@ def sa_level_mlp2_max(xyz, new_xyz, points, idx, convs, bns, xyz_first, out=None
         f = fold_first_layer(convs[0], bns[0], D, xyz_first)
         C1p = (f["C1"] + 15) // 16 * 16
         W2f, b2 = fold_second_layer(convs[1], bns[1], C1p)
-        return dict(C1p=C1p, W2f=W2f, b2=b2, b1=_pad_cols(f["b2"], C1p),
+        return dict(C1p=C1p, W2f=W2f, b2=b2, b1=_pad_cols(f["b2"], C1p), W2s=split_second_layer(W2f) if SA_BF16X3 else None,
                     W1=_pad_cols(f["Wd"] if direct else f["Wxs"], C1p),      # direct: (16, C1p) rows [x, y, z, features..., 0]
                     Wt=None if direct else _pad_cols(f["Wt"], C1p))
-    ops = _derived.cached(bns[1], "mlp2", _derived.sources(convs[0], bns[0], convs[1], bns[1]), (D, bool(xyz_first), direct), operands)
+    ops = _derived.cached(bns[1], "mlp2", _derived.sources(convs[0], bns[0], convs[1], bns[1]), (D, bool(xyz_first), direct, SA_BF16X3),
+                          operands)
     C1p, W2f, b2, b1, W1 = ops["C1p"], ops["W2f"], ops["b2"], ops["b1"], ops["W1"]
     C2 = b2.shape[0]
     idx = idx.contiguous()
@@ -560,8 +572,13 @@ def sa_level_mlp2_max(xyz, new_xyz, points, idx, convs, bns, xyz_first, out=None
     assert out.shape == (B, S, C2) and out.stride(2) == 1 and out.stride(0) == S * out.stride(1) and out.dtype == torch.float32
     A1 = None if direct else sa_point_transform(xyz, points, ops["Wt"])      # (B, N, C1p)
     _lib.begin_index_check()
-    check(L.tgn_sa_mlp2_max(B, N, S, K, D, C1p, C2, ptr(A1), ptr(xyz), ptr(points), ptr(new_xyz), ptr(W1), ptr(b1), ptr(idx),
-                            int(idx.dtype == torch.int64), ptr(W2f), ptr(b2), ptr(out), out.stride(1), stream()), "sa_mlp2_max")
+    if ops["W2s"] is not None:
+        check(L.tgn_sa_mlp2_max_bf16x3(B, N, S, K, D, C1p, C2, ptr(A1), ptr(xyz), ptr(points), ptr(new_xyz), ptr(W1), ptr(b1), ptr(idx),
+                                       int(idx.dtype == torch.int64), ptr(ops["W2s"]), ptr(b2), ptr(out), out.stride(1), stream()),
+              "sa_mlp2_max_bf16x3")
+    else:
+        check(L.tgn_sa_mlp2_max(B, N, S, K, D, C1p, C2, ptr(A1), ptr(xyz), ptr(points), ptr(new_xyz), ptr(W1), ptr(b1), ptr(idx),
+                                int(idx.dtype == torch.int64), ptr(W2f), ptr(b2), ptr(out), out.stride(1), stream()), "sa_mlp2_max")
     _lib.raise_on_index_error("set abstraction (grouping)")
     return out
 
