@@ -112,13 +112,16 @@ MLP2_SHAPES = [(6000, 1024, 32, 6, 128, 128), (6000, 1024, 64, 6, 128, 128), (10
 
 @pytest.mark.parametrize("N,S,K,D,C1,C2", MLP2_SHAPES)
 @pytest.mark.parametrize("xyz_first", [True, False])
-@pytest.mark.parametrize("bf16x3", [True, False])
+@pytest.mark.parametrize("bf16x3", [128, 256, False])
 def test_two_layer_level_vs_oracle(dev, oracle, N, S, K, D, C1, C2, xyz_first, bf16x3, monkeypatch):
-    """tgn_sa_mlp2_max_bf16x3 (second layer as six bf16 MFMAs per fp32 product, the default) and tgn_sa_mlp2_max (fp32 MFMA) -- the
+    """tgn_sa_mlp2_max_bf16x3 (second layer as six bf16 MFMAs per fp32 product, the default; both workgroup tiles) and tgn_sa_mlp2_max
+    (fp32 MFMA) -- the
     whole two-layer level in one kernel, direct or commuted first layer -- against the float64 restatement of
     grouping -> [conv -> BN -> ReLU] x 2 -> max on real ball-query neighbourhoods, elementwise 1e-5."""
     from toothgroupnetwork_amd import pointnet2_utils as U, synth
-    monkeypatch.setattr(U, "SA_BF16X3", bf16x3)
+    from toothgroupnetwork_amd import _lib
+    monkeypatch.setattr(U, "SA_BF16X3", bool(bf16x3))
+    prev_tile = _lib.set_tuning("sa_tile", int(bf16x3))          # both workgroup tiles of the bf16x3 kernel: 128 x 128 and 256 x 256
     B = 2
     rng = np.random.default_rng(N + K + D + C2)
     pts6 = synth.scan_batch(B, N, "arch", seed=N % 89)
@@ -143,8 +146,9 @@ def test_two_layer_level_vs_oracle(dev, oracle, N, S, K, D, C1, C2, xyz_first, b
         for index in (idx, idx.to(torch.int32)):
             got = U.sa_level_mlp2_max(tx, new_xyz, tf, index, [conv1, conv2], [bn1, bn2], xyz_first)
             close(got.cpu().numpy(), want, f"two-layer level ({index.dtype})")
+    _lib.set_tuning("sa_tile", prev_tile)
     err = np.abs(got.cpu().numpy().astype(np.float64) - want) / (1.0 + np.abs(want))
-    print(f"\n{'bf16x3' if bf16x3 else 'fp32-mfma'} ({N},{S},{K},{D},{C1},{C2}) xyz_first={xyz_first}: max {err.max():.2e} "
+    print(f"\n{f'bf16x3 tile {bf16x3}' if bf16x3 else 'fp32-mfma'} ({N},{S},{K},{D},{C1},{C2}) xyz_first={xyz_first}: max {err.max():.2e} "
           f"rms {np.sqrt((err ** 2).mean()):.2e} (bound 1e-5)")
 
 

@@ -292,37 +292,45 @@ __global__ __launch_bounds__(256) void sa_mlp2_split_weights_kernel(int C1p, int
     *(bf16x8 *)(dst + 2 * kSplitPlane) = c3;
 }
 
-template <typename IdxT, bool DIRECT>
-__global__ __launch_bounds__(256, 2) void sa_mlp2_max_split_kernel(long long Q, int N, int S, int K, int D, int C1p, int C2, int ostride,
-                                                                    const float *__restrict__ A1, const float *__restrict__ xyz,
-                                                                    const float *__restrict__ points, const float *__restrict__ new_xyz,
-                                                                    const float *__restrict__ W1, const float *__restrict__ b1,
-                                                                    const IdxT *__restrict__ idx,
-                                                                    const unsigned char *__restrict__ W2s,   // split image of W2
-                                                                    const float *__restrict__ b2, float *__restrict__ out,
-                                                                    int *__restrict__ err) {
+// Tile shape: WM x 2 waves, each 64 rows x (32 TN) columns -- (WM, TN) = (2, 2): 128 x 128 per workgroup of 256 threads, two workgroups
+// per CU; (4, 4): 256 x 256 per workgroup of 512 threads, one per CU.  At 2.7x the fp32-MFMA rate the 128 x 128 tile is bound by
+// the memory system, not the matrix cores: every 128 rows re-read the whole weight image (4.7 MB at 784 x 1024: more than an XCD's
+// L2) and every 128 columns re-gather the rows -- 26 flop per byte, 7.8 TB/s of L2 / Infinity-Cache traffic at 200 TFLOP/s
+// (profiles/r04_sa_split_counters.txt).  The 256 x 256 tile halves both streams.
+template <typename IdxT, bool DIRECT, int WM, int TN>
+__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void sa_mlp2_max_split_kernel(
+    long long Q, int N, int S, int K, int D, int C1p, int C2, int ostride, const float *__restrict__ A1, const float *__restrict__ xyz,
+    const float *__restrict__ points, const float *__restrict__ new_xyz, const float *__restrict__ W1, const float *__restrict__ b1,
+    const IdxT *__restrict__ idx, const unsigned char *__restrict__ W2s,   // split image of W2 (128-column tiles)
+    const float *__restrict__ b2, float *__restrict__ out, int *__restrict__ err) {
+    constexpr int MT = WM * 64, NTL = TN * 64, THREADS = WM * 128;
+    constexpr int kAPlane = MT * 32, kATile = 3 * kAPlane;          // bytes
+    constexpr int kBTile = (NTL / 128) * kSplitTile;                // one or two 128-column tiles of the image, back to back
+    constexpr int kPieces = kBTile / 1024 / (2 * WM);               // LDS-DMA pieces per wave and K tile
+    static_assert(kPieces * 2 * WM * 1024 == kBTile, "whole pieces");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    unsigned char *FA = smem_b, *FB = smem_b + 2 * kSplitTile;
-    float *cst = (float *)(smem_b + 4 * kSplitTile);
+    unsigned char *FA = smem_b, *FB = smem_b + 2 * kATile;
+    float *cst = (float *)(smem_b + 2 * kATile + 2 * kBTile);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
     const int lo = lane & 31, hi = lane >> 5;
-    const int kshift = K > 32 ? 6 : 5, Kp = 1 << kshift, QPT = kMlpMT >> kshift;
-    const unsigned ntiles = ((unsigned)C2 + kMlpNT - 1) / kMlpNT;
+    const int kshift = K > 32 ? 6 : 5, Kp = 1 << kshift, QPT = MT >> kshift;
+    const unsigned ntiles = ((unsigned)C2 + NTL - 1) / NTL;
+    const unsigned ntiles128 = ((unsigned)C2 + kMlpNT - 1) / kMlpNT;
     const long long mtiles = (Q + QPT - 1) / QPT;
     const unsigned nb = gridDim.x;
     const long long item = (long long)(blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
     const long long mt = item / ntiles;
     if (mt >= mtiles) return;
     const int ntile = (int)(item - mt * ntiles);
-    const int col0 = ntile * kMlpNT;
+    const int col0 = ntile * NTL;
     const long long q0 = mt * QPT;
     const int T = C1p / kMlpKT;
 
     // ---- producer of A: thread (row ar, k half ah) makes 8 consecutive channels of one (query, neighbour) row per K tile
-    const int ar = tid & 127;
-    const int ah = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int ar = tid & (MT - 1);
+    const int ah = __builtin_amdgcn_readfirstlane(tid / MT);
     const int ql = ar >> kshift;
     long long q = q0 + ql;
     if (q >= Q) q = Q - 1;
@@ -358,23 +366,26 @@ __global__ __launch_bounds__(256, 2) void sa_mlp2_max_split_kernel(long long Q, 
             long long qq = q0 + l;
             if (qq >= Q) qq = Q - 1;
             if (!new_xyz) {
-                for (int c = tid; c < C1p; c += 256) cst[l * C1p + c] = b1[c];
+                for (int c = tid; c < C1p; c += THREADS) cst[l * C1p + c] = b1[c];
                 continue;
             }
             const float cx = new_xyz[qq * 3 + 0], cy = new_xyz[qq * 3 + 1], cz = new_xyz[qq * 3 + 2];
-            for (int c = tid; c < C1p; c += 256)
+            for (int c = tid; c < C1p; c += THREADS)
                 cst[l * C1p + c] = b1[c] - ((W1[c] * cx + W1[C1p + c] * cy) + W1[2 * C1p + c] * cz);
         }
     }
-    // ---- B: K tile t of this column tile is 12 contiguous KiB of the image; wave wv moves pieces 3 wv .. 3 wv + 2 (1 KiB each)
+    // ---- B: K tile t of 128-column tile j is 12 contiguous KiB of the image at (j T + t); a 256-wide workgroup takes tiles 2 ntile
+    // and 2 ntile + 1 (the second may lie past the last one: the descriptor's bound then returns zeros).  Wave wv moves kPieces pieces.
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char *>(W2s + (size_t)ntile * T * kSplitTile), 0, T * kSplitTile, 0x00020000);
+        const_cast<unsigned char *>(W2s), 0, (int)((size_t)ntiles128 * T * kSplitTile), 0x00020000);
     auto dma = [&](int t, int buf) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const int piece = wv * 3 + p;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(FB + buf * kSplitTile + piece * 1024), 16,
-                                                     lane * 16, t * kSplitTile + piece * 1024, 0, 0);
+        for (int p = 0; p < kPieces; ++p) {
+            const int piece = wv * kPieces + p;          // 0 .. kBTile / 1024 - 1; 12 pieces per 128-column tile
+            const int half = piece / 12, within = piece - half * 12;
+            const int j128 = ntile * (NTL / 128) + half;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(FB + buf * kBTile + piece * 1024), 16,
+                                                     lane * 16, (j128 * T + t) * kSplitTile + within * 1024, 0, 0);
         }
     };
     f32x4 ra0, ra1;
@@ -411,34 +422,40 @@ __global__ __launch_bounds__(256, 2) void sa_mlp2_max_split_kernel(long long Q, 
         }
         bf16x8 p1, p2, p3;
         split3(h, p1, p2, p3);
-        unsigned char *fa = FA + buf * kSplitTile + split_chunk(ar, ah);
+        unsigned char *fa = FA + buf * kATile + split_chunk(ar, ah);
         *(bf16x8 *)fa = p1;
-        *(bf16x8 *)(fa + kSplitPlane) = p2;
-        *(bf16x8 *)(fa + 2 * kSplitPlane) = p3;
+        *(bf16x8 *)(fa + kAPlane) = p2;
+        *(bf16x8 *)(fa + 2 * kAPlane) = p3;
     };
-    f32x16 acc[2][2];
+    f32x16 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    auto compute = [&](int buf) {
-        const unsigned char *fa = FA + buf * kSplitTile, *fb = FB + buf * kSplitTile;
-        bf16x8 a[2][3], w[2][3];
+    bf16x8 fa_[2][3], fw_[TN][3];
+    auto load_frags = [&](int buf) {
+        const unsigned char *fa = FA + buf * kATile, *fb = FB + buf * kBTile;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int ca = split_chunk(wm * 64 + i * 32 + lo, hi), cb = split_chunk(wn * 64 + i * 32 + lo, hi);
+            const int ca = split_chunk(wm * 64 + i * 32 + lo, hi);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                a[i][c] = *(const bf16x8 *)(fa + c * kSplitPlane + ca);
-                w[i][c] = *(const bf16x8 *)(fb + c * kSplitPlane + cb);
-            }
+            for (int c = 0; c < 3; ++c) fa_[i][c] = *(const bf16x8 *)(fa + c * kAPlane + ca);
         }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * (NTL / 2) + j * 32 + lo;   // column within the workgroup's tile; 128-column halves are separate images
+            const int cb = (col >> 7) * kSplitTile + split_chunk(col & 127, hi);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) fw_[j][c] = *(const bf16x8 *)(fb + c * kSplitPlane + cb);
+        }
+    };
+    auto mma = [&]() {
         // six products per tile, smallest first; consecutive MFMAs go to different accumulators
-#define TGN_SPLIT_STEP(CA, CB)                                                                                \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = \
-        __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][CA], w[j][CB], acc[i][j], 0, 0, 0)
+#define TGN_SPLIT_STEP(CA, CB)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i][CA], fw_[j][CB], acc[i][j], 0, 0, 0)
         TGN_SPLIT_STEP(2, 0);
         TGN_SPLIT_STEP(0, 2);
         TGN_SPLIT_STEP(1, 1);
@@ -447,31 +464,46 @@ __global__ __launch_bounds__(256, 2) void sa_mlp2_max_split_kernel(long long Q, 
         TGN_SPLIT_STEP(0, 0);
 #undef TGN_SPLIT_STEP
     };
+    const int last = T - 1;
 
     fetch(0);
     dma(0, 0);
     __syncthreads();   // cst is complete
     stage(0, 0);
-    if (T > 1) fetch(1);
+    fetch(last < 1 ? last : 1);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the LDS-DMA pieces have landed (hipcc orders no ds_read behind them)
     __syncthreads();
-    for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) {
-            dma(t + 1, (t + 1) & 1);     // FB / FA[(t+1)&1] were last read by compute(t-1): every wave is past the barrier that ended it
-            stage(t + 1, (t + 1) & 1);   // from the registers fetch(t+1) filled one iteration ago
+    for (int t = 0; t < last; ++t) {      // one basic block per trip: the scheduling pattern below needs it
+        dma(t + 1, (t + 1) & 1);          // FB / FA[(t+1)&1] were last read in trip t-1: every wave is past the barrier that ended it
+        load_frags(t & 1);                // IN FRONT of the producer's LDS stores: hipcc keeps an LDS read behind an earlier LDS write it
+                                          // cannot tell apart, which would chain  split -> ds_write -> ds_read -> MFMA  and serialise the trip
+        stage(t + 1, (t + 1) & 1);        // from the registers fetch(t+1) filled one trip ago
+        fetch(t + 2 < last ? t + 2 : last);   // in flight under the MFMAs (the last trip re-reads tile T-1: unused)
+        mma();
+        if constexpr (!DIRECT) {
+            // the waves of a SIMD run in phase (one workgroup, or two that drift into phase: SQ counters in profiles/), so the producer's
+            // work must hide under this wave's OWN matrix instructions: a 32x32x16 bf16 MFMA holds the pipe for 32 cycles, room for ~4
+            // other instructions.  Order: the fragment reads, then one MFMA + a few vector instructions, 12 TN times, then the stores.
+            __builtin_amdgcn_sched_group_barrier(0x100, 6 + 3 * TN + 2, 0);   // DS reads: the fragments + 2 per-query constants
+#pragma unroll
+            for (int m = 0; m < 12 * TN; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, TN == 2 ? 3 : 2, 0);   // VALU
+            }
+            __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);                // DS writes of the staged tile
         }
-        if (t + 2 < T) fetch(t + 2);     // in flight under the MFMAs
-        compute(t & 1);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
     }
+    load_frags(last & 1);
+    mma();
 
     // ---- max over the rows of a query.  Accumulator register r of lane l is row (r & 3) + 8 (r >> 2) + 4 hi, column lo of its tile.
-    float cm[2][2];
+    float cm[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TN; ++j) {
             float m = acc[i][j][0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
@@ -479,11 +511,11 @@ __global__ __launch_bounds__(256, 2) void sa_mlp2_max_split_kernel(long long Q, 
         }
     if (hi == 0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = col0 + wn * 64 + j * 32 + lo;
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + wn * (NTL / 2) + j * 32 + lo;
             if (col >= C2) continue;
             const float bias = b2[col];
-            if (kshift == 6) {
+            if (kshift == 6) {   // the wave's 64 rows = one query
                 const long long qq = q0 + wm;
                 if (qq < Q) out[(size_t)qq * ostride + col] = fmaxf(fmaxf(cm[0][j], cm[1][j]) + bias, 0.0f);
             } else {
@@ -555,28 +587,44 @@ static int sa_mlp2_launch(const char *who, int B, int N, int S, int K, int D, in
                                   80 * 1024);                                                                             \
     hipLaunchKernelGGL((sa_mlp2_max_kernel<IT, DIR>), dim3((unsigned)blocks), dim3(256), lds, st, Q, N, S, K, D, C1p, C2, out_stride, \
                        A1, xyz, points, new_xyz, W1, b1, (const IT *)idx, W2f, b2, out, err)
-#define TGN_MLP2S(IT, DIR)                                                                                                      \
-    if (lds > 48 * 1024)                                                                                                        \
-        (void)hipFuncSetAttribute((const void *)sa_mlp2_max_split_kernel<IT, DIR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  80 * 1024);                                                                                   \
-    hipLaunchKernelGGL((sa_mlp2_max_split_kernel<IT, DIR>), dim3((unsigned)blocks), dim3(256), lds, st, Q, N, S, K, D, C1p, C2,  \
-                       out_stride, A1, xyz, points, new_xyz, W1, b1, (const IT *)idx, (const unsigned char *)W2f, b2, out, err)
+#define TGN_MLP2S(IT, DIR, WM_, TN_, LDS_, BLOCKS_)                                                                                \
+    if ((LDS_) > 48 * 1024)                                                                                                        \
+        (void)hipFuncSetAttribute((const void *)sa_mlp2_max_split_kernel<IT, DIR, WM_, TN_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)(LDS_));                                                                                    \
+    hipLaunchKernelGGL((sa_mlp2_max_split_kernel<IT, DIR, WM_, TN_>), dim3((unsigned)(BLOCKS_)), dim3(WM_ * 128), (LDS_), st, Q, N, S, K, D, \
+                       C1p, C2, out_stride, A1, xyz, points, new_xyz, W1, b1, (const IT *)idx, (const unsigned char *)W2f, b2, out, err)
     if (split) {
-        if ((long long)(C1p / kMlpKT) * kSplitTile > 0x7FFFFFFFLL || ((uintptr_t)W2f & 15)) {
+        if (ntiles * (long long)(C1p / kMlpKT) * kSplitTile > 0x7FFFFFFFLL || ((uintptr_t)W2f & 15)) {
             set_error("%s: split weight image too large or misaligned", who);
             return TGN_ERR_UNSUPPORTED;
         }
-        if (idx_is_int64) {
-            if (direct) {
-                TGN_MLP2S(long long, true);
+        // 256 x 256 tiles (512 threads, one workgroup per CU) where the level is wide and tall enough to fill the chip with them:
+        // half the weight and gather traffic per flop of the 128 x 128 form, which the memory system bounds ("sa_tile": 0 picks,
+        // 128 / 256 force)
+        const int qpt_big = K > 32 ? 4 : 8;
+        const long long mt_big = (Q + qpt_big - 1) / qpt_big, nt_big = (C2 + 255) / 256;
+        const size_t lds_big = (size_t)4 * 2 * kSplitTile + (size_t)qpt_big * C1p * sizeof(float);
+        const int forced = tuning(kTuneSaTile);
+        const bool big = !direct && lds_big <= 150 * 1024 && forced != 128 &&
+                         (forced == 256 || (C2 % 256 == 0 && mt_big * nt_big >= 256));
+        if (big) {
+            const long long blocks_big = (mt_big * nt_big + 7) / 8 * 8;
+            if (idx_is_int64) {
+                TGN_MLP2S(long long, false, 4, 4, lds_big, blocks_big);
             } else {
-                TGN_MLP2S(long long, false);
+                TGN_MLP2S(int, false, 4, 4, lds_big, blocks_big);
+            }
+        } else if (idx_is_int64) {
+            if (direct) {
+                TGN_MLP2S(long long, true, 2, 2, lds, blocks);
+            } else {
+                TGN_MLP2S(long long, false, 2, 2, lds, blocks);
             }
         } else {
             if (direct) {
-                TGN_MLP2S(int, true);
+                TGN_MLP2S(int, true, 2, 2, lds, blocks);
             } else {
-                TGN_MLP2S(int, false);
+                TGN_MLP2S(int, false, 2, 2, lds, blocks);
             }
         }
         return check_launch("sa_mlp2_max_split_kernel");
