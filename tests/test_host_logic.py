@@ -294,3 +294,24 @@ def test_derived_operand_memo_follows_storage_swaps_and_copies():
     _derived.invalidate(lin)
     get()
     assert len(builds) == 5
+
+
+def test_effective_cpus_honours_the_cgroup_quota(tmp_path):
+    """sharding.effective_cpus: the affinity mask cut down by the container's CPU quota (cgroup v2 cpu.max / v1 cfs files)."""
+    import os
+
+    from toothgroupnetwork_amd import sharding
+    have = len(os.sched_getaffinity(0))
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert sharding.effective_cpus(str(tmp_path)) == have
+    (tmp_path / "cpu.max").write_text("150000 100000\n")                       # 1.5 cores' worth of time
+    assert sharding.effective_cpus(str(tmp_path)) == min(have, 2)
+    (tmp_path / "cpu.max").write_text("1600000 100000\n")
+    assert sharding.effective_cpus(str(tmp_path)) == min(have, 16)
+    (tmp_path / "cpu.max").unlink()
+    os.makedirs(tmp_path / "cpu")
+    (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("300000\n")
+    (tmp_path / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert sharding.effective_cpus(str(tmp_path)) == min(have, 3)
+    (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    assert sharding.effective_cpus(str(tmp_path)) == have

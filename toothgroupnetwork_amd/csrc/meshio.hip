@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include <charconv>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -372,11 +373,43 @@ static long long remap_fdi(long long l, bool lower) {
     return l;
 }
 
+// Everything a scan needs on the host, result and scratch alike.  The objects are POOLED: a raw scan touches ~25 MB of fresh heap
+// (file text, vertices, faces, normals, rows) -- 4 500 page faults, a third of the loader's time in the kernel -- and with eight
+// ranks x several loader threads on one node those faults contend (measured: 20 -> 120 ms per scan and thread from 16 to 64 loaders,
+// profiles/r04_preprocess_host_scaling.txt).  A recycled object keeps its vectors' capacity: no allocation, no fault after warm-up.
 struct Scan {
     std::vector<double> labeled;   // (n, 7)
     std::string jaw;
     long long n = 0;
+    std::string data;              // scratch: file text
+    std::vector<long long> labels, f;
+    std::vector<double> v, nrm;
 };
+constexpr size_t kScanPoolMax = 64;   // objects kept (each retains ~25 MB of capacity for a 100 000-vertex scan)
+static std::mutex g_scan_mu;
+static std::vector<Scan *> g_scan_pool;
+
+static Scan *scan_acquire() {
+    {
+        std::lock_guard<std::mutex> lock(g_scan_mu);
+        if (!g_scan_pool.empty()) {
+            Scan *s = g_scan_pool.back();
+            g_scan_pool.pop_back();
+            return s;
+        }
+    }
+    return new Scan();
+}
+static void scan_release(Scan *s) {
+    {
+        std::lock_guard<std::mutex> lock(g_scan_mu);
+        if (g_scan_pool.size() < kScanPoolMax) {
+            g_scan_pool.push_back(s);
+            return;
+        }
+    }
+    delete s;
+}
 
 }  // namespace tgn
 
@@ -464,9 +497,20 @@ TGN_API int tgn_scan_open(const char *obj_path, const char *json_path, double y_
         return TGN_ERR_INVALID_ARGUMENT;
     }
     *handle = nullptr;
-    std::string data;
+    Scan *sc = scan_acquire();
+    struct Guard {   // back to the pool on every early return
+        Scan *s;
+        ~Guard() {
+            if (s) scan_release(s);
+        }
+    } guard{sc};
+    std::string &data = sc->data;
+    std::vector<long long> &labels = sc->labels, &f = sc->f;
+    std::vector<double> &v = sc->v, &nrm = sc->nrm;
+    labels.clear();
+    v.clear();
+    f.clear();
     if (int rc = read_file(json_path, data)) return rc;
-    std::vector<long long> labels;
     std::string jaw_s;
     if (parse_scan_json(data, labels, jaw_s) != TGN_OK || (long long)jaw_s.size() >= jaw_cap) {
         set_error("tgn_scan_open: %s is not a plain {\"jaw\": str, \"labels\": [int]} object", json_path);
@@ -474,20 +518,16 @@ TGN_API int tgn_scan_open(const char *obj_path, const char *json_path, double y_
     }
     if (int rc = read_file(obj_path, data)) return rc;
     long long nv = 0, nf = 0;
-    std::vector<double> v;
-    std::vector<long long> f;
     v.reserve(data.size() / 24);                                // ~ "v -12.345678 -12.345678 -12.345678\n" per vertex, two
     f.reserve(data.size() / 12);                                //   "f 123456 123457 123458\n" per vertex: a first guess
     if (int rc = parse_obj(data, nullptr, nullptr, 0, 0, &nv, &nf, &v, &f)) return rc;
-    std::string().swap(data);
-    std::vector<double> nrm((size_t)nv * 3);
+    nrm.resize((size_t)nv * 3);
     for (auto &x : f) x -= 1;                                   // gen_utils.py:226
     if (int rc = tgn_vertex_normals(v.data(), nv, f.data(), nf, nrm.data())) return rc;
     if ((long long)labels.size() != nv) {
         set_error("tgn_scan_open: %lld labels for %lld vertices (np.concatenate raises)", (long long)labels.size(), nv);
         return TGN_ERR_INVALID_ARGUMENT;
     }
-    Scan *sc = new Scan();
     sc->n = nv;
     sc->jaw = jaw_s;
     sc->labeled.resize((size_t)nv * 7);
@@ -510,11 +550,12 @@ TGN_API int tgn_scan_open(const char *obj_path, const char *json_path, double y_
     memcpy(jaw, jaw_s.c_str(), jaw_s.size() + 1);
     *n_vertices = nv;
     *handle = sc;
+    guard.s = nullptr;   // the caller owns it until tgn_scan_take
     return TGN_OK;
 }
 
 // Copies the (n, 7) rows out (and, when xyz32 is given, the float32 copy of the coordinates the sampler takes) and frees
-// the handle.  With both pointers null it only frees.
+// the handle (back to the pool).  With both pointers null it only frees.
 TGN_API int tgn_scan_take(void *handle, double *labeled, float *xyz32) {
     Scan *sc = (Scan *)handle;
     if (!sc) {
@@ -525,6 +566,6 @@ TGN_API int tgn_scan_take(void *handle, double *labeled, float *xyz32) {
     if (xyz32)
         for (long long i = 0; i < sc->n; ++i)
             for (int a = 0; a < 3; ++a) xyz32[i * 3 + a] = (float)sc->labeled[i * 7 + a];
-    delete sc;
+    scan_release(sc);
     return TGN_OK;
 }

@@ -103,12 +103,38 @@ def load_scan(obj_path, json_path):
     return np.concatenate([vertices, labels], axis=1), str(base_name), loaded["jaw"]
 
 
-def load_scan_native(obj_path, json_path, with_xyz32=False):
+class ArrayPool:
+    """Recycled row buffers for the loader threads: a raw scan's (n, 7) float64 rows and (n, 3) float32 coordinates are 7.5 MB of
+    fresh memory per scan -- page faults that contend once eight ranks x several loader threads share a node.  take(rows) hands out
+    the first `rows` rows of a kept buffer of enough capacity (or a new one, capacity rounded up to 16 384 rows); give(view) takes
+    it back."""
+
+    def __init__(self, cols, dtype, keep=160):
+        self.cols, self.dtype, self.keep = cols, np.dtype(dtype), keep
+        self.lock, self.free = threading.Lock(), []
+
+    def take(self, rows):
+        with self.lock:
+            for i, buf in enumerate(self.free):
+                if buf.shape[0] >= rows:
+                    return self.free.pop(i)[:rows]
+        cap = -(-max(int(rows), 1) // 16384) * 16384
+        return np.empty((cap, self.cols), dtype=self.dtype)[:rows]
+
+    def give(self, view):
+        base = view.base if isinstance(view.base, np.ndarray) else view
+        with self.lock:
+            if len(self.free) < self.keep:
+                self.free.append(base)
+
+
+def load_scan_native(obj_path, json_path, with_xyz32=False, pools=None):
     """load_scan in ONE native call that never holds the interpreter lock (tgn_scan_open / tgn_scan_take): what the sharded
     runner's load threads use, since json.load, the label remap and the numpy glue of load_scan serialise on the GIL.
     -> (labeled_vertices, base_name, jaw, xyz32 or None); xyz32 = float32 copy of the coordinates when with_xyz32 and the
     scan has more than N_SAMPLED vertices.  Returns None when the json is not the plain {"jaw": str, "labels": [int]} shape
-    (the caller then takes load_scan); raises ValueError where load_scan raises."""
+    (the caller then takes load_scan); raises ValueError where load_scan raises.  pools: optional (ArrayPool(7, float64),
+    ArrayPool(3, float32)) the two arrays are taken from (the caller gives them back)."""
     L = _lib.lib()
     handle, nv = ctypes.c_void_p(), ctypes.c_longlong(0)
     jaw = ctypes.create_string_buffer(64)
@@ -119,8 +145,13 @@ def load_scan_native(obj_path, json_path, with_xyz32=False):
     if rc:
         raise ValueError(L.tgn_last_error().decode("utf-8", "replace"))
     try:
-        lv = np.empty((nv.value, 7), dtype=np.float64)
-        x32 = np.empty((nv.value, 3), dtype=np.float32) if with_xyz32 and nv.value > N_SAMPLED else None
+        want32 = with_xyz32 and nv.value > N_SAMPLED
+        if pools is not None:                                   # (rows64 pool, xyz32 pool): recycled buffers, see ArrayPool
+            lv = pools[0].take(nv.value)
+            x32 = pools[1].take(nv.value) if want32 else None
+        else:
+            lv = np.empty((nv.value, 7), dtype=np.float64)
+            x32 = np.empty((nv.value, 3), dtype=np.float32) if want32 else None
     except BaseException:
         L.tgn_scan_take(handle, None, None)
         raise
@@ -146,7 +177,7 @@ def _default_fps_batch(xyz_list, npoint):
 def preprocess_scans(pairs, save_path, batch=16, fps_batch=None, workers=None, samplers=None):
     """pairs: [(obj_path, json_path)] -> one "<id>_<jaw>_sampled_points.npy" per scan under save_path, exactly the arrays
     preprocess_data.py writes.  Scans with more than 24 000 vertices are farthest-point-sampled up to `batch` at a time in
-    one launch.  Three stages overlap: load threads (`workers`, default min(32, host cores / ranks on the node): more only contend for page faults) run the
+    one launch.  Three stages overlap: load threads (`workers`, default min(16, usable host cores / ranks on the node)) run the
     host side of a scan in one native call that never holds the interpreter lock (load_scan_native: json, OBJ parse,
     normals, scaling); `samplers` threads (default 2, TGN_PREPROCESS_SAMPLERS) each pack a batch, launch the FPS on a
     stream of their own and hand the picks to writer threads, which select and save.  The FPS launch is bound by its
@@ -161,7 +192,9 @@ def preprocess_scans(pairs, save_path, batch=16, fps_batch=None, workers=None, s
     os.makedirs(save_path, exist_ok=True)
     if workers is None:
         local = max(int(os.environ.get("LOCAL_WORLD_SIZE", "1")), 1)
-        workers = int(os.environ.get("TGN_PREPROCESS_WORKERS", "0")) or max(1, min(32, (os.cpu_count() or 1) // local))
+        # loader threads: the cores this rank can really use (affinity mask and cgroup CPU quota, shared by the ranks of the node),
+        # at most 16 -- one process's loaders scale linearly to 16 threads (84 scans/s each) and not beyond
+        workers = int(os.environ.get("TGN_PREPROCESS_WORKERS", "0")) or max(1, min(16, sharding.effective_cpus() // local))
     if samplers is None:
         samplers = max(int(os.environ.get("TGN_PREPROCESS_SAMPLERS", "2")), 1)
     stats = dict(scans=0, sampled=0, points_in=0, checksum=0.0, batches=0, seconds_load=0.0, seconds_fps=0.0)
@@ -171,8 +204,10 @@ def preprocess_scans(pairs, save_path, batch=16, fps_batch=None, workers=None, s
     sampler = ThreadPoolExecutor(max_workers=samplers)
     writer = ThreadPoolExecutor(max_workers=4)
 
+    pools = (ArrayPool(7, np.float64), ArrayPool(3, np.float32))
+
     def load(obj_path, json_path):
-        fast = load_scan_native(obj_path, json_path, with_xyz32=True)
+        fast = load_scan_native(obj_path, json_path, with_xyz32=True, pools=pools)
         if fast is not None:
             return fast
         lv, name, jaw = load_scan(obj_path, json_path)         # a json the strict native reader hands back
@@ -180,15 +215,17 @@ def preprocess_scans(pairs, save_path, batch=16, fps_batch=None, workers=None, s
 
     def select_and_save(lv, ix, name, jaw):
         # (writer thread) gen_utils.resample_pcd: pcd[idx[:n]], then np.save (preprocess_data.py:56-58)
-        if ix is not None:
-            lv = lv[np.asarray(ix)[:N_SAMPLED]]
-        np.save(os.path.join(save_path, sampled_points_name(name, jaw)), lv)
+        out = lv[np.asarray(ix)[:N_SAMPLED]] if ix is not None else lv
+        np.save(os.path.join(save_path, sampled_points_name(name, jaw)), out)
+        pools[0].give(lv)
 
     def sample(loaded):
         # (sampler thread) one FPS launch over the scans of this batch that need it, then the writes
         t0 = time.perf_counter()
         big = [i for i, item in enumerate(loaded) if item[3] is not None]
         idx = fps_batch([loaded[i][3] for i in big], N_SAMPLED) if big else []
+        for i in big:                                           # (the sampler copied the coordinates into its staging buffer)
+            pools[1].give(loaded[i][3])
         picked = dict(zip(big, idx))
         checksum = sum(float(np.asarray(ix, dtype=np.int64).sum()) for ix in idx)
         dt = time.perf_counter() - t0

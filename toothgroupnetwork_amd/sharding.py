@@ -51,6 +51,34 @@ def parse_cpulist(text):
     return sorted(cpus)
 
 
+def effective_cpus(cgroup_root="/sys/fs/cgroup"):
+    """Host cores this process can really use: the affinity mask, cut down by the container's CPU bandwidth quota (cgroup v2
+    `cpu.max` = "quota period", v1 `cpu.cfs_quota_us` / `cpu.cfs_period_us`).  os.cpu_count() reports the machine -- 256 on the
+    MI355X boxes whose sandbox grants 16 cores' worth of time -- and sizing thread pools by it oversubscribes the quota: the
+    loaders of the preprocess runner then throttle each other (measured: 1 240 scans/s from 16 loader threads, 840 from 128;
+    profiles/r04_preprocess_host_scaling.txt)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, period = open(os.path.join(cgroup_root, "cpu.max")).read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open(os.path.join(cgroup_root, "cpu", "cpu.cfs_quota_us")).read())
+            period = float(open(os.path.join(cgroup_root, "cpu", "cpu.cfs_period_us")).read())
+            if q > 0 and period > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(n, 1)
+
+
 def pin_to_gpu_numa(device_index, sysfs="/sys/bus/pci/devices"):
     """Restrict this process's host threads to the CPUs of the NUMA node its GPU hangs off (the PCI device's
     local_cpulist): one process per GPU on an 8-GPU node otherwise lets the OBJ parser / OpenMP threads of eight ranks
