@@ -69,7 +69,6 @@ int tgn_get_fps_mode(void);
  *   "fps_cell_bits"      4 (default) or 5: bits per axis of the bucket kernel's Z-order cell code       (TGN_FPS_CELL_BITS)
  *   "fps_bucket_min"     smallest cloud the bucket kernel takes, -1 = built-in thresholds               (TGN_FPS_BUCKET_MIN)
  *   "ball_bitmap"        0 = rank-select ball-query kernel instead of the bitmap one                    (TGN_BALL_BITMAP)
- *   "ball_pair"          0 = one query per wave in the bitmap ball query, 1 (default) = two             (TGN_BALL_PAIR)
  *   "sa_tile"            0 = pick, 128 / 256 = force the workgroup tile of tgn_sa_mlp2_max_bf16x3                (TGN_SA_TILE)
  *   "knn_memset"         1 = clear the kNN redo counter with hipMemsetAsync (reproduces a graph fault)  (TGN_KNN_MEMSET)
  *   "knn_grid_scale"     kNN grid cell, per mille of the estimated k-neighbour radius (1000)            (TGN_KNN_GRID_SCALE)

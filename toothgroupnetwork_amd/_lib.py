@@ -150,7 +150,7 @@ def get_fps_mode():
 
 def set_tuning(key, value):
     """Select a kernel variant inside the library (include/tgn_pointops.h: tgn_set_tuning; keys "fps_plain", "fps_config",
-    "fps_bucket_config", "fps_cell_bits", "fps_bucket_min", "ball_bitmap", "ball_pair", "knn_memset", "knn_grid_scale").
+    "fps_bucket_config", "fps_cell_bits", "fps_bucket_min", "ball_bitmap", "sa_tile", "knn_memset", "knn_grid_scale").
     (nt, p) pairs are given as tuples.  Returns the previous value.  Experiments and parity tests only."""
     if isinstance(value, (tuple, list)):
         value = int(value[0]) * 256 + int(value[1])

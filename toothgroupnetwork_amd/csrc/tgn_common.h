@@ -32,7 +32,6 @@ enum Tuning {
     kTuneBallBitmap,        // "ball_bitmap": 0 = the rank-select ball-query kernel
     kTuneKnnMemset,         // "knn_memset": 1 = clear the redo counter with hipMemsetAsync (reproduces the graph-replay fault)
     kTuneKnnGridScale,      // "knn_grid_scale": kNN grid cell size, per mille of the estimated k-neighbour radius (1000)
-    kTuneBallPair,          // "ball_pair": 0 = one query per wave in the level-1 ball query (default 1: two)
     kTuneSaTile,            // "sa_tile": 0 = pick, 128 / 256 = force the workgroup tile of tgn_sa_mlp2_max_bf16x3
     kTuneCount
 };
