@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -o pmc -- \
-      python $GRAFT_REPO_ROOT/bench.py --pipeline 0 --steps 2 --warmup 1 --cpu-meshes 0 --no-alt --no-kernel-timing > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1)
+      python $GRAFT_REPO_ROOT/bench.py --pipeline 0 --steps 2 --warmup 1 --cpu-meshes 0 --no-alt --no-kernel-timing --secondary 0 > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1)
   tail -1 gpurun_out/pmc_$C.log | cut -c1-200
   ls gpurun_out/pmc_$C
 done

@@ -17,7 +17,7 @@ import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
-tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
+tag = sys.argv[3] if len(sys.argv) > 3 else "r04"
 LEVELS = 3
 
 
