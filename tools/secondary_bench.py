@@ -10,6 +10,7 @@ An entry that fails reports {"error": ...} and never takes the headline down.
   fused_shape_A / _B     the same levels with the shared MLP fused in; _B is the reference net's own SA stack
   knn_24000_k36          pointops.knnquery at config 4's first stage (blocks.py:34)
   fps_100k_to_24k        preprocess_data.py:55-56 / gen_utils.py:124-140, one scan and 64 scans per launch (config 5's kernel)
+  pnpp_forward_8x24000   config 2's whole network (pointnet_pp.py get_model) on 8 scans, eval
   pt_forward_24000       config 4: PointTransformerSeg encoder / decoder forward on one 24 000-point scan, eager and as a HIP graph
   train_step_graph       config 3's first-stage step (forward, loss terms, backward, Adam) as one HIP graph, fp32
 
@@ -170,6 +171,24 @@ def pt_forward(device):
     return out
 
 
+def pnpp_forward(device, B=8):
+    """BASELINE config 2's network end to end: models/modules/pointnet_pp.py:43-70 (three multi-scale set-abstraction levels, three
+    feature-propagation levels, heads) in eval mode on B scans of 24 000 points -- every SA branch one chained kernel."""
+    from toothgroupnetwork_amd import nets
+    torch.manual_seed(0)
+    net = nets.PointNetPPSeg().to(device).eval()
+    inp = torch.from_numpy(synth.scan_batch(B, 24000, "arch", 5).transpose(0, 2, 1).copy()).to(device)
+    with torch.no_grad():
+        ms = _events(lambda: net([inp]), 6, 3)
+    # second-layer flops of the six SA branches + per-point first layers (the rest -- FP stack, heads -- is ~25 % on top)
+    fl = fused_flops(hotpath.SHAPE_B)
+    return dict(value=B * 1e3 / ms, unit="scans/s", ms=ms,
+                config=f"nets.PointNetPPSeg (pointnet_pp.py get_model, scale 4) forward, {B} x 24 000-point scans, eval, eager",
+                roofline=_roof("mfma", fl * B / ms / 1e9, MFMA_FP32_PEAK, "TFLOP/s",
+                               note="set-abstraction flops only (fp32-equivalent; second layers run as bf16x3 MFMAs) over the WHOLE forward time, "
+                                    "which also holds sampling, ball queries, three feature-propagation levels and the heads"))
+
+
 def train_step(device, steps=6):
     spec = importlib.util.spec_from_file_location("train_step_bench", os.path.join(REPO, "tools", "train_step_bench.py"))
     T = importlib.util.module_from_spec(spec)
@@ -196,6 +215,7 @@ def measure_all(make_inputs, device, budget_s=150.0):
             ("fused_shape_B", lambda: hot_path(make_inputs, device, "B", True, steps=4, warmup=2)),
             ("knn_24000_k36", lambda: knn(device)),
             ("fps_100k_to_24k", lambda: fps_large(device)),
+            ("pnpp_forward_8x24000", lambda: pnpp_forward(device)),
             ("pt_forward_24000", lambda: pt_forward(device)),
             ("train_step_graph", lambda: train_step(device))]
     for name, fn in plan:

@@ -435,33 +435,64 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void sa_mlp2_max_split_k
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     bf16x8 fa_[2][3], fw_[TN][3];
+    // Fragment reads in the order the products need them -- a1, w1, w2, a2, w3, a3 -- so that the first MFMAs (a1 x w1) can start after
+    // 2 + TN reads instead of all 6 + 3 TN: after a barrier the waves of a CU read their fragments at the same time (18 b128 reads x
+    // 8 waves = 580 cycles of LDS) and the matrix cores used to idle behind all of them.
     auto load_frags = [&](int buf) {
         const unsigned char *fa = FA + buf * kATile, *fb = FB + buf * kBTile;
+        int ca[2], cb[TN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ca = split_chunk(wm * 64 + i * 32 + lo, hi);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) fa_[i][c] = *(const bf16x8 *)(fa + c * kAPlane + ca);
-        }
+        for (int i = 0; i < 2; ++i) ca[i] = split_chunk(wm * 64 + i * 32 + lo, hi);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = wn * (NTL / 2) + j * 32 + lo;   // column within the workgroup's tile; 128-column halves are separate images
-            const int cb = (col >> 7) * kSplitTile + split_chunk(col & 127, hi);
+            cb[j] = (col >> 7) * kSplitTile + split_chunk(col & 127, hi);
+        }
+        auto ra = [&](int c) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) fw_[j][c] = *(const bf16x8 *)(fb + c * kSplitPlane + cb);
+            for (int i = 0; i < 2; ++i) fa_[i][c] = *(const bf16x8 *)(fa + c * kAPlane + ca[i]);
+        };
+        auto rw = [&](int c) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fw_[j][c] = *(const bf16x8 *)(fb + c * kSplitPlane + cb[j]);
+        };
+        if constexpr (DIRECT) {   // (255 registers: the need-order below makes this form spill)
+            ra(0);
+            ra(1);
+            ra(2);
+            rw(0);
+            rw(1);
+            rw(2);
+        } else {
+            ra(0);
+            rw(0);
+            rw(1);
+            ra(1);
+            rw(2);
+            ra(2);
         }
     };
     auto mma = [&]() {
-        // six products per tile, smallest first; consecutive MFMAs go to different accumulators
+        // six products per tile, in the order their fragments arrive; consecutive MFMAs go to different accumulators.  (The order of the
+        // six is irrelevant to the rounding: the accumulator already holds the sum over the earlier K tiles.)
 #define TGN_SPLIT_STEP(CA, CB)                                                                                 \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i][CA], fw_[j][CB], acc[i][j], 0, 0, 0)
-        TGN_SPLIT_STEP(2, 0);
-        TGN_SPLIT_STEP(0, 2);
-        TGN_SPLIT_STEP(1, 1);
-        TGN_SPLIT_STEP(1, 0);
-        TGN_SPLIT_STEP(0, 1);
-        TGN_SPLIT_STEP(0, 0);
+        if constexpr (DIRECT) {   // (the order this form does not spill in)
+            TGN_SPLIT_STEP(2, 0);
+            TGN_SPLIT_STEP(0, 2);
+            TGN_SPLIT_STEP(1, 1);
+            TGN_SPLIT_STEP(1, 0);
+            TGN_SPLIT_STEP(0, 1);
+            TGN_SPLIT_STEP(0, 0);
+        } else {
+            TGN_SPLIT_STEP(0, 0);
+            TGN_SPLIT_STEP(0, 1);
+            TGN_SPLIT_STEP(1, 0);
+            TGN_SPLIT_STEP(1, 1);
+            TGN_SPLIT_STEP(0, 2);
+            TGN_SPLIT_STEP(2, 0);
+        }
 #undef TGN_SPLIT_STEP
     };
     const int last = T - 1;
@@ -484,9 +515,15 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void sa_mlp2_max_split_k
             // the waves of a SIMD run in phase (one workgroup, or two that drift into phase: SQ counters in profiles/), so the producer's
             // work must hide under this wave's OWN matrix instructions: a 32x32x16 bf16 MFMA holds the pipe for 32 cycles, room for ~4
             // other instructions.  Order: the fragment reads, then one MFMA + a few vector instructions, 12 TN times, then the stores.
-            __builtin_amdgcn_sched_group_barrier(0x100, 6 + 3 * TN + 2, 0);   // DS reads: the fragments + 2 per-query constants
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 + TN + 2, 0);   // DS reads: a1, w1 (+ the 2 per-query constants of the producer)
 #pragma unroll
-            for (int m = 0; m < 12 * TN; ++m) {
+            for (int m = 0; m < 4 + 2 * TN; ++m) {                        // the remaining 4 + 2 TN fragment reads, one behind each MFMA
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            }
+#pragma unroll
+            for (int m = 4 + 2 * TN; m < 12 * TN; ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, TN == 2 ? 3 : 2, 0);   // VALU
             }
