@@ -315,3 +315,20 @@ def test_effective_cpus_honours_the_cgroup_quota(tmp_path):
     assert sharding.effective_cpus(str(tmp_path)) == min(have, 3)
     (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
     assert sharding.effective_cpus(str(tmp_path)) == have
+
+
+def test_tuning_table_round_trip_and_unknown_key():
+    """tgn_set_tuning / tgn_get_tuning (include/tgn_pointops.h): host-side table, no GPU needed.  Known keys round-trip, (nt, p) pairs
+    pack as nt * 256 + p, the context manager restores, an unknown key is an error (not silently a no-op)."""
+    from toothgroupnetwork_amd import _lib
+    L = _lib.lib()
+    for key, default in (("fps_plain", 0), ("fps_bucket_min", -1), ("fps_cell_bits", 4), ("ball_bitmap", 1), ("sa_tile", 0), ("knn_grid_scale", 1000)):
+        assert L.tgn_get_tuning(key.encode(), -12345) == default, key
+    with _lib.tuning(fps_bucket_config=(512, 48), fps_plain=1):
+        assert L.tgn_get_tuning(b"fps_bucket_config", 0) == 512 * 256 + 48
+        assert L.tgn_get_tuning(b"fps_plain", 0) == 1
+    assert L.tgn_get_tuning(b"fps_bucket_config", -1) == 0 and L.tgn_get_tuning(b"fps_plain", -1) == 0
+    assert L.tgn_set_tuning(b"no_such_switch", 1) != 0 and b"no_such_switch" in L.tgn_last_error()
+    assert L.tgn_get_tuning(b"no_such_switch", 77) == 77
+    with pytest.raises(RuntimeError):
+        _lib.set_tuning("no_such_switch", 1)
