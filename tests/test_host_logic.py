@@ -332,3 +332,18 @@ def test_tuning_table_round_trip_and_unknown_key():
     assert L.tgn_get_tuning(b"no_such_switch", 77) == 77
     with pytest.raises(RuntimeError):
         _lib.set_tuning("no_such_switch", 1)
+
+
+def test_secondary_bench_loads_and_prices_the_fused_levels():
+    """bench.py attaches tools/secondary_bench.py's measurements to its JSON line; on CPU: the module loads the way bench.py loads it
+    and its flop count for the fused levels is the documented one (20.3 GFLOP per Shape-A scan, 57.7 per Shape-B scan)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sec = bench._secondary()
+    from toothgroupnetwork_amd import hotpath
+    assert sec.fused_flops(hotpath.SHAPE_A) == 20293091328
+    assert sec.fused_flops(hotpath.SHAPE_B) == 57713197056
+    r = sec._roof("hbm", 4000.0, 8000.0, "GB/s")
+    assert r["frac"] == 0.5 and sec._roof("latency", 0.81, None, "us")["frac"] is None
