@@ -144,31 +144,39 @@ def pt_forward(device):
         eager = _events(lambda: net([inp]), 5, 2)
     out = dict(value=1e3 / eager, unit="scans/s", ms=eager,
                config="nets.PointTransformerSeg (tgnet_fps stage sizes, class + offset heads) forward, one 24 000-point scan, eval, fp32")
+    out.update(_graph_ms(lambda x: net([x]), inp))
+    if "graph_ms" in out:
+        out["graph_scans_per_s"] = 1e3 / out["graph_ms"]
+    out["roofline"] = _roof("latency", out.get("graph_ms", eager), None, "ms per forward",
+                            note="the 24 000 -> 6000 sampling chain (5 999 serial arg-maxes in one workgroup, ~4.8 ms) is the floor of a "
+                                 "single-scan forward; the rest is ~350 small launches")
+    return out
+
+
+def _graph_ms(fn, inp):
+    """fn(static input) captured in one HIP graph after two warm-up runs on a side stream; median replay time, or the error."""
+    from toothgroupnetwork_amd import pointops as P
     try:
         static_in = inp.clone()
         s_ = torch.cuda.Stream()
         s_.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s_), torch.no_grad():
             for _ in range(2):
-                net([static_in])
+                fn(static_in)
         torch.cuda.current_stream().wait_stream(s_)
         torch.cuda.synchronize()
         P.knn_cache_clear()
         P.fps_prefix_clear()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g), torch.no_grad():
-            static_out = net([static_in])
+            static_out = fn(static_in)
         P.knn_cache_clear()
         P.fps_prefix_clear()
-        out["graph_ms"] = _events(g.replay, 8, 2)
-        out["graph_scans_per_s"] = 1e3 / out["graph_ms"]
+        ms = _events(g.replay, 8, 2)
         del g, static_out
+        return {"graph_ms": ms}
     except Exception as e:  # noqa: BLE001
-        out["graph_error"] = f"{type(e).__name__}: {str(e)[:200]}"
-    out["roofline"] = _roof("latency", out.get("graph_ms", eager), None, "ms per forward",
-                            note="the 24 000 -> 6000 sampling chain (5 999 serial arg-maxes in one workgroup, ~4.8 ms) is the floor of a "
-                                 "single-scan forward; the rest is ~350 small launches")
-    return out
+        return {"graph_error": f"{type(e).__name__}: {str(e)[:200]}"}
 
 
 def pnpp_forward(device, B=8):
@@ -180,10 +188,11 @@ def pnpp_forward(device, B=8):
     inp = torch.from_numpy(synth.scan_batch(B, 24000, "arch", 5).transpose(0, 2, 1).copy()).to(device)
     with torch.no_grad():
         ms = _events(lambda: net([inp]), 6, 3)
+    graph_ms = _graph_ms(lambda x: net([x]), inp)
     # second-layer flops of the six SA branches + per-point first layers (the rest -- FP stack, heads -- is ~25 % on top)
     fl = fused_flops(hotpath.SHAPE_B)
-    return dict(value=B * 1e3 / ms, unit="scans/s", ms=ms,
-                config=f"nets.PointNetPPSeg (pointnet_pp.py get_model, scale 4) forward, {B} x 24 000-point scans, eval, eager",
+    return dict(value=B * 1e3 / ms, unit="scans/s", ms=ms, **graph_ms,
+                config=f"nets.PointNetPPSeg (pointnet_pp.py get_model, scale 4) forward, {B} x 24 000-point scans, eval, eager (graph_ms: one HIP graph)",
                 roofline=_roof("mfma", fl * B / ms / 1e9, MFMA_FP32_PEAK, "TFLOP/s",
                                note="set-abstraction flops only (fp32-equivalent; second layers run as bf16x3 MFMAs) over the WHOLE forward time, "
                                     "which also holds sampling, ball queries, three feature-propagation levels and the heads"))
