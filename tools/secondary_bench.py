@@ -220,8 +220,8 @@ def measure_all(make_inputs, device, budget_s=150.0):
     t0 = time.perf_counter()
     out = {}
     plan = [("shape_B_materialised", lambda: hot_path(make_inputs, device, "B", False, steps=10, warmup=3)),
-            ("fused_shape_A", lambda: hot_path(make_inputs, device, "A", True, steps=4, warmup=2)),
-            ("fused_shape_B", lambda: hot_path(make_inputs, device, "B", True, steps=4, warmup=2)),
+            ("fused_shape_A", lambda: hot_path(make_inputs, device, "A", True, steps=10, warmup=3)),
+            ("fused_shape_B", lambda: hot_path(make_inputs, device, "B", True, steps=8, warmup=3)),
             ("knn_24000_k36", lambda: knn(device)),
             ("fps_100k_to_24k", lambda: fps_large(device)),
             ("pnpp_forward_8x24000", lambda: pnpp_forward(device)),
