@@ -2,13 +2,14 @@
 """Round-4 golden fixtures (tests/golden/reference_cpu_r4.npz), produced by running the REFERENCE's own Python on CPU in the
 build container:
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_r4.py [part ...]      (parts: group_all modules64 nets24k train)
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_r4.py [part ...]      (parts: group_all modules64 tsegnet nets24k train)
 
   (a) `group_all`: external_libs/pointnet2_utils/pointnet2_utils.py:198-239 `PointNetSetAbstraction(..., group_all=True)` in
       eval mode -- the only form of that module any reference model builds -- at the reference's own instantiation
       (models/modules/tsg_seg_module.py:28: `PointNetSetAbstraction(None, None, None, 512+3, [256, 512], True)` over the 256
       points of the last set-abstraction level) and at a ragged narrow shape (100 points, 3+5 channels -> [16, 32]).
   (a') `modules64`: the module-level fixtures of make_golden.py evaluated in float64 on the same indices.
+  (a'') `tsegnet`: the two modules of tsegnet (tsg_centroid_module / tsg_seg_module get_model), whole, eval mode.
   (b) `nets24k`: the WHOLE networks of BASELINE configs 2 and 4 at the configs' own size, ONE 24 000-point scan:
       models/modules/pointnet_pp.py:43-70 `get_model.forward` and cbl_point_transformer_module.py:93-216
       `PointTransformerSeg.forward`, eval mode, served exactly as in make_golden_r3.py (only the CUDA-only FPS / kNN come from
@@ -132,6 +133,43 @@ def pointnet_pp_24k(out):
             out[f"pnpp24_{n_}_32"] = a.numpy()[s]
 
 
+def tsegnet_modules(out):
+    """The two modules of tsegnet (models/modules/tsegnet.py:15-16): tsg_centroid_module.get_model on two 3000-point scans and
+    tsg_seg_module.get_model -- whose `flatten_sa` is the reference's one PointNetSetAbstraction(group_all=True) -- on two cropped
+    neighbourhoods of 3072 points with 36 channels (xyz + 33 synthetic feature channels), eval mode, float32 and float64 on the same
+    indices.  Only `farthest_point_sample` (CUDA-only) is served, by the reference's CPU FPS with start 0."""
+    if REFERENCE not in sys.path:
+        sys.path.append(REFERENCE)
+    import models.modules.tsg_centroid_module as CM
+    import models.modules.tsg_seg_module as SM
+    U = sys.modules["external_libs.pointnet2_utils.pointnet2_utils"]
+    assert U.__file__.startswith(REFERENCE), U.__file__
+    keep_fps, keep_sqd = U.farthest_point_sample, U.square_distance
+    U.farthest_point_sample = lambda x, n: torch.from_numpy(ref_fps(U, x.detach().float().numpy(), n))
+    try:
+        for tag, M, seed, N, C in (("cent", CM, 34, 3000, 6), ("seg", SM, 35, 3072, 36)):
+            scans = synth.scan_batch(2, N, "arch", seed=400 + seed)                      # (2, N, 6)
+            g = torch.Generator().manual_seed(seed)
+            feats = torch.from_numpy(np.ascontiguousarray(scans.transpose(0, 2, 1)))
+            if C > 6:
+                feats = torch.cat([feats, 0.5 * torch.randn(2, C - 6, N, generator=g)], 1)
+            net = M.get_model().eval()
+            out[f"tsg_{tag}_params"] = np.array(seeded_fill(net, seed))
+            U.square_distance = keep_sqd
+            with torch.no_grad():
+                y32 = net(feats)
+                U.square_distance = lambda a, b: keep_sqd(a.float(), b.float()).double()
+                y64 = net.double()(feats.double())
+            out[f"tsg_{tag}_feats"] = feats.numpy()
+            for i, (a, b) in enumerate(zip(y32, y64)):
+                print(f"  tsg_{tag}[{i}] {tuple(a.shape)}  |fp32 - fp64| / (1 + |fp64|) = {rel_err(a.numpy(), b.numpy()):.2e}")
+                sl = (slice(None), slice(None), slice(0, None, 4)) if a.dim() == 3 and a.shape[2] > 1000 else (slice(None),)
+                out[f"tsg_{tag}_{i}_64"] = b.numpy()[sl].astype(np.float32)
+                out[f"tsg_{tag}_{i}_32"] = a.numpy()[sl]
+    finally:
+        U.farthest_point_sample, U.square_distance = keep_fps, keep_sqd
+
+
 def _serve_pointops(RP):
     def fps(xyz, offset, new_offset):
         return torch.from_numpy(O.furthestsampling(xyz.detach().float().numpy(), offset.numpy(), new_offset.numpy()).astype(np.int32))
@@ -251,7 +289,7 @@ def train_step(out, N=int(os.environ.get("TGN_TRAIN_GOLDEN_POINTS", "24000"))):
 
 def main():
     torch.set_num_threads(8)
-    parts = sys.argv[1:] or ["group_all", "modules64", "nets24k", "train"]
+    parts = sys.argv[1:] or ["group_all", "modules64", "tsegnet", "nets24k", "train"]
     path = os.path.join(HERE, "reference_cpu_r4.npz")
     out = dict(np.load(path)) if os.path.exists(path) else {}
     R = load_reference()
@@ -259,6 +297,8 @@ def main():
         group_all(R, out)
     if "modules64" in parts:
         modules64(R, out)
+    if "tsegnet" in parts:
+        tsegnet_modules(out)
     if "nets24k" in parts:
         pointnet_pp_24k(out)
         point_transformer_24k(out)

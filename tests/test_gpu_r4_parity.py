@@ -232,3 +232,36 @@ def test_training_step_gradients_match_the_reference_network(dev, golden_r4):
     for n, n64, ng, d_got, d_own, s_ref in rows:
         assert d_got <= max(4.0 * d_own, 0.02 * s_ref, floor), (n, d_got, d_own, s_ref)
         assert abs(ng - n64) <= max(4.0 * abs(norms[names.index(n), 1] - n64), 0.02 * n64, 8 * floor), (n, ng, n64)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the two modules of tsegnet, whole (north_star: models/tsegnet_model.py imports the operators unchanged)
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,cls_name,seed", [("cent", "TsgCentroidNet", 34), ("seg", "TsgSegNet", 35)])
+def test_tsegnet_modules_match_the_reference(dev, golden_r4, monkeypatch, tag, cls_name, seed):
+    """tsg_centroid_module.get_model / tsg_seg_module.get_model (models/modules/tsegnet.py:15-16) run by the reference on CPU
+    (tests/golden/make_golden_r4.py tsegnet) against the mirrors built from the drop-in modules: every output within 1e-5 of the exact
+    (float64) value, no torch Conv2d anywhere -- every set-abstraction branch is the chained kernel, and the seg module's `flatten_sa`,
+    the reference's only PointNetSetAbstraction(group_all=True), runs on tgn_sa_all_mlp2_max."""
+    from toothgroupnetwork_amd import nets, pointnet2_utils as U
+    calls = {"conv2d": 0, "all": 0, "mlp2": 0}
+    real_conv, real_all, real_mlp2 = torch.nn.Conv2d.forward, U.sa_all_mlp2_max, U.sa_level_mlp2_max
+    monkeypatch.setattr(torch.nn.Conv2d, "forward", lambda self, x: calls.__setitem__("conv2d", calls["conv2d"] + 1) or real_conv(self, x))
+    monkeypatch.setattr(U, "sa_all_mlp2_max", lambda *a, **k: calls.__setitem__("all", calls["all"] + 1) or real_all(*a, **k))
+    monkeypatch.setattr(U, "sa_level_mlp2_max", lambda *a, **k: calls.__setitem__("mlp2", calls["mlp2"] + 1) or real_mlp2(*a, **k))
+    net = getattr(nets, cls_name)()
+    assert seeded_fill(net, seed) == golden_r4[f"tsg_{tag}_params"].tolist()          # names, shapes AND order of the reference's parameters
+    net = net.to(dev).eval()
+    feats = torch.from_numpy(golden_r4[f"tsg_{tag}_feats"]).to(dev)
+    with torch.no_grad():
+        y = net(feats)
+    worst = {}
+    for i, t in enumerate(y):
+        got = t.cpu().numpy()
+        want = golden_r4[f"tsg_{tag}_{i}_64"]
+        if got.ndim == 3 and got.shape[2] > 1000:
+            got = got[:, :, ::4]
+        worst[i] = (_err(got, want), _err(golden_r4[f"tsg_{tag}_{i}_32"], want))
+        assert worst[i][0] <= 1e-5, (tag, i, worst[i])
+    print(f"\ntsegnet {cls_name}: (drop-in vs exact, reference fp32 vs exact) per output {worst}")
+    assert calls == ({"conv2d": 0, "all": 0, "mlp2": 6} if tag == "cent" else {"conv2d": 0, "all": 1, "mlp2": 12}), calls

@@ -37,6 +37,9 @@ def test_mirrors_have_the_reference_networks_parameters(golden_r3):
     from toothgroupnetwork_amd import nets
     assert seeded_fill(nets.PointNetPPSeg(), 31) == golden_r3["pnpp_params"].tolist()
     assert seeded_fill(nets.PointTransformerSeg(), 32) == golden_r3["pt_params"].tolist()
+    r4 = np.load(os.path.join(GOLDEN, "reference_cpu_r4.npz"))
+    assert seeded_fill(nets.TsgCentroidNet(), 34) == r4["tsg_cent_params"].tolist()     # tsg_centroid_module.get_model
+    assert seeded_fill(nets.TsgSegNet(), 35) == r4["tsg_seg_params"].tolist()           # tsg_seg_module.get_model
 
 
 def test_seeded_fill_is_order_independent():

@@ -7,6 +7,10 @@ of the fused eval paths.  Parameter names and shapes equal the reference classes
 
   PointNetPPSeg        models/modules/pointnet_pp.py:6-70 (`get_model`): three multi-scale set-abstraction levels, three
                        feature-propagation levels, offset / distance / class heads; BASELINE.json config 2's network.
+  TsgCentroidNet       models/modules/tsg_centroid_module.py:5-46 and
+  TsgSegNet            models/modules/tsg_seg_module.py:4-80 -- the two modules of tsegnet (models/modules/tsegnet.py:15-16, the network behind
+                       models/tsegnet_model.py): PointNet++-MSG trunks; the second one ends in the ONLY PointNetSetAbstraction(group_all=True)
+                       of the reference (`flatten_sa`, :28).
   PointTransformerSeg  models/modules/cbl_point_transformer/cbl_point_transformer_module.py:28-216 with the configuration
                        the reference ships (default.yaml: five stages, `multi` heads over the decoder stages, latent
                        features concatenated); BASELINE.json configs 3 / 4's network.  Inference outputs only: the
@@ -17,7 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _derived, point_transformer as PT, pointops
-from .pointnet2_utils import PointNetFeaturePropagation, PointNetSetAbstractionMsg
+from .pointnet2_utils import PointNetFeaturePropagation, PointNetSetAbstraction, PointNetSetAbstractionMsg
 
 
 class PointNetPPSeg(nn.Module):
@@ -72,6 +76,84 @@ class PointNetPPSeg(nn.Module):
         if self.cls_pred:
             out.append(self._head("cls", up))
         return out
+
+
+def _msg_sa(mod, suffix, c_in):
+    """The three multi-scale set-abstraction levels both tsegnet modules share (tsg_centroid_module.py:10-12, tsg_seg_module.py:11-13 /
+    :24-26), registered on `mod` as sa{1,2,3}{suffix}."""
+    levels = ((1024, [0.025, 0.05], c_in, [32, 32]), (512, [0.05, 0.1], 64, [64, 128]), (256, [0.1, 0.2], 256, [196, 256]))
+    for i, (S, radii, c, widths) in enumerate(levels, 1):
+        setattr(mod, f"sa{i}{suffix}", PointNetSetAbstractionMsg(S, radii, [32, 64], c, [widths, widths]))
+
+
+def _msg_fp(mod, suffix, c_in):
+    """... and their three feature-propagation levels fp{3,2,1}{suffix} (:15-17 / :16-18 / :30-32)."""
+    for i, (c, widths) in ((3, (768, [256, 256])), (2, (320, [128, 128])), (1, (128 + c_in, [64, 32]))):
+        setattr(mod, f"fp{i}{suffix}", PointNetFeaturePropagation(c, widths))
+
+
+def _run_trunk(mod, suffix, feats):
+    """-> (per-point features (B, 32, N), xyz / features of the three coarse levels)"""
+    xyz, pts = [feats[:, :3, :]], [feats]
+    for i in (1, 2, 3):
+        x, p = getattr(mod, f"sa{i}{suffix}")(xyz[-1], pts[-1])
+        xyz.append(x)
+        pts.append(p)
+    up = pts[3]
+    for lvl in (3, 2, 1):
+        up = getattr(mod, f"fp{lvl}{suffix}")(xyz[lvl - 1], xyz[lvl], pts[lvl - 1], up)
+    return up, xyz, pts
+
+
+class TsgCentroidNet(nn.Module):
+    """tsg_centroid_module.get_model: per coarse point (256 of them) an offset to the nearest tooth centroid and its distance."""
+
+    def __init__(self):
+        super().__init__()
+        _msg_sa(self, "", 6)
+        _msg_fp(self, "", 6)
+        for head, width in (("offset", 3), ("dist", 1)):
+            setattr(self, f"{head}_conv_1", nn.Conv1d(515, 256, 1))
+            setattr(self, f"{head}_bn_1", nn.BatchNorm1d(256))
+        self.offset_conv_2, self.dist_conv_2 = nn.Conv1d(256, 3, 1), nn.Conv1d(256, 1, 1)
+        nn.init.zeros_(self.offset_conv_2.weight)
+        nn.init.zeros_(self.dist_conv_2.weight)
+
+    def forward(self, feats):
+        """feats (B, 6, N), xyz first -> [l0_points, l3_points, l0_xyz, l3_xyz, offset (B,3,256), dist (B,1,256)] (:29-46)"""
+        up, xyz, pts = _run_trunk(self, "", feats)
+        coarse = torch.cat([pts[3], xyz[3]], 1)
+        heads = [getattr(self, f"{h}_conv_2")(F.relu(getattr(self, f"{h}_bn_1")(getattr(self, f"{h}_conv_1")(coarse)))) for h in ("offset", "dist")]
+        return [up, pts[3], xyz[0], xyz[3]] + heads
+
+
+class TsgSegNet(nn.Module):
+    """tsg_seg_module.get_model: two trunks on a cropped tooth neighbourhood (36 input channels; the second sees the first's
+    foreground probabilities), a per-point mask each, and a tooth-id head on the max over ALL 256 coarse points -- the reference's
+    one PointNetSetAbstraction(group_all=True), which runs on tgn_sa_all_mlp2_max in eval mode."""
+
+    def __init__(self, input_feature_num=36):
+        super().__init__()
+        _msg_sa(self, "_1", input_feature_num)
+        _msg_fp(self, "_1", input_feature_num)
+        self.pd_mask_1, self.pd_mask_1_softmax, self.wt_mask_1 = nn.Conv1d(32, 2, 1), nn.Softmax(dim=1), nn.Conv1d(32, 1, 1)
+        _msg_sa(self, "_2", input_feature_num + 2)                       # (module order = the reference's: state_dict keys line up)
+        self.flatten_sa = PointNetSetAbstraction(None, None, None, 512 + 3, [256, 512], True)
+        _msg_fp(self, "_2", input_feature_num + 2)
+        self.pd_mask_2 = nn.Conv1d(32, 1, 1)
+        self.fc1, self.bn1, self.fc2 = nn.Linear(512, 256), nn.LayerNorm(256), nn.Linear(256, 17)
+        nn.init.zeros_(self.fc2.weight)
+        nn.init.zeros_(self.fc2.bias)
+
+    def forward(self, feats):
+        """feats (B, 36, N), xyz first -> (pd_1 (B,2,N), weight_1 (B,1,N), pd_2 (B,1,N), id_pred (B,17)) (:45-79)"""
+        up1, _, _ = _run_trunk(self, "_1", feats)
+        pd_1 = self.pd_mask_1_softmax(self.pd_mask_1(up1))
+        weight_1 = self.wt_mask_1(up1)
+        up2, xyz, pts = _run_trunk(self, "_2", torch.cat([feats, pd_1], 1))
+        _, pooled = self.flatten_sa(xyz[3], pts[3])
+        id_pred = self.fc2(F.relu(self.bn1(self.fc1(pooled.view(feats.shape[0], 512)))))
+        return pd_1, weight_1, self.pd_mask_2(up2), id_pred
 
 
 class _LatentMLP(nn.Module):
