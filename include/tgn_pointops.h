@@ -340,6 +340,10 @@ int tgn_sa_mlp2_max(int B, int N, int S, int K, int D, int C1p, int C2, const fl
  *   tgn_sa_mlp2_max_bf16x3              tgn_sa_mlp2_max with W2s (the image) in place of W2f; every other argument as above.
  */
 size_t tgn_sa_mlp2_split_bytes(int C1p, int C2);
+/* tgn_sa_point_transform on the same scheme: Wts = tgn_sa_mlp2_split_weights(Kp, C1, Wtf) with Wtf (Kp/8, C1, 8),
+ * Wtf[kb][c][i] = Wt[8 kb + i][c] (rows [features..., x, y, z], zero rows past D + 3), Kp = D + 3 rounded up to a multiple of 16. */
+int tgn_sa_point_transform_bf16x3(long long M, int D, int Kp, int C1, const float *xyz, const float *points, const void *Wts,
+                                  float *A, tgn_stream_t stream);
 int tgn_sa_mlp2_split_weights(int C1p, int C2, const float *W2f, void *W2s, tgn_stream_t stream);
 int tgn_sa_mlp2_max_bf16x3(int B, int N, int S, int K, int D, int C1p, int C2, const float *A1, const float *xyz,
                            const float *points, const float *new_xyz, const float *W1, const float *b1, const void *idx,

@@ -270,3 +270,24 @@ def test_hotpath_fused_multi_scale_levels_vs_oracle(dev, oracle, pipeline):
             col += c2
         assert col == lv["out"].shape[2]
         cur, feat = new_xyz, lv["out"].cpu().numpy()
+
+
+@pytest.mark.parametrize("M,D,C1", [(6000, 256, 256), (4099, 1024, 784), (1000, 61, 100), (300, 13, 208), (129, 0, 16)])
+def test_point_transform_bf16x3_vs_float64(dev, M, D, C1):
+    """tgn_sa_point_transform_bf16x3 (per-point first layer as six bf16 MFMAs per fp32 product) and the fp32-MFMA form against
+    [points, xyz] @ Wt in float64, elementwise 1e-5; odd row counts, widths that need K padding, D = 0."""
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    g = torch.Generator().manual_seed(M + D)
+    xyz = (torch.rand(1, M, 3, generator=g) * 2 - 1).to(dev)
+    pts = torch.randn(1, M, D, generator=g).to(dev) if D else None
+    Wt = (torch.randn(D + 3, C1, generator=g) / (D + 3) ** 0.5).to(dev)
+    rows = xyz[0] if pts is None else torch.cat([pts[0], xyz[0]], 1)
+    want = (rows.double() @ Wt.double()).cpu().numpy()
+    exact = U.sa_point_transform(xyz, pts, Wt)[0].cpu().numpy()
+    split = U.sa_point_transform(xyz, pts, Wt, U.split_point_transform(Wt))[0].cpu().numpy()
+    close(exact, want, "fp32-MFMA transform")
+    close(split, want, "bf16x3 transform")
+    e1 = np.abs(exact - want) / (1 + np.abs(want))
+    e2 = np.abs(split - want) / (1 + np.abs(want))
+    print(f"\npoint transform ({M},{D},{C1}): fp32-mfma max {e1.max():.2e} rms {np.sqrt((e1 ** 2).mean()):.2e} | bf16x3 max {e2.max():.2e} "
+          f"rms {np.sqrt((e2 ** 2).mean()):.2e}")

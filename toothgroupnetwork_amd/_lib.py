@@ -89,6 +89,7 @@ SIGNATURES = {
     "tgn_sa_mlp2_max": (c_int, [c_int] * 7 + [_P] * 7 + [c_int, _P, _P, _P, c_int, _P]),
     "tgn_sa_mlp2_split_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "tgn_sa_mlp2_split_weights": (c_int, [c_int, c_int, _P, _P, _P]),
+    "tgn_sa_point_transform_bf16x3": (c_int, [ctypes.c_longlong, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "tgn_sa_mlp2_max_bf16x3": (c_int, [c_int] * 7 + [_P] * 7 + [c_int, _P, _P, _P, c_int, _P]),
     "tgn_sa_all_chunks": (c_int, [c_int]),
     "tgn_sa_all_mlp2_max": (c_int, [c_int] * 5 + [_P] * 9 + [c_int, _P]),

@@ -566,6 +566,131 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void sa_mlp2_max_split_k
     }
 }
 
+// Per-point first layer of the commuted form, A[m, :] = [points[m, :], xyz[m, :]] * Wt (tgn_sa_point_transform), on the same bf16x3
+// scheme: rows [features..., x, y, z] split in registers, the weights as a split image (tgn_sa_mlp2_split_weights of Wt arranged as
+// (Kp/8, C1, 8)), 128 x 128 tile, the full tile written (no ReLU, no max: the chained kernel adds the per-query constant).
+__global__ __launch_bounds__(256, 2) void sa_point_transform_split_kernel(long long M, int D, int Kp, int C1,
+                                                                           const float *__restrict__ xyz, const float *__restrict__ points,
+                                                                           const unsigned char *__restrict__ Wts, float *__restrict__ A) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem_t[4 * kSplitTile];
+    unsigned char *FA = smem_t, *FB = smem_t + 2 * kSplitTile;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int Kc = D + 3, T = Kp / kMlpKT;
+    const unsigned ntiles = ((unsigned)C1 + kMlpNT - 1) / kMlpNT;
+    const long long row0 = (long long)blockIdx.y * kMlpMT;
+    const int ntile = (int)blockIdx.x, col0 = ntile * kMlpNT;
+    const int ar = tid & 127;
+    const int ah = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const long long grow = row0 + ar;
+    const bool row_ok = grow < M;
+    const bool feat4 = (D & 3) == 0 && points != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(Wts), 0,
+                                                                          (int)((size_t)ntiles * T * kSplitTile), 0x00020000);
+    auto dma = [&](int t, int buf) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int piece = wv * 3 + p;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(FB + buf * kSplitTile + piece * 1024), 16,
+                                                     lane * 16, (ntile * T + t) * kSplitTile + piece * 1024, 0, 0);
+        }
+    };
+    float ra[8];
+    auto fetch = [&](int t) {
+        const int c = t * kMlpKT + ah * 8;   // first channel of this thread's 8
+        if (row_ok && feat4 && c + 8 <= D) {
+            const f32x4 u = *(const f32x4 *)(points + (size_t)grow * D + c);
+            const f32x4 w = *(const f32x4 *)(points + (size_t)grow * D + c + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = u[i];
+                ra[4 + i] = w[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ci = c + i;
+                float val = 0.0f;
+                if (row_ok) {
+                    if (ci < D) val = points[(size_t)grow * D + ci];
+                    else if (ci < Kc) val = xyz[(size_t)grow * 3 + (ci - D)];
+                }
+                ra[i] = val;
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+        bf16x8 p1, p2, p3;
+        split3(ra, p1, p2, p3);
+        unsigned char *fa = FA + buf * kSplitTile + split_chunk(ar, ah);
+        *(bf16x8 *)fa = p1;
+        *(bf16x8 *)(fa + kSplitPlane) = p2;
+        *(bf16x8 *)(fa + 2 * kSplitPlane) = p3;
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    bf16x8 fa_[2][3], fw_[2][3];
+    auto load_frags = [&](int buf) {
+        const unsigned char *fa = FA + buf * kSplitTile, *fb = FB + buf * kSplitTile;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ca = split_chunk(wm * 64 + i * 32 + lo, hi), cb = split_chunk(wn * 64 + i * 32 + lo, hi);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                fa_[i][c] = *(const bf16x8 *)(fa + c * kSplitPlane + ca);
+                fw_[i][c] = *(const bf16x8 *)(fb + c * kSplitPlane + cb);
+            }
+        }
+    };
+    auto mma = [&]() {
+#define TGN_SPLIT_STEP(CA, CB)                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i][CA], fw_[j][CB], acc[i][j], 0, 0, 0)
+        TGN_SPLIT_STEP(0, 0);
+        TGN_SPLIT_STEP(0, 1);
+        TGN_SPLIT_STEP(1, 0);
+        TGN_SPLIT_STEP(1, 1);
+        TGN_SPLIT_STEP(0, 2);
+        TGN_SPLIT_STEP(2, 0);
+#undef TGN_SPLIT_STEP
+    };
+    fetch(0);
+    dma(0, 0);
+    stage(0);
+    if (T > 1) fetch(1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the LDS-DMA pieces have landed
+    __syncthreads();
+    for (int t = 0; t + 1 < T; ++t) {
+        dma(t + 1, (t + 1) & 1);
+        load_frags(t & 1);
+        stage((t + 1) & 1);
+        fetch(t + 2 < T ? t + 2 : T - 1);
+        mma();
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+    }
+    load_frags((T - 1) & 1);
+    mma();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + wn * 64 + j * 32 + lo;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row < M && col < C1) A[(size_t)row * C1 + col] = acc[i][j][r];
+            }
+        }
+}
+
 // out[b, c] = max_s part[b, s, c]: the chunks of a group_all level (post-ReLU values, so the order of the two maxima is free)
 __global__ __launch_bounds__(256) void sa_chunks_max_kernel(int B, int S, int C, int ostride, const float *__restrict__ part,
                                                             float *__restrict__ out) {
@@ -758,4 +883,25 @@ TGN_API int tgn_sa_all_mlp2_max(int B, int N, int D, int C1p, int C2, const floa
     hipLaunchKernelGGL(sa_chunks_max_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, S, C2, out_stride,
                        part, out);
     return check_launch("sa_chunks_max_kernel");
+}
+
+// tgn_sa_point_transform on the bf16 matrix cores at fp32 accuracy (the scheme of tgn_sa_mlp2_max_bf16x3): Wts = the split image of Wt
+// -- tgn_sa_mlp2_split_weights(Kp, C1, Wtf, Wts) with Wtf (Kp/8, C1, 8), Wtf[kb][c][i] = Wt[8 kb + i][c], zero rows past D + 3;
+// Kp = D + 3 rounded up to a multiple of 16.  A (M, C1) as tgn_sa_point_transform writes it (fp32-class rounding, not bit-identical).
+TGN_API int tgn_sa_point_transform_bf16x3(long long M, int D, int Kp, int C1, const float *xyz, const float *points, const void *Wts,
+                                          float *A, tgn_stream_t stream) {
+    if (M <= 0 || C1 <= 0) return TGN_OK;
+    if (!xyz || !Wts || !A || (D > 0 && !points) || D < 0 || Kp < D + 3 || (Kp & 15) || ((uintptr_t)Wts & 15)) {
+        set_error("tgn_sa_point_transform_bf16x3: null pointer, or Kp is not D + 3 rounded up to a multiple of 16");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    const long long by = (M + kMlpMT - 1) / kMlpMT;
+    const long long nt = (C1 + kMlpNT - 1) / kMlpNT;
+    if (by > 65535 || nt * (Kp / kMlpKT) * kSplitTile > 0x7FFFFFFFLL) {   // (grid.y; the fp32 form has the same bound)
+        set_error("tgn_sa_point_transform_bf16x3: too many rows (> 65535 x 128) or too large a weight image");
+        return TGN_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(sa_point_transform_split_kernel, dim3((unsigned)nt, (unsigned)by), dim3(256), 0, (hipStream_t)stream, M, D, Kp, C1,
+                       xyz, points, (const unsigned char *)Wts, A);
+    return check_launch("sa_point_transform_split_kernel");
 }

@@ -220,6 +220,7 @@ class HotPath:
             from . import pointnet2_utils as U
             # second layer on the bf16 matrix cores at fp32 accuracy (tgn_sa_mlp2_max_bf16x3) unless TGN_SA_BF16X3=0
             out["W2s"] = U.split_second_layer(out["W2f"]) if U.SA_BF16X3 else None
+            out["Wts"] = U.split_point_transform(out["Wt"]) if (U.SA_BF16X3 and not out["direct"]) else None
         out["layers"] = layers
         out["A"] = None if out["direct"] else torch.empty(self.B, N, C1p, **f32)
         return out
@@ -241,7 +242,10 @@ class HotPath:
     def _sa(self, lv, br, cur_xyz, pts, st):
         """one fused (radius, nsample) branch of a set-abstraction level on stream st"""
         L, B = self.L, self.B
-        if not br["direct"]:
+        if not br["direct"] and br.get("Wts") is not None and B * lv["N"] <= 65535 * 128:
+            check(L.tgn_sa_point_transform_bf16x3(B * lv["N"], lv["D"], br["Wts"][1], br["C1p"], ptr(cur_xyz), ptr(pts), ptr(br["Wts"][0]),
+                                                  ptr(br["A"]), st), "sa_point_transform_bf16x3")
+        elif not br["direct"]:
             check(L.tgn_sa_point_transform(B * lv["N"], lv["D"], br["C1p"], ptr(cur_xyz), ptr(pts), ptr(br["Wt"]), ptr(br["A"]), st),
                   "sa_point_transform")
         out = br["out"]

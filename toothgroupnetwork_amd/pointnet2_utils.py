@@ -447,14 +447,29 @@ def _fold_first_layer(conv, bn, D, xyz_first):
     return dict(Wt=Wt, Wxs=Wt[D:].contiguous(), Wd=Wd, b2=(shift + scale * bias).contiguous(), C1=C1)
 
 
-def sa_point_transform(xyz, points, Wt):
-    """A[b,n,:] = [points[b,n,:], xyz[b,n,:]] @ Wt -- the per-POINT half of a fused first layer, on the fp32 matrix
-    cores (tgn_sa_point_transform).  xyz (B,N,3), points (B,N,D) or None, Wt (D+3, C1) -> (B,N,C1)."""
+def split_point_transform(Wt):
+    """The bf16 x 3 image of a per-point first-layer matrix Wt (D+3, C1) for tgn_sa_point_transform_bf16x3: rows padded with zeros
+    to a multiple of 16, arranged (Kp/8, C1, 8) and split like a second layer (tgn_sa_mlp2_split_weights)."""
+    Kc, C1 = Wt.shape
+    Kp = (Kc + 15) // 16 * 16
+    Wp = Wt.new_zeros(Kp, C1)
+    Wp[:Kc] = Wt
+    return split_second_layer(Wp.view(Kp // 8, 8, C1).permute(0, 2, 1).contiguous()), Kp
+
+
+def sa_point_transform(xyz, points, Wt, Wts=None):
+    """A[b,n,:] = [points[b,n,:], xyz[b,n,:]] @ Wt -- the per-POINT half of a fused first layer, on the matrix cores.
+    xyz (B,N,3), points (B,N,D) or None, Wt (D+3, C1) -> (B,N,C1).  Wts = split_point_transform(Wt): the bf16 x 3 form
+    (tgn_sa_point_transform_bf16x3, fp32-class rounding at up to 2.7x the rate); None: exact fp32 MFMA (tgn_sa_point_transform)."""
     B, N, _ = xyz.shape
     D = 0 if points is None else points.shape[2]
     C1 = Wt.shape[1]
     A = torch.empty(B, N, C1, dtype=torch.float32, device=xyz.device)
-    check(lib().tgn_sa_point_transform(B * N, D, C1, ptr(xyz), ptr(points), ptr(Wt), ptr(A), stream()), "sa_point_transform")
+    if Wts is not None and B * N <= 65535 * 128:
+        img, Kp = Wts
+        check(lib().tgn_sa_point_transform_bf16x3(B * N, D, Kp, C1, ptr(xyz), ptr(points), ptr(img), ptr(A), stream()), "sa_point_transform_bf16x3")
+    else:
+        check(lib().tgn_sa_point_transform(B * N, D, C1, ptr(xyz), ptr(points), ptr(Wt), ptr(A), stream()), "sa_point_transform")
     return A
 
 
@@ -561,7 +576,8 @@ def sa_level_mlp2_max(xyz, new_xyz, points, idx, convs, bns, xyz_first, out=None
         W2f, b2 = fold_second_layer(convs[1], bns[1], C1p)
         return dict(C1p=C1p, W2f=W2f, b2=b2, b1=_pad_cols(f["b2"], C1p), W2s=split_second_layer(W2f) if SA_BF16X3 else None,
                     W1=_pad_cols(f["Wd"] if direct else f["Wxs"], C1p),      # direct: (16, C1p) rows [x, y, z, features..., 0]
-                    Wt=None if direct else _pad_cols(f["Wt"], C1p))
+                    Wt=None if direct else _pad_cols(f["Wt"], C1p),
+                    Wts=split_point_transform(_pad_cols(f["Wt"], C1p)) if (SA_BF16X3 and not direct) else None)
     ops = _derived.cached(bns[1], "mlp2", _derived.sources(convs[0], bns[0], convs[1], bns[1]), (D, bool(xyz_first), direct, SA_BF16X3),
                           operands)
     C1p, W2f, b2, b1, W1 = ops["C1p"], ops["W2f"], ops["b2"], ops["b1"], ops["W1"]
@@ -570,7 +586,7 @@ def sa_level_mlp2_max(xyz, new_xyz, points, idx, convs, bns, xyz_first, out=None
     if out is None:
         out = torch.empty(B, S, C2, dtype=torch.float32, device=xyz.device)
     assert out.shape == (B, S, C2) and out.stride(2) == 1 and out.stride(0) == S * out.stride(1) and out.dtype == torch.float32
-    A1 = None if direct else sa_point_transform(xyz, points, ops["Wt"])      # (B, N, C1p)
+    A1 = None if direct else sa_point_transform(xyz, points, ops["Wt"], ops["Wts"])      # (B, N, C1p)
     _lib.begin_index_check()
     if ops["W2s"] is not None:
         check(L.tgn_sa_mlp2_max_bf16x3(B, N, S, K, D, C1p, C2, ptr(A1), ptr(xyz), ptr(points), ptr(new_xyz), ptr(W1), ptr(b1), ptr(idx),
