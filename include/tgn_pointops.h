@@ -450,6 +450,9 @@ int tgn_scan_open(const char *obj_path, const char *json_path, double y_min, dou
 /* Copies the rows to labeled (n,7) double and, when xyz32 is not NULL, the float32 coordinates to xyz32 (n,3); frees the
  * handle (both pointers NULL: only frees). */
 int tgn_scan_take(void *handle, double *labeled, float *xyz32);
+/* The loader recycles its per-scan scratch (file text, vertices, faces, normals, rows: ~25 MB for a 100 000-vertex scan) through a pool of
+ * at most 64 objects; this frees them (returns how many).  Safe at any time: tgn_scan_open allocates afresh when the pool is empty. */
+int tgn_scan_pool_trim(void);
 
 #ifdef __cplusplus
 }

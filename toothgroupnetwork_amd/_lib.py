@@ -107,6 +107,7 @@ SIGNATURES = {
     "tgn_vertex_normals": (c_int, [_P, ctypes.c_longlong, _P, ctypes.c_longlong, _P]),
     "tgn_scan_open": (c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_double, ctypes.c_double, _P, _P, ctypes.c_char_p, c_int]),
     "tgn_scan_take": (c_int, [_P, _P, _P]),
+    "tgn_scan_pool_trim": (c_int, []),
 }
 
 ERR_INVALID_ARGUMENT, ERR_LAUNCH, ERR_UNSUPPORTED = 1, 2, 3     # TGN_ERR_* of include/tgn_pointops.h

@@ -554,6 +554,17 @@ TGN_API int tgn_scan_open(const char *obj_path, const char *json_path, double y_
     return TGN_OK;
 }
 
+// Frees the pooled scan objects (their retained scratch: ~25 MB each); tgn_scan_open refills the pool on demand.  Returns how many.
+TGN_API int tgn_scan_pool_trim(void) {
+    std::vector<Scan *> drop;
+    {
+        std::lock_guard<std::mutex> lock(g_scan_mu);
+        drop.swap(g_scan_pool);
+    }
+    for (Scan *sc : drop) delete sc;
+    return (int)drop.size();
+}
+
 // Copies the (n, 7) rows out (and, when xyz32 is given, the float32 copy of the coordinates the sampler takes) and frees
 // the handle (back to the pool).  With both pointers null it only frees.
 TGN_API int tgn_scan_take(void *handle, double *labeled, float *xyz32) {

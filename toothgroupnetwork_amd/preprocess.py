@@ -204,7 +204,7 @@ def preprocess_scans(pairs, save_path, batch=16, fps_batch=None, workers=None, s
     sampler = ThreadPoolExecutor(max_workers=samplers)
     writer = ThreadPoolExecutor(max_workers=4)
 
-    pools = (ArrayPool(7, np.float64), ArrayPool(3, np.float32))
+    pools = (ArrayPool(7, np.float64, keep=2 * step + workers), ArrayPool(3, np.float32, keep=2 * step + workers))   # (what can be in flight)
 
     def load(obj_path, json_path):
         fast = load_scan_native(obj_path, json_path, with_xyz32=True, pools=pools)
@@ -273,6 +273,7 @@ def preprocess_scans(pairs, save_path, batch=16, fps_batch=None, workers=None, s
         pool.shutdown()
         sampler.shutdown()
         writer.shutdown()
+        _lib.lib().tgn_scan_pool_trim()                         # the native loader's recycled scratch (~25 MB per loader thread)
     return stats
 
 
