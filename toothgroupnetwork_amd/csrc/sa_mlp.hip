@@ -319,11 +319,21 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void sa_mlp2_max_split_k
     const unsigned ntiles = ((unsigned)C2 + NTL - 1) / NTL;
     const unsigned ntiles128 = ((unsigned)C2 + kMlpNT - 1) / kMlpNT;
     const long long mtiles = (Q + QPT - 1) / QPT;
+    // XCD-contiguous item ranges.  Within an XCD the items run SCAN by scan, within a scan COLUMN TILE by column tile, the scan's row
+    // tiles fastest: the ~32-64 workgroups an XCD holds at a time then share ONE column tile of the weight image (1.2 MB at 784 x 256)
+    // and gather from ONE scan's first-layer rows (1.6 MB at 512 x 784) -- both stay in its 4 MB L2.  (Column tile fastest, the
+    // fp32 kernel's order, has all column tiles -- the whole 4.7 MB image -- cycling through the L2 at once.)
     const unsigned nb = gridDim.x;
     const long long item = (long long)(blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
-    const long long mt = item / ntiles;
-    if (mt >= mtiles) return;
-    const int ntile = (int)(item - mt * ntiles);
+    const long long R = (S + QPT - 1) / QPT;                       // row tiles per scan (tiles of a ragged S straddle scans: harmless)
+    const long long per_group = R * ntiles;
+    const long long grp = item / per_group, rem = item - grp * per_group;
+    const long long base_mt = grp * R;
+    if (base_mt >= mtiles) return;
+    const long long Rg = mtiles - base_mt < R ? mtiles - base_mt : R;   // row tiles of this group (the last one may be short)
+    if (rem >= Rg * ntiles) return;
+    const int ntile = (int)(rem / Rg);
+    const long long mt = base_mt + (rem - (long long)ntile * Rg);
     const int col0 = ntile * NTL;
     const long long q0 = mt * QPT;
     const int T = C1p / kMlpKT;
