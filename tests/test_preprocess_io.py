@@ -187,3 +187,24 @@ def test_gpu_pipeline_writes_the_reference_files(dev, tmp_path, golden_r2, oracl
     d = ((full[sub, None, :3].astype(np.float32) - arr[None, :, :3].astype(np.float32)) ** 2).sum(-1)
     assert np.array_equal(got[sub], arr[d.argmin(1), 6])
     assert np.array_equal(got[idx_of_samples], arr[:, 6])      # a vertex that IS a sample gets its own label back
+
+
+def test_array_pool_recycles_row_buffers():
+    """preprocess.ArrayPool: take() hands out a view of a kept buffer of enough capacity (or a new one rounded up to 16 384 rows),
+    give() takes the base back whatever view it is handed, and at most `keep` buffers are retained."""
+    import numpy as np
+
+    from toothgroupnetwork_amd import preprocess
+    pool = preprocess.ArrayPool(7, np.float64, keep=2)
+    a = pool.take(100000)
+    assert a.shape == (100000, 7) and a.dtype == np.float64 and a.base.shape[0] == 114688     # 7 x 16 384 rows of capacity
+    base = a.base
+    pool.give(a)
+    b = pool.take(90000)                                                                         # fits the kept buffer: recycled
+    assert b.base is base and b.shape == (90000, 7)
+    c = pool.take(120000)                                                                        # too large for anything kept: new
+    assert c.base is not base and c.base.shape[0] == 131072
+    pool.give(b[:10])                                                                            # a view of a view: still the base
+    pool.give(c)
+    pool.give(np.empty((5, 7)))                                                                  # beyond `keep`: dropped
+    assert len(pool.free) == 2 and pool.free[0] is base
