@@ -21,6 +21,7 @@
 //     that is written.
 // Rows past K (K < 32 or 32 < K < 64) repeat neighbour 0, which a max does not see.
 #include "tgn_common.h"
+#include <type_traits>
 
 namespace tgn {
 
@@ -444,67 +445,35 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void sa_mlp2_max_split_k
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    bf16x8 fa_[2][3], fw_[TN][3];
-    // Fragment reads in the order the products need them -- a1, w1, w2, a2, w3, a3 -- so that the first MFMAs (a1 x w1) can start after
-    // 2 + TN reads instead of all 6 + 3 TN: after a barrier the waves of a CU read their fragments at the same time (18 b128 reads x
-    // 8 waves = 580 cycles of LDS) and the matrix cores used to idle behind all of them.
-    auto load_frags = [&](int buf) {
-        const unsigned char *fa = FA + buf * kATile, *fb = FB + buf * kBTile;
-        int ca[2], cb[TN];
+    bf16x8 fa_[2][3], fw_[TN][3];   // fragments: [tile of the wave][bf16 component]
+    int ca[2], cb[TN];              // their byte offsets inside a component plane
 #pragma unroll
-        for (int i = 0; i < 2; ++i) ca[i] = split_chunk(wm * 64 + i * 32 + lo, hi);
+    for (int i = 0; i < 2; ++i) ca[i] = split_chunk(wm * 64 + i * 32 + lo, hi);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = wn * (NTL / 2) + j * 32 + lo;   // column within the workgroup's tile; 128-column halves are separate images
-            cb[j] = (col >> 7) * kSplitTile + split_chunk(col & 127, hi);
-        }
-        auto ra = [&](int c) {
+    for (int j = 0; j < TN; ++j) {
+        const int col = wn * (NTL / 2) + j * 32 + lo;   // column within the workgroup's tile; 128-column halves are separate images
+        cb[j] = (col >> 7) * kSplitTile + split_chunk(col & 127, hi);
+    }
+    auto ra = [&](int buf, int c) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa_[i][c] = *(const bf16x8 *)(fa + c * kAPlane + ca[i]);
-        };
-        auto rw = [&](int c) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fw_[j][c] = *(const bf16x8 *)(fb + c * kSplitPlane + cb[j]);
-        };
-        if constexpr (DIRECT) {   // (255 registers: the need-order below makes this form spill)
-            ra(0);
-            ra(1);
-            ra(2);
-            rw(0);
-            rw(1);
-            rw(2);
-        } else {
-            ra(0);
-            rw(0);
-            rw(1);
-            ra(1);
-            rw(2);
-            ra(2);
-        }
+        for (int i = 0; i < 2; ++i) fa_[i][c] = *(const bf16x8 *)(FA + buf * kATile + c * kAPlane + ca[i]);
     };
-    auto mma = [&]() {
-        // six products per tile, in the order their fragments arrive; consecutive MFMAs go to different accumulators.  (The order of the
-        // six is irrelevant to the rounding: the accumulator already holds the sum over the earlier K tiles.)
-#define TGN_SPLIT_STEP(CA, CB)                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = \
-        __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i][CA], fw_[j][CB], acc[i][j], 0, 0, 0)
-        if constexpr (DIRECT) {   // (the order this form does not spill in)
-            TGN_SPLIT_STEP(2, 0);
-            TGN_SPLIT_STEP(0, 2);
-            TGN_SPLIT_STEP(1, 1);
-            TGN_SPLIT_STEP(1, 0);
-            TGN_SPLIT_STEP(0, 1);
-            TGN_SPLIT_STEP(0, 0);
-        } else {
-            TGN_SPLIT_STEP(0, 0);
-            TGN_SPLIT_STEP(0, 1);
-            TGN_SPLIT_STEP(1, 0);
-            TGN_SPLIT_STEP(1, 1);
-            TGN_SPLIT_STEP(0, 2);
-            TGN_SPLIT_STEP(2, 0);
-        }
-#undef TGN_SPLIT_STEP
+    auto rw = [&](int buf, int c) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fw_[j][c] = *(const bf16x8 *)(FB + buf * kBTile + c * kSplitPlane + cb[j]);
     };
+    // one of the six products of a K tile: component CA of the activations x component CB of the weights, 2 TN MFMAs on 2 TN different
+    // accumulators.  (The order of the six is irrelevant to the rounding: the accumulator already holds the sum over the earlier K tiles.)
+    auto product = [&](auto CA, auto CB) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i][CA()], fw_[j][CB()], acc[i][j], 0, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
     const int last = T - 1;
 
     fetch(0);
@@ -514,36 +483,104 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void sa_mlp2_max_split_k
     fetch(last < 1 ? last : 1);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the LDS-DMA pieces have landed (hipcc orders no ds_read behind them)
     __syncthreads();
-    for (int t = 0; t < last; ++t) {      // one basic block per trip: the scheduling pattern below needs it
-        dma(t + 1, (t + 1) & 1);          // FB / FA[(t+1)&1] were last read in trip t-1: every wave is past the barrier that ended it
-        load_frags(t & 1);                // IN FRONT of the producer's LDS stores: hipcc keeps an LDS read behind an earlier LDS write it
-                                          // cannot tell apart, which would chain  split -> ds_write -> ds_read -> MFMA  and serialise the trip
-        stage(t + 1, (t + 1) & 1);        // from the registers fetch(t+1) filled one trip ago
-        fetch(t + 2 < last ? t + 2 : last);   // in flight under the MFMAs (the last trip re-reads tile T-1: unused)
-        mma();
-        if constexpr (!DIRECT) {
-            // the waves of a SIMD run in phase (one workgroup, or two that drift into phase: SQ counters in profiles/), so the producer's
-            // work must hide under this wave's OWN matrix instructions: a 32x32x16 bf16 MFMA holds the pipe for 32 cycles, room for ~4
-            // other instructions.  Order: the fragment reads, then one MFMA + a few vector instructions, 12 TN times, then the stores.
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 + TN + 2, 0);   // DS reads: a1, w1 (+ the 2 per-query constants of the producer)
-#pragma unroll
-            for (int m = 0; m < 4 + 2 * TN; ++m) {                        // the remaining 4 + 2 TN fragment reads, one behind each MFMA
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-            }
-#pragma unroll
-            for (int m = 4 + 2 * TN; m < 12 * TN; ++m) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, TN == 2 ? 3 : 2, 0);   // VALU
-            }
-            __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);                // DS writes of the staged tile
+    if constexpr (DIRECT) {
+        // (255 registers: this read order and this product order are the ones the form does not spill in)
+        auto tile = [&](int buf) {
+            ra(buf, 0);
+            ra(buf, 1);
+            ra(buf, 2);
+            rw(buf, 0);
+            rw(buf, 1);
+            rw(buf, 2);
+        };
+        auto mma = [&]() {
+            product(I2{}, I0{});
+            product(I0{}, I2{});
+            product(I1{}, I1{});
+            product(I1{}, I0{});
+            product(I0{}, I1{});
+            product(I0{}, I0{});
+        };
+        for (int t = 0; t < last; ++t) {
+            dma(t + 1, (t + 1) & 1);          // FB / FA[(t+1)&1] were last read in trip t-1: every wave is past the barrier that ended it
+            tile(t & 1);                      // IN FRONT of the producer's LDS stores: hipcc keeps an LDS read behind an earlier LDS write
+                                              // it cannot tell apart, which would chain  split -> ds_write -> ds_read -> MFMA
+            stage(t + 1, (t + 1) & 1);
+            mma();
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
+        tile(last & 1);
+        mma();
+    } else {
+        // One trip per K tile, one basic block each (the scheduling hints need it).  The waves of a CU leave the barrier together and all
+        // read their fragments at once (20 b128 reads x 8 waves = 1280 cycles of LDS), so the matrix cores used to idle behind the first
+        // reads of every trip.  Two things shorten that: the fragments are read in the order the products need them -- a2, w2, a1, w3,
+        // then a3, w1 -- and the LAST product of a tile (a3 x w1) is held back and issued after the barrier, under the reads of the next
+        // tile: it needs no LDS data, and its registers are the last ones the new tile overwrites.  (+2.5..4 % on the reference net's
+        // levels, profiles/r04_sa_held_group.txt.)
+        auto trip = [&](int t, auto FIRST, auto LAST) {
+            const int buf = t & 1;
+            f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+            if constexpr (!LAST()) {
+                dma(t + 1, buf ^ 1);          // FB / FA[buf ^ 1] were last read in trip t-1: every wave is past the barrier that ended it
+                const float *cs = cst + ql * C1p + (t + 1) * kMlpKT + ah * 8;   // the producer's per-query constants first: its
+                c0 = *(const f32x4 *)cs;                                         // arithmetic can start under the first MFMAs
+                c1 = *(const f32x4 *)(cs + 4);
+            }
+            // the fragment reads stand IN FRONT of the producer's LDS stores: hipcc keeps an LDS read behind an earlier LDS write it
+            // cannot tell apart, which would chain  split -> ds_write -> ds_read -> MFMA  and serialise the trip
+            ra(buf, 1);
+            rw(buf, 1);
+            ra(buf, 0);
+            rw(buf, 2);
+            if constexpr (!FIRST()) product(I2{}, I0{});   // of tile t-1
+            ra(buf, 2);
+            rw(buf, 0);
+            if constexpr (!LAST()) {                   // tile t+1 of the activations, from the registers fetch(t+1) filled one trip ago
+                float h[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    h[i] = fmaxf(ra0[i] + c0[i], 0.0f);
+                    h[4 + i] = fmaxf(ra1[i] + c1[i], 0.0f);
+                }
+                bf16x8 p1, p2, p3;
+                split3(h, p1, p2, p3);
+                unsigned char *sa = FA + (buf ^ 1) * kATile + split_chunk(ar, ah);
+                *(bf16x8 *)sa = p1;
+                *(bf16x8 *)(sa + kAPlane) = p2;
+                *(bf16x8 *)(sa + 2 * kAPlane) = p3;
+                fetch(t + 2 < last ? t + 2 : last);   // in flight under the MFMAs (the last trip re-reads tile T-1: unused)
+            }
+            product(I1{}, I1{});
+            product(I0{}, I1{});
+            product(I0{}, I2{});
+            product(I1{}, I0{});
+            product(I0{}, I0{});
+            if constexpr (!LAST()) {
+                // the waves of a SIMD run in phase (SQ counters in profiles/), so the producer's work has to hide under this wave's OWN
+                // matrix instructions: a 32x32x16 bf16 MFMA holds the pipe for 32 cycles, room for ~4 other instructions.  The hints are
+                // best effort (the greedy solver drops what it cannot place); this set measured best of six (same file).
+                if constexpr (!FIRST()) __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);   // the held product first
+#pragma unroll
+                for (int m = 0; m < 10 * TN; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, TN == 2 ? 3 : 2, 0);   // VALU
+                }
+                __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);                     // DS writes of the staged tile
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                __syncthreads();
+            }
+        };
+        if (last == 0) {
+            trip(0, std::true_type{}, std::true_type{});
+        } else {
+            trip(0, std::true_type{}, std::false_type{});
+            for (int t = 1; t < last; ++t) trip(t, std::false_type{}, std::false_type{});
+            trip(last, std::false_type{}, std::true_type{});
+        }
+        product(I2{}, I0{});
     }
-    load_frags(last & 1);
-    mma();
 
     // ---- max over the rows of a query.  Accumulator register r of lane l is row (r & 3) + 8 (r >> 2) + 4 hi, column lo of its tile.
     float cm[2][TN];
