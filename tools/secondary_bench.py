@@ -32,6 +32,17 @@ from toothgroupnetwork_amd import _lib, hotpath, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
 MFMA_FP32_PEAK = 157.3      # TFLOP/s, v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK = 2500.0     # TFLOP/s dense, v_mfma_f32_32x32x16_bf16 (same guide)
+
+
+def _sa_peak():
+    """(peak, what it is) for the fused set-abstraction second layer: an fp32 product is SIX bf16 MFMA products in the default
+    bf16x3 form, so the ceiling in fp32-equivalent flops is the bf16 peak / 6; the exact-fp32 form is priced against
+    the fp32 MFMA peak."""
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    if U.SA_BF16X3:
+        return MFMA_BF16_PEAK / 6.0, "fp32-equivalent flops; peak = bf16 dense MFMA peak / 6 (bf16x3: six bf16 products per fp32 product)"
+    return MFMA_FP32_PEAK, "exact fp32 MFMA (TGN_SA_BF16X3=0)"
 
 
 def _roof(bound, achieved, peak, unit, **more):
@@ -87,8 +98,9 @@ def hot_path(make_inputs, device, shape_name, fused, B=256, steps=6, warmup=2):
     if fused:
         fl = fused_flops(shape)
         tf = fl * value / 1e12
-        out["roofline"] = _roof("mfma", tf, MFMA_FP32_PEAK, "TFLOP/s", flops_per_scan=fl,
-                                note="whole step (FPS and ball queries hide under the set-abstraction kernels); fp32 MFMA = exact fp32")
+        peak, what = _sa_peak()
+        out["roofline"] = _roof("mfma", tf, peak, "TFLOP/s", flops_per_scan=fl, fp32_mfma_peak=MFMA_FP32_PEAK,
+                                note="whole step (FPS and ball queries hide under the set-abstraction kernels); " + what)
     else:
         out["roofline"] = _roof("hbm", nbytes * value / 1e9, HBM_PEAK_GBS, "GB/s", algorithmic_bytes_per_scan=nbytes,
                                 note="whole path; the grouping stores are the bulk")
@@ -193,9 +205,9 @@ def pnpp_forward(device, B=8):
     fl = fused_flops(hotpath.SHAPE_B)
     return dict(value=B * 1e3 / ms, unit="scans/s", ms=ms, **graph_ms,
                 config=f"nets.PointNetPPSeg (pointnet_pp.py get_model, scale 4) forward, {B} x 24 000-point scans, eval, eager (graph_ms: one HIP graph)",
-                roofline=_roof("mfma", fl * B / ms / 1e9, MFMA_FP32_PEAK, "TFLOP/s",
-                               note="set-abstraction flops only (fp32-equivalent; second layers run as bf16x3 MFMAs) over the WHOLE forward time, "
-                                    "which also holds sampling, ball queries, three feature-propagation levels and the heads"))
+                roofline=_roof("mfma", fl * B / ms / 1e9, _sa_peak()[0], "TFLOP/s", fp32_mfma_peak=MFMA_FP32_PEAK,
+                               note="set-abstraction flops only over the WHOLE forward time, which also holds sampling, ball queries, three "
+                                    "feature-propagation levels and the heads; " + _sa_peak()[1]))
 
 
 def train_step(device, steps=6):
