@@ -107,7 +107,8 @@ def _bn_np(bn):
 MLP2_SHAPES = [(6000, 1024, 32, 6, 128, 128), (6000, 1024, 64, 6, 128, 128), (1024, 512, 32, 256, 256, 512),
                (1024, 512, 64, 256, 256, 512), (512, 256, 32, 1024, 784, 1024), (512, 256, 64, 1024, 784, 1024),
                (3000, 1024, 32, 36, 32, 32), (512, 256, 64, 256, 196, 256), (700, 50, 7, 13, 20, 36), (640, 33, 36, 200, 72, 100),
-               (300, 1, 48, 0, 16, 4), (900, 77, 17, 61, 100, 260)]
+               (300, 1, 48, 0, 16, 4), (900, 77, 17, 61, 100, 260),
+               (400, 20, 32, 40, 16, 48)]   # commuted form with ONE K tile (C1 = 16): the K loop's first trip is also its last
 
 
 @pytest.mark.parametrize("N,S,K,D,C1,C2", MLP2_SHAPES)
