@@ -30,7 +30,7 @@ if REPO not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from toothgroupnetwork_amd import hotpath, sharding, synth  # noqa: E402
+from toothgroupnetwork_amd import hotpath, launch, sharding, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured-achievable
 
@@ -86,7 +86,37 @@ def _secondary():
     return mod
 
 
-def main():
+def run_secondary(timeout_s):
+    """tools/secondary_bench.py as a child process writing its dict to a file; {"error": ...} when it fails or overruns"""
+    import subprocess
+    import tempfile
+    fd, path = tempfile.mkstemp(suffix=".json", prefix="tgn_secondary_")
+    os.close(fd)
+    try:
+        r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "secondary_bench.py"), "--json-out", path],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+        try:
+            res = json.load(open(path))
+        except Exception:
+            res = {}
+        if r.returncode != 0:
+            res["error"] = f"secondary_bench.py exited with status {r.returncode}: {r.stderr[-400:]}"
+        return res
+    except subprocess.TimeoutExpired:
+        try:
+            res = json.load(open(path))      # (the child rewrites the file after every entry: keep what it finished)
+        except Exception:
+            res = {}
+        res["error"] = f"secondary_bench.py did not finish within {timeout_s:.0f} s"
+        return res
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -110,15 +140,18 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the extra with_fps_prefix_identity measurement (profiling runs)")
     ap.add_argument("--secondary", type=int, default=1, help="1 (default, N = 1 only): after the headline, also measure the non-headline "
                     "configurations of BASELINE.json (Shape B, the fused levels, kNN, large-cloud FPS, Point-Transformer forward, training "
-                    "step) and attach them as `secondary` (tools/secondary_bench.py; ~1 minute); 0: skip")
-    args = ap.parse_args()
+                    "step), in a child process, and attach them as `secondary` (tools/secondary_bench.py; ~1-2 minutes); 0: skip")
+    ap.add_argument("--secondary-timeout", type=float, default=420.0, help="seconds the secondary child process may take")
+    args = ap.parse_args(argv)
 
+    if argv is None:
+        # `python bench.py --gpus N` (no torchrun): this process replaces itself by N ranks of the same command line
+        launch.ensure_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:], backend=args.backend)
     rank, local_rank, world, device = sharding.init_from_env(backend=args.backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU implementation")
-    if world != max(args.gpus, 1):
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    launch.require_world(args.gpus, world)          # a rank count other than --gpus is an error (exit status 2), never a warning
+    who = launch.describe_ranks(device)             # per-rank device records + backend + RCCL version (set-up time, untimed)
     B = args.batch
     shape = hotpath.SHAPE_A if args.shape == "A" else hotpath.SHAPE_B
     xyz, feats, scans = make_inputs(B, device, seed=100 + rank, shape=shape)
@@ -150,6 +183,8 @@ def main():
         "value": value,
         "unit": "meshes/s",
         "n_gpus": world,
+        "ranks": who["ranks"], "backend": who["backend"], "rccl_version": who["rccl_version"],
+        "distinct_devices": who["distinct_devices"], "self_spawned": who["self_spawned"],
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
@@ -285,9 +320,12 @@ def main():
         except Exception:
             pass
     if rank == 0 and world == 1 and args.secondary and args.shape == "A" and not args.fused and not args.fps_prefix:
+        # in a process of its own, under a time limit: a fault or a hang in a non-headline configuration (graph-captured training
+        # step, the matrix-core kernels) must not take the headline line with it
+        hp = xyz = feats = None
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
-        out["secondary"] = _secondary().measure_all(make_inputs, device)
+        out["secondary"] = run_secondary(args.secondary_timeout)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

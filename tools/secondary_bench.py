@@ -228,7 +228,8 @@ def train_step(device, steps=6):
                                note="batch 1: ~2000 small kernels; bf16 autocast measured no faster at this size (DESIGN.md 4.6)"))
 
 
-def measure_all(make_inputs, device, budget_s=150.0):
+def measure_all(make_inputs, device, budget_s=150.0, checkpoint=None):
+    """checkpoint(out): called after every entry (bench.py's child process rewrites its result file there)"""
     t0 = time.perf_counter()
     out = {}
     plan = [("shape_B_materialised", lambda: hot_path(make_inputs, device, "B", False, steps=10, warmup=3)),
@@ -249,6 +250,8 @@ def measure_all(make_inputs, device, budget_s=150.0):
         except Exception as e:  # noqa: BLE001
             out[name] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         out[name]["wall_s"] = round(time.perf_counter() - t1, 2)
+        if checkpoint is not None:
+            checkpoint(out)
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
     out["total_wall_s"] = round(time.perf_counter() - t0, 2)
@@ -259,4 +262,16 @@ if __name__ == "__main__":
     spec = importlib.util.spec_from_file_location("bench", os.path.join(REPO, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    print(json.dumps(measure_all(bench.make_inputs, torch.device("cuda", 0)), indent=1))
+    json_out = sys.argv[sys.argv.index("--json-out") + 1] if "--json-out" in sys.argv else None
+
+    def _save(res):
+        tmp = json_out + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump(res, f)
+        os.replace(tmp, json_out)
+
+    result = measure_all(bench.make_inputs, torch.device("cuda", 0), checkpoint=_save if json_out else None)
+    if json_out:
+        _save(result)
+    else:
+        print(json.dumps(result, indent=1))
