@@ -683,6 +683,181 @@ def test_gather_family_vs_reference_kernels_on_this_gpu(dev):
     torch.testing.assert_close(g3, ref_gpu.interpolation_backward(go2, ik, wk, n), rtol=1e-5, atol=1e-5)
 
 
+def test_all_ten_verbatim_launchers_on_a_side_stream(dev, oracle):
+    """pointops_api.cpp:12-23, all ten names, through `pointops_cuda` (= the ten reference-signature `*_cuda_launcher` symbols of
+    include/tgn_pointops.h section 1) on a NON-default torch stream: the inputs are produced on that stream behind a long sleep and
+    nothing is synchronised before the call, so a launcher that did not pick the stream up from `tgn_set_default_stream` (or
+    forwarded an argument to the wrong slot) reads zeros / writes the wrong buffer.  Checked against the reference's own kernels
+    (oracle/_ref) where built, and always against the stream forms (`tgn_*`)."""
+    import pointops_cuda as PC
+    from oracle import ref_gpu
+    from toothgroupnetwork_amd import _lib
+    L, p = _lib.lib(), _lib.ptr
+    have_ref = ref_gpu.available()
+    n, ns, c, wc, k = 700, 9, 24, 6, 3
+    g = torch.Generator().manual_seed(29)
+    host = dict(x=torch.randn(n, c, generator=g), y=torch.randn(n, c, generator=g), pos=torch.randn(n, ns, c, generator=g),
+                w=torch.randn(n, ns, wc, generator=g), go3=torch.randn(n, ns, c, generator=g), go2=torch.randn(n, c, generator=g),
+                wk=torch.rand(n, k, generator=g), xyz=torch.from_numpy(synth.uniform_cloud(n, 4)))
+    idx_h = torch.randint(0, n, (n, ns), generator=g, dtype=torch.int32)
+    real = {k_: v.to(dev) for k_, v in host.items()}
+    idx_real = idx_h.to(dev)
+    off = torch.tensor([n], dtype=torch.int32, device=dev)
+    noff = torch.tensor([64], dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    seen = []
+
+    def staged(fn):
+        """run fn(inputs) on the side stream with the inputs filled in BEHIND a sleep on that stream"""
+        t = {k_: torch.zeros_like(v) for k_, v in real.items()}
+        idx = torch.zeros_like(idx_real)
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(40_000_000)
+            for k_ in t:
+                t[k_].copy_(real[k_], non_blocking=True)
+            idx.copy_(idx_real, non_blocking=True)
+            out = fn(t, idx)
+        side.synchronize()
+        return out
+
+    def z(*shape, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype, device=dev)
+
+    def via_stream_form(name, *args):
+        _lib.check(getattr(L, name)(*args, _lib.stream()), name)
+        torch.cuda.synchronize()
+
+    # 1. furthestsampling_cuda ------------------------------------------------------------------------------------------
+    def fps(t, idx):
+        out, tmp = z(64, dtype=torch.int32), torch.full((n,), 1e10, device=dev)
+        PC.furthestsampling_cuda(1, n, t["xyz"], off, noff, tmp, out)
+        return out
+    got = staged(fps)
+    seen.append("furthestsampling_cuda")
+    assert np.array_equal(got.cpu().numpy(), oracle.furthestsampling(host["xyz"].numpy(), [n], [64]))
+    # 2. knnquery_cuda --------------------------------------------------------------------------------------------------
+    def knn(t, idx):
+        ki, kd = z(n, 5, dtype=torch.int32), z(n, 5)
+        PC.knnquery_cuda(n, 5, t["xyz"], t["xyz"], off, off, ki, kd)
+        return ki, kd
+    ki, kd = staged(knn)
+    seen.append("knnquery_cuda")
+    oi, od = oracle.knnquery(5, host["xyz"].numpy(), host["xyz"].numpy(), [n], [n])
+    assert np.array_equal(ki.cpu().numpy(), oi) and np.array_equal(torch.sqrt(kd).cpu().numpy(), od)
+    if have_ref:
+        ri, rd = ref_gpu.knnquery(5, real["xyz"], real["xyz"], off, off)
+        assert torch.equal(ki, ri) and torch.equal(kd, rd)
+    # 3./4. grouping ----------------------------------------------------------------------------------------------------
+    def grp_f(t, idx):
+        out = z(n, ns, c)
+        PC.grouping_forward_cuda(n, ns, c, t["x"], idx, out)
+        return out
+    got = staged(grp_f)
+    seen.append("grouping_forward_cuda")
+    want = z(n, ns, c)
+    via_stream_form("tgn_grouping_forward", n, ns, c, p(real["x"]), p(idx_real), p(want))
+    assert torch.equal(got, want) and torch.equal(got, real["x"][idx_real.long()])
+    if have_ref:
+        assert torch.equal(got, ref_gpu.grouping_forward(real["x"], idx_real))
+
+    def grp_b(t, idx):
+        gi = z(n, c)
+        PC.grouping_backward_cuda(n, ns, c, t["go3"], idx, gi)
+        return gi
+    got = staged(grp_b)
+    seen.append("grouping_backward_cuda")
+    want = z(n, c)
+    via_stream_form("tgn_grouping_backward", n, ns, c, p(real["go3"]), p(idx_real), p(want))
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    if have_ref:
+        torch.testing.assert_close(got, ref_gpu.grouping_backward(real["go3"], idx_real, n), rtol=1e-5, atol=1e-5)
+    # 5./6. interpolation -----------------------------------------------------------------------------------------------
+    ik_real = idx_real[:, :k].contiguous()
+
+    def itp_f(t, idx):
+        out = z(n, c)
+        PC.interpolation_forward_cuda(n, c, k, t["x"], idx[:, :k].contiguous(), t["wk"], out)
+        return out
+    got = staged(itp_f)
+    seen.append("interpolation_forward_cuda")
+    want = z(n, c)
+    via_stream_form("tgn_interpolation_forward", n, c, k, p(real["x"]), p(ik_real), p(real["wk"]), p(want))
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+    if have_ref:
+        torch.testing.assert_close(got, ref_gpu.interpolation_forward(real["x"], ik_real, real["wk"]), rtol=1e-5, atol=1e-5)
+
+    def itp_b(t, idx):
+        gi = z(n, c)
+        PC.interpolation_backward_cuda(n, c, k, t["go2"], idx[:, :k].contiguous(), t["wk"], gi)
+        return gi
+    got = staged(itp_b)
+    seen.append("interpolation_backward_cuda")
+    want = z(n, c)
+    via_stream_form("tgn_interpolation_backward", n, c, k, p(real["go2"]), p(ik_real), p(real["wk"]), p(want))
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    if have_ref:
+        torch.testing.assert_close(got, ref_gpu.interpolation_backward(real["go2"], ik_real, real["wk"], n), rtol=1e-5, atol=1e-5)
+    # 7./8. subtraction -------------------------------------------------------------------------------------------------
+    def sub_f(t, idx):
+        out = z(n, ns, c)
+        PC.subtraction_forward_cuda(n, ns, c, t["x"], t["y"], idx, out)
+        return out
+    got = staged(sub_f)
+    seen.append("subtraction_forward_cuda")
+    assert torch.equal(got, real["x"][:, None, :] - real["y"][idx_real.long()])
+    if have_ref:
+        assert torch.equal(got, ref_gpu.subtraction_forward(real["x"], real["y"], idx_real))
+
+    def sub_b(t, idx):
+        g1, g2 = z(n, c), z(n, c)
+        PC.subtraction_backward_cuda(n, ns, c, idx, t["go3"], g1, g2)
+        return g1, g2
+    g1, g2 = staged(sub_b)
+    seen.append("subtraction_backward_cuda")
+    w1, w2 = z(n, c), z(n, c)
+    via_stream_form("tgn_subtraction_backward", n, ns, c, p(idx_real), p(real["go3"]), p(w1), p(w2))
+    torch.testing.assert_close(g1, w1, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(g2, w2, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(g1, real["go3"].sum(1), rtol=1e-5, atol=1e-5)
+    if have_ref:
+        r1, r2 = ref_gpu.subtraction_backward(idx_real, real["go3"])
+        torch.testing.assert_close(g1, r1, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(g2, r2, rtol=1e-5, atol=1e-5)
+    # 9./10. aggregation ------------------------------------------------------------------------------------------------
+    def agg_f(t, idx):
+        out = z(n, c)
+        PC.aggregation_forward_cuda(n, ns, c, wc, t["x"], t["pos"], t["w"], idx, out)
+        return out
+    got = staged(agg_f)
+    seen.append("aggregation_forward_cuda")
+    want = z(n, c)
+    via_stream_form("tgn_aggregation_forward", n, ns, c, wc, p(real["x"]), p(real["pos"]), p(real["w"]), p(idx_real), p(want))
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+    if have_ref:
+        torch.testing.assert_close(got, ref_gpu.aggregation_forward(real["x"], real["pos"], real["w"], idx_real), rtol=1e-5, atol=1e-5)
+
+    def agg_b(t, idx):
+        a, b_, c_ = z(n, c), z(n, ns, c), z(n, ns, wc)
+        PC.aggregation_backward_cuda(n, ns, c, wc, t["x"], t["pos"], t["w"], idx, t["go2"], a, b_, c_)
+        return a, b_, c_
+    a, b_, c_ = staged(agg_b)
+    seen.append("aggregation_backward_cuda")
+    wa, wb, wcg = z(n, c), z(n, ns, c), z(n, ns, wc)
+    via_stream_form("tgn_aggregation_backward", n, ns, c, wc, p(real["x"]), p(real["pos"]), p(real["w"]), p(idx_real), p(real["go2"]),
+                    p(wa), p(wb), p(wcg))
+    torch.testing.assert_close(a, wa, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(b_, wb, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(c_, wcg, rtol=1e-4, atol=1e-4)
+    if have_ref:
+        ra, rb, rc = ref_gpu.aggregation_backward(real["x"], real["pos"], real["w"], idx_real, real["go2"])
+        torch.testing.assert_close(a, ra, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(b_, rb, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(c_, rc, rtol=1e-4, atol=1e-4)
+    # every name of pointops_api.cpp:13-22 went through the shim
+    assert sorted(seen) == sorted(n_ for n_ in dir(PC) if n_.endswith("_cuda")) and len(seen) == 10
+
+
 def test_pointops_cuda_shim_runs_reference_style_code(dev, oracle):
     """The legacy native-module API (pointops_api.cpp:13-22): caller-allocated, pre-initialised buffers."""
     import pointops_cuda

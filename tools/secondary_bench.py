@@ -8,6 +8,7 @@ An entry that fails reports {"error": ...} and never takes the headline down.
 
   shape_B_materialised   config 2's operators at the widths the reference net instantiates (pointnet_pp.py:13-15), grouped tensors written
   fused_shape_A / _B     the same levels with the shared MLP fused in; _B is the reference net's own SA stack
+  gather_family          grouping / subtraction / aggregation / interpolation forward + backward (pointops_api.cpp:12-23) at config 4's first stage
   knn_24000_k36          pointops.knnquery at config 4's first stage (blocks.py:34)
   fps_100k_to_24k        preprocess_data.py:55-56 / gen_utils.py:124-140, one scan and 64 scans per launch (config 5's kernel)
   pnpp_forward_8x24000   config 2's whole network (pointnet_pp.py get_model) on 8 scans, eval
@@ -228,13 +229,71 @@ def train_step(device, steps=6):
                                note="batch 1: ~2000 small kernels; bf16 autocast measured no faster at this size (DESIGN.md 4.6)"))
 
 
-def measure_all(make_inputs, device, budget_s=150.0, checkpoint=None):
+def gather_family(device, n=24000, ns=36, c=32, wc=4, k=3, m_coarse=6000, batch_launches=10):
+    """The gather / scatter operators of pointops_api.cpp:12-23 at the first Point-Transformer stage (n = 24 000 points, nsample = 36,
+    c = 32, w_c = c / 8 = 4; interpolation: dec1's 6000 -> 24 000, k = 3), each priced against HBM: algorithmic bytes = every distinct
+    operand byte once (an accumulated output counts read + write) / the launch time (HIP events around `batch_launches` back-to-back
+    launches).  Neighbour lists are a real kNN of an arch scan, so the gathers have the locality the network sees."""
+    from toothgroupnetwork_amd import pointops as P
+    L, p = _lib.lib(), _lib.ptr
+    xyz = torch.from_numpy(synth.arch_cloud(n, 1, False)).to(device)
+    off = torch.tensor([n], dtype=torch.int32, device=device)
+    P.knn_cache_clear()
+    idx, _ = P.knnquery(ns, xyz, xyz, off, off)
+    idx = idx.contiguous()
+    coarse = xyz[torch.randperm(n, device=device)[:m_coarse]].contiguous()
+    coff = torch.tensor([m_coarse], dtype=torch.int32, device=device)
+    ik, dk = P.knnquery(k, coarse, xyz, coff, off)
+    ik = ik.contiguous()
+    wk = (1.0 / (dk + 1e-8))
+    wk = (wk / wk.sum(1, keepdim=True)).contiguous()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    R = lambda *sh: torch.randn(*sh, generator=g).to(device)   # noqa: E731
+    x, y, pos, w = R(n, c), R(n, c), R(n, ns, c), R(n, ns, wc)
+    go3, go2, xc = R(n, ns, c), R(n, c), R(m_coarse, c)
+    out3, o2 = torch.empty(n, ns, c, device=device), torch.zeros(n, c, device=device)
+    gi, g1, g2 = torch.zeros(n, c, device=device), torch.zeros(n, c, device=device), torch.zeros(n, c, device=device)
+    ga, gp, gw = torch.zeros(n, c, device=device), torch.zeros(n, ns, c, device=device), torch.zeros(n, ns, wc, device=device)
+    gc = torch.zeros(m_coarse, c, device=device)
+    st = _lib.stream
+    F = 4
+    rows = n * ns
+    ops = {
+        "grouping_fwd": (lambda: L.tgn_grouping_forward(n, ns, c, p(x), p(idx), p(out3), st()), F * (n * c + rows + rows * c)),
+        "grouping_bwd": (lambda: L.tgn_grouping_backward(n, ns, c, p(go3), p(idx), p(gi), st()), F * (rows * c + rows + 2 * n * c)),
+        "subtraction_fwd": (lambda: L.tgn_subtraction_forward(n, ns, c, p(x), p(y), p(idx), p(out3), st()), F * (2 * n * c + rows + rows * c)),
+        "subtraction_bwd": (lambda: L.tgn_subtraction_backward(n, ns, c, p(idx), p(go3), p(g1), p(g2), st()), F * (rows + rows * c + 4 * n * c)),
+        "aggregation_fwd": (lambda: L.tgn_aggregation_forward(n, ns, c, wc, p(x), p(pos), p(w), p(idx), p(o2), st()),
+                            F * (n * c + rows * c + rows * wc + rows + 2 * n * c)),
+        "aggregation_bwd": (lambda: L.tgn_aggregation_backward(n, ns, c, wc, p(x), p(pos), p(w), p(idx), p(go2), p(ga), p(gp), p(gw), st()),
+                            F * (n * c + rows * c + rows * wc + rows + n * c + 2 * n * c + rows * c + 2 * rows * wc)),
+        "interpolation_fwd": (lambda: L.tgn_interpolation_forward(n, c, k, p(xc), p(ik), p(wk), p(o2), st()),
+                              F * (m_coarse * c + 2 * n * k + 2 * n * c)),
+        "interpolation_bwd": (lambda: L.tgn_interpolation_backward(n, c, k, p(go2), p(ik), p(wk), p(gc), st()),
+                              F * (n * c + 2 * n * k + 2 * m_coarse * c)),
+    }
+    out = dict(config=f"tgn_* gather family at n = {n}, nsample = {ns}, c = {c}, w_c = {wc} (interpolation: {m_coarse} -> {n}, k = {k}); one launch each, "
+                      f"timed over {batch_launches} back-to-back launches")
+    for name, (fn, nbytes) in ops.items():
+        def batch():
+            for _ in range(batch_launches):
+                _lib.check(fn(), name)
+        ms = _events(batch, 7, 2) / batch_launches
+        out[name] = dict(us=1e3 * ms, algorithmic_bytes=nbytes,
+                         roofline=_roof("hbm", nbytes / ms / 1e6, HBM_PEAK_GBS, "GB/s"))
+    out["interpolation_fwd"]["note"] = out["interpolation_bwd"]["note"] = \
+        "a few MB per launch: ~1 us of HBM time, so the launch itself is the floor at this size"
+    return out
+
+
+def measure_all(make_inputs, device, budget_s=240.0, checkpoint=None):
     """checkpoint(out): called after every entry (bench.py's child process rewrites its result file there)"""
     t0 = time.perf_counter()
     out = {}
     plan = [("shape_B_materialised", lambda: hot_path(make_inputs, device, "B", False, steps=10, warmup=3)),
             ("fused_shape_A", lambda: hot_path(make_inputs, device, "A", True, steps=10, warmup=3)),
             ("fused_shape_B", lambda: hot_path(make_inputs, device, "B", True, steps=8, warmup=3)),
+            ("gather_family", lambda: gather_family(device)),
             ("knn_24000_k36", lambda: knn(device)),
             ("fps_100k_to_24k", lambda: fps_large(device)),
             ("pnpp_forward_8x24000", lambda: pnpp_forward(device)),

@@ -169,6 +169,209 @@ __global__ __launch_bounds__(256) void aggregation_bwd_kernel(long long rows, in
     }
 }
 
+// ---- the same eight kernels with 16-byte lanes --------------------------------------------------------
+// Taken when c % 4 == 0 and every row base is 16-byte aligned (the shapes of the Point-Transformer stages: c = 32 ... 512,
+// w_c = c / 8).  A lane owns FOUR consecutive channels (global_load/store_dwordx4), a group of cx = 2^cx_log2 lanes owns a row.
+//   * forward gathers (grouping, subtraction) walk the OUTPUT rows, four rows per lane in flight;
+//   * the reductions walk the POINTS: a lane group keeps the sum over a point's nsample neighbours (aggregation forward, in the
+//     reference's j order: bit-identical) or over its rows (subtraction backward: grad_input1 is ONE read-modify-write per point
+//     instead of nsample atomics; aggregation backward: grad_weight is summed over the c / w_c channels that share a weight
+//     across the lanes and added once) -- every such element has exactly one owner, so no atomics; what the caller pre-filled is
+//     still accumulated into, like the reference's atomicAdd onto a zeroed buffer;
+//   * the scatters (grad of a gathered operand) stay hardware fp32 atomics: their targets are data dependent.
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct Vec4Shape {
+    int cx_log2;
+    int groups_per_block;
+    unsigned blocks;
+};
+
+static Vec4Shape vec4_shape(long long units, int c, int units_per_group_pass) {
+    const int c4 = c >> 2;
+    int l = 0;
+    while ((1 << l) < c4 && l < 6) ++l;
+    Vec4Shape s;
+    s.cx_log2 = l;
+    s.groups_per_block = 256 >> l;
+    const long long per_block = (long long)s.groups_per_block * units_per_group_pass;
+    long long blocks = (units + per_block - 1) / per_block;
+    const long long cap = 256LL * 64;
+    s.blocks = (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+    return s;
+}
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define TGN_V4_LANES                        \
+    const int cx = 1 << cx_log2;            \
+    const int tx = threadIdx.x & (cx - 1);  \
+    const int ty = threadIdx.x >> cx_log2;  \
+    const int ry = blockDim.x >> cx_log2;
+
+__device__ __forceinline__ void atomic_add4(float *dst, f4 v) {
+    atomicAdd(dst + 0, v.x);
+    atomicAdd(dst + 1, v.y);
+    atomicAdd(dst + 2, v.z);
+    atomicAdd(dst + 3, v.w);
+}
+
+constexpr int kV4Rows = 4;  // output rows a lane keeps in flight
+
+template <bool SUB>
+__global__ __launch_bounds__(256) void gather_rows_v4_kernel(long long rows, int nsample, int c4, int cx_log2,
+                                                              const f4 *__restrict__ input1,
+                                                              const f4 *__restrict__ input2,
+                                                              const int *__restrict__ idx, f4 *__restrict__ output) {
+    // SUB = false: output[r] = input2[idx[r]]                    (grouping forward; input1 unused)
+    // SUB = true : output[r] = input1[r / nsample] - input2[idx[r]]   (subtraction forward)
+    TGN_V4_LANES
+    const long long step = (long long)gridDim.x * kV4Rows * ry;
+    for (long long r0 = (long long)blockIdx.x * kV4Rows * ry + ty; r0 < rows; r0 += step) {
+        int id[kV4Rows];
+        long long own[kV4Rows];
+#pragma unroll
+        for (int u = 0; u < kV4Rows; ++u) {
+            const long long r = r0 + (long long)u * ry;
+            id[u] = r < rows ? idx[r] : 0;
+            own[u] = SUB ? (r < rows ? r / nsample : 0) : 0;
+        }
+        for (int ci = tx; ci < c4; ci += cx) {
+            f4 v[kV4Rows], a[kV4Rows];
+#pragma unroll
+            for (int u = 0; u < kV4Rows; ++u) {
+                v[u] = input2[(size_t)id[u] * c4 + ci];
+                if (SUB) a[u] = input1[(size_t)own[u] * c4 + ci];
+            }
+#pragma unroll
+            for (int u = 0; u < kV4Rows; ++u) {
+                const long long r = r0 + (long long)u * ry;
+                if (r < rows) output[(size_t)r * c4 + ci] = SUB ? a[u] - v[u] : v[u];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void grouping_bwd_v4_kernel(long long rows, int c4, int cx_log2,
+                                                               const f4 *__restrict__ grad_output,
+                                                               const int *__restrict__ idx, float *__restrict__ grad_input) {
+    TGN_V4_LANES
+    for (long long r = (long long)blockIdx.x * ry + ty; r < rows; r += (long long)gridDim.x * ry) {
+        float *dst = grad_input + (size_t)idx[r] * c4 * 4;
+        for (int ci = tx; ci < c4; ci += cx) atomic_add4(dst + ci * 4, grad_output[(size_t)r * c4 + ci]);
+    }
+}
+
+__global__ __launch_bounds__(256) void interpolation_fwd_v4_kernel(long long rows, int c4, int k, int cx_log2,
+                                                                    const f4 *__restrict__ input,
+                                                                    const int *__restrict__ idx,
+                                                                    const float *__restrict__ weight,
+                                                                    f4 *__restrict__ output) {
+    TGN_V4_LANES
+    for (long long r = (long long)blockIdx.x * ry + ty; r < rows; r += (long long)gridDim.x * ry) {
+        for (int ci = tx; ci < c4; ci += cx) {
+            f4 acc = output[(size_t)r * c4 + ci];  // the reference accumulates into the (pre-zeroed) output
+            for (int i = 0; i < k; ++i) acc = acc + input[(size_t)idx[r * k + i] * c4 + ci] * weight[r * k + i];
+            output[(size_t)r * c4 + ci] = acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void interpolation_bwd_v4_kernel(long long rows, int c4, int k, int cx_log2,
+                                                                    const f4 *__restrict__ grad_output,
+                                                                    const int *__restrict__ idx,
+                                                                    const float *__restrict__ weight,
+                                                                    float *__restrict__ grad_input) {
+    TGN_V4_LANES
+    for (long long r = (long long)blockIdx.x * ry + ty; r < rows; r += (long long)gridDim.x * ry) {
+        for (int ci = tx; ci < c4; ci += cx) {
+            const f4 g = grad_output[(size_t)r * c4 + ci];
+            for (int i = 0; i < k; ++i)
+                atomic_add4(grad_input + ((size_t)idx[r * k + i] * c4 + ci) * 4, g * weight[r * k + i]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void subtraction_bwd_v4_kernel(long long n, int nsample, int c4, int cx_log2,
+                                                                  const int *__restrict__ idx,
+                                                                  const f4 *__restrict__ grad_output,
+                                                                  f4 *__restrict__ grad_input1,
+                                                                  float *__restrict__ grad_input2) {
+    TGN_V4_LANES
+    for (long long p = (long long)blockIdx.x * ry + ty; p < n; p += (long long)gridDim.x * ry) {
+        const int *__restrict__ ip = idx + p * nsample;
+        for (int ci = tx; ci < c4; ci += cx) {
+            const f4 *__restrict__ src = grad_output + (size_t)p * nsample * c4 + ci;
+            f4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+            for (int j = 0; j < nsample; ++j) {
+                const f4 g = src[(size_t)j * c4];
+                s = s + g;
+                atomic_add4(grad_input2 + ((size_t)ip[j] * c4 + ci) * 4, -g);
+            }
+            grad_input1[(size_t)p * c4 + ci] = grad_input1[(size_t)p * c4 + ci] + s;  // the point's only owner: no atomic
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void aggregation_fwd_v4_kernel(long long n, int nsample, int c4, int w4, int cx_log2,
+                                                                  const f4 *__restrict__ input,
+                                                                  const f4 *__restrict__ position,
+                                                                  const f4 *__restrict__ weight,
+                                                                  const int *__restrict__ idx, f4 *__restrict__ output) {
+    // w4 = w_c / 4: channel quad ci reads weight quad ci % w4 (channels 4ci..4ci+3 -> weights (4ci % w_c)..+3)
+    TGN_V4_LANES
+    for (long long p = (long long)blockIdx.x * ry + ty; p < n; p += (long long)gridDim.x * ry) {
+        const int *__restrict__ ip = idx + p * nsample;
+        for (int ci = tx; ci < c4; ci += cx) {
+            const f4 *__restrict__ pp = position + (size_t)p * nsample * c4 + ci;
+            const f4 *__restrict__ wp = weight + (size_t)p * nsample * w4 + (ci % w4);
+            f4 acc = output[(size_t)p * c4 + ci];
+#pragma unroll 4
+            for (int j = 0; j < nsample; ++j)   // the reference's order over j, (input + position) * weight unfused
+                acc = acc + (input[(size_t)ip[j] * c4 + ci] + pp[(size_t)j * c4]) * wp[(size_t)j * w4];
+            output[(size_t)p * c4 + ci] = acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void aggregation_bwd_v4_kernel(long long n, int nsample, int w4, int cx_log2,
+                                                                  const f4 *__restrict__ input,
+                                                                  const f4 *__restrict__ position,
+                                                                  const f4 *__restrict__ weight,
+                                                                  const int *__restrict__ idx,
+                                                                  const f4 *__restrict__ grad_output,
+                                                                  float *__restrict__ grad_input,
+                                                                  f4 *__restrict__ grad_position,
+                                                                  f4 *__restrict__ grad_weight) {
+    // one lane per channel quad (c4 == cx, a power of two <= 64; w4 a power of two dividing it): the lanes tx, tx + w4, tx + 2 w4 ...
+    // share weight quad tx % w4 -- their products are summed by xor-shuffles over the lane bits >= log2(w4)
+    TGN_V4_LANES
+    const int c4 = cx;
+    const int wq = tx & (w4 - 1);
+    for (long long p = (long long)blockIdx.x * ry + ty; p < n; p += (long long)gridDim.x * ry) {
+        const int *__restrict__ ip = idx + p * nsample;
+        const f4 go = grad_output[(size_t)p * c4 + tx];
+#pragma unroll 2
+        for (int j = 0; j < nsample; ++j) {
+            const size_t ii = (size_t)p * nsample + j;
+            const f4 w = weight[ii * w4 + wq];
+            const size_t in_i = (size_t)ip[j] * c4 + tx;
+            const f4 gw = go * w;
+            f4 t = go * (input[in_i] + position[ii * c4 + tx]);
+            atomic_add4(grad_input + in_i * 4, gw);
+            grad_position[ii * c4 + tx] = gw;
+            for (int m = w4; m < cx; m <<= 1) {
+                t.x += __shfl_xor(t.x, m, kWave);
+                t.y += __shfl_xor(t.y, m, kWave);
+                t.z += __shfl_xor(t.z, m, kWave);
+                t.w += __shfl_xor(t.w, m, kWave);
+            }
+            if (tx < w4) grad_weight[ii * w4 + tx] = grad_weight[ii * w4 + tx] + t;  // one owner per weight quad
+        }
+    }
+}
+
 // ---- pointnet2_utils composites (group_points lives in group.hip) ---------------------------------
 constexpr int kGroupMaxK = 128;
 
@@ -301,6 +504,12 @@ TGN_API int tgn_grouping_forward(int m, int nsample, int c, const float *input, 
                                  tgn_stream_t stream) {
     const long long rows = (long long)m * nsample;
     if (rows <= 0 || c <= 0) return TGN_OK;
+    if (c % 4 == 0 && aligned16(input) && aligned16(output)) {
+        const Vec4Shape v = vec4_shape(rows, c, kV4Rows);
+        hipLaunchKernelGGL(gather_rows_v4_kernel<false>, dim3(v.blocks), dim3(256), 0, (hipStream_t)stream, rows, nsample, c / 4,
+                           v.cx_log2, (const f4 *)nullptr, (const f4 *)input, idx, (f4 *)output);
+        return check_launch("grouping_fwd_v4_kernel");
+    }
     const RowShape s = row_shape(rows, c);
     hipLaunchKernelGGL(grouping_fwd_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, c, s.cx_log2, input,
                        idx, output);
@@ -311,6 +520,12 @@ TGN_API int tgn_grouping_backward(int m, int nsample, int c, const float *grad_o
                                   float *grad_input, tgn_stream_t stream) {
     const long long rows = (long long)m * nsample;
     if (rows <= 0 || c <= 0) return TGN_OK;
+    if (c % 4 == 0 && aligned16(grad_output)) {
+        const Vec4Shape v = vec4_shape(rows, c, 1);
+        hipLaunchKernelGGL(grouping_bwd_v4_kernel, dim3(v.blocks), dim3(256), 0, (hipStream_t)stream, rows, c / 4, v.cx_log2,
+                           (const f4 *)grad_output, idx, grad_input);
+        return check_launch("grouping_bwd_v4_kernel");
+    }
     const RowShape s = row_shape(rows, c);
     hipLaunchKernelGGL(grouping_bwd_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, c, s.cx_log2,
                        grad_output, idx, grad_input);
@@ -320,6 +535,12 @@ TGN_API int tgn_grouping_backward(int m, int nsample, int c, const float *grad_o
 TGN_API int tgn_interpolation_forward(int n, int c, int k, const float *input, const int *idx, const float *weight,
                                       float *output, tgn_stream_t stream) {
     if (n <= 0 || c <= 0) return TGN_OK;
+    if (c % 4 == 0 && aligned16(input) && aligned16(output)) {
+        const Vec4Shape v = vec4_shape(n, c, 1);
+        hipLaunchKernelGGL(interpolation_fwd_v4_kernel, dim3(v.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, c / 4, k,
+                           v.cx_log2, (const f4 *)input, idx, weight, (f4 *)output);
+        return check_launch("interpolation_fwd_v4_kernel");
+    }
     const RowShape s = row_shape(n, c);
     hipLaunchKernelGGL(interpolation_fwd_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, c, k,
                        s.cx_log2, input, idx, weight, output);
@@ -329,6 +550,12 @@ TGN_API int tgn_interpolation_forward(int n, int c, int k, const float *input, c
 TGN_API int tgn_interpolation_backward(int n, int c, int k, const float *grad_output, const int *idx,
                                        const float *weight, float *grad_input, tgn_stream_t stream) {
     if (n <= 0 || c <= 0) return TGN_OK;
+    if (c % 4 == 0 && aligned16(grad_output)) {
+        const Vec4Shape v = vec4_shape(n, c, 1);
+        hipLaunchKernelGGL(interpolation_bwd_v4_kernel, dim3(v.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, c / 4, k,
+                           v.cx_log2, (const f4 *)grad_output, idx, weight, grad_input);
+        return check_launch("interpolation_bwd_v4_kernel");
+    }
     const RowShape s = row_shape(n, c);
     hipLaunchKernelGGL(interpolation_bwd_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, c, k,
                        s.cx_log2, grad_output, idx, weight, grad_input);
@@ -339,6 +566,12 @@ TGN_API int tgn_subtraction_forward(int n, int nsample, int c, const float *inpu
                                     const int *idx, float *output, tgn_stream_t stream) {
     const long long rows = (long long)n * nsample;
     if (rows <= 0 || c <= 0) return TGN_OK;
+    if (c % 4 == 0 && aligned16(input1) && aligned16(input2) && aligned16(output)) {
+        const Vec4Shape v = vec4_shape(rows, c, kV4Rows);
+        hipLaunchKernelGGL(gather_rows_v4_kernel<true>, dim3(v.blocks), dim3(256), 0, (hipStream_t)stream, rows, nsample, c / 4,
+                           v.cx_log2, (const f4 *)input1, (const f4 *)input2, idx, (f4 *)output);
+        return check_launch("subtraction_fwd_v4_kernel");
+    }
     const RowShape s = row_shape(rows, c);
     hipLaunchKernelGGL(subtraction_fwd_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, nsample, c,
                        s.cx_log2, input1, input2, idx, output);
@@ -349,6 +582,12 @@ TGN_API int tgn_subtraction_backward(int n, int nsample, int c, const int *idx, 
                                      float *grad_input1, float *grad_input2, tgn_stream_t stream) {
     const long long rows = (long long)n * nsample;
     if (rows <= 0 || c <= 0) return TGN_OK;
+    if (c % 4 == 0 && aligned16(grad_output) && aligned16(grad_input1)) {
+        const Vec4Shape v = vec4_shape(n, c, 1);
+        hipLaunchKernelGGL(subtraction_bwd_v4_kernel, dim3(v.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, nsample,
+                           c / 4, v.cx_log2, idx, (const f4 *)grad_output, (f4 *)grad_input1, grad_input2);
+        return check_launch("subtraction_bwd_v4_kernel");
+    }
     const RowShape s = row_shape(rows, c);
     hipLaunchKernelGGL(subtraction_bwd_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, nsample, c,
                        s.cx_log2, idx, grad_output, grad_input1, grad_input2);
@@ -361,6 +600,13 @@ TGN_API int tgn_aggregation_forward(int n, int nsample, int c, int w_c, const fl
     if (w_c <= 0) {
         set_error("tgn_aggregation_forward: w_c must be positive");
         return TGN_ERR_INVALID_ARGUMENT;
+    }
+    if (c % 4 == 0 && w_c % 4 == 0 && aligned16(input) && aligned16(position) && aligned16(weight) && aligned16(output)) {
+        const Vec4Shape v = vec4_shape(n, c, 1);
+        hipLaunchKernelGGL(aggregation_fwd_v4_kernel, dim3(v.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, nsample,
+                           c / 4, w_c / 4, v.cx_log2, (const f4 *)input, (const f4 *)position, (const f4 *)weight, idx,
+                           (f4 *)output);
+        return check_launch("aggregation_fwd_v4_kernel");
     }
     const RowShape s = row_shape(n, c);
     hipLaunchKernelGGL(aggregation_fwd_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, nsample,
@@ -376,6 +622,18 @@ TGN_API int tgn_aggregation_backward(int n, int nsample, int c, int w_c, const f
     if (w_c <= 0) {
         set_error("tgn_aggregation_backward: w_c must be positive");
         return TGN_ERR_INVALID_ARGUMENT;
+    }
+    {
+        const int c4 = c / 4, w4 = w_c / 4;
+        const bool pow2 = c % 4 == 0 && w_c % 4 == 0 && c4 <= 64 && (c4 & (c4 - 1)) == 0 && (w4 & (w4 - 1)) == 0 && w4 <= c4;
+        if (pow2 && aligned16(input) && aligned16(position) && aligned16(weight) && aligned16(grad_output) &&
+            aligned16(grad_position) && aligned16(grad_weight)) {
+            const Vec4Shape v = vec4_shape(n, c, 1);
+            hipLaunchKernelGGL(aggregation_bwd_v4_kernel, dim3(v.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n,
+                               nsample, w4, v.cx_log2, (const f4 *)input, (const f4 *)position, (const f4 *)weight, idx,
+                               (const f4 *)grad_output, grad_input, (f4 *)grad_position, (f4 *)grad_weight);
+            return check_launch("aggregation_bwd_v4_kernel");
+        }
     }
     const RowShape s = row_shape(n, c);
     hipLaunchKernelGGL(aggregation_bwd_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, nsample,
