@@ -70,6 +70,8 @@ int tgn_get_fps_mode(void);
  *   "fps_bucket_min"     smallest cloud the bucket kernel takes, -1 = built-in thresholds               (TGN_FPS_BUCKET_MIN)
  *   "ball_bitmap"        0 = rank-select ball-query kernel instead of the bitmap one                    (TGN_BALL_BITMAP)
  *   "sa_tile"            0 = pick, 128 / 256 = force the workgroup tile of tgn_sa_mlp2_max_bf16x3                (TGN_SA_TILE)
+ *   "gather_v4"          gather family: bit 0 forward kernels with 16-byte lanes, bit 1 backward kernels with 16-byte lanes,
+ *                        bit 2 subtraction / aggregation backward with owner-side sums on dword lanes (default 5)    (TGN_GATHER_V4)
  *   "knn_memset"         1 = clear the kNN redo counter with hipMemsetAsync (reproduces a graph fault)  (TGN_KNN_MEMSET)
  *   "knn_grid_scale"     kNN grid cell, per mille of the estimated k-neighbour radius (1000)            (TGN_KNN_GRID_SCALE)
  * tgn_set_tuning returns TGN_ERR_INVALID_ARGUMENT for an unknown key; tgn_get_tuning returns `fallback` for one.
@@ -406,6 +408,10 @@ int tgn_three_nn(int B, int N, int S, const float *xyz1, const float *xyz2, floa
 /* inverse-distance weighted sum (pointnet2_utils.py:337-340); weight (B,N,3) is also written if non-NULL. */
 int tgn_three_interpolate(int B, int N, int S, int C, const float *points2, const float *dist, const void *idx,
                           int idx_is_int64, float *out, float *weight, tgn_stream_t stream);
+/* the same with the epilogue of the eval-mode feature propagation fused in (pointnet2_utils.py:337-347, first convolution
+ * commuted onto the coarse points): out = [relu](interpolation (+ add)); add (B,N,C) may be NULL and may be `out` itself. */
+int tgn_three_interpolate_ex(int B, int N, int S, int C, const float *points2, const float *dist, const void *idx,
+                             int idx_is_int64, const float *add, int relu, float *out, float *weight, tgn_stream_t stream);
 /*
  * Gather indices follow torch's advanced indexing (pointnet2_utils.py:56-60): negative values wrap (k + N); an
  * index still outside [0,N) -- where the reference raises, e.g. an empty ball yields index N -- makes

@@ -855,7 +855,8 @@ def test_all_ten_verbatim_launchers_on_a_side_stream(dev, oracle):
         torch.testing.assert_close(b_, rb, rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(c_, rc, rtol=1e-4, atol=1e-4)
     # every name of pointops_api.cpp:13-22 went through the shim
-    assert sorted(seen) == sorted(n_ for n_ in dir(PC) if n_.endswith("_cuda")) and len(seen) == 10
+    assert sorted(seen) == sorted(n_ for n_ in dir(PC) if n_.endswith("ward_cuda") or n_ in ("furthestsampling_cuda", "knnquery_cuda"))
+    assert len(seen) == 10
 
 
 def test_pointops_cuda_shim_runs_reference_style_code(dev, oracle):
@@ -877,3 +878,82 @@ def test_pointops_cuda_shim_runs_reference_style_code(dev, oracle):
     out = torch.empty(900, 5, 3, device=dev)
     pointops_cuda.grouping_forward_cuda(900, 5, 3, xyz, kidx, out)
     assert np.array_equal(out.cpu().numpy(), xyz_np[oi])
+
+
+@pytest.mark.parametrize("variant", [0, 3, 5])
+@pytest.mark.parametrize("shape", [(600, 12, 32, 4), (257, 7, 64, 8), (300, 5, 16, 16), (200, 9, 128, 16), (150, 6, 10, 5), (90, 4, 36, 12)])
+def test_gather_family_every_kernel_variant_matches_a_float64_evaluation(dev, variant, shape):
+    """The gather family's kernel variants (tgn_set_tuning "gather_v4": 0 = dword lanes and atomics everywhere, 3 = 16-byte lanes
+    forward and backward, 5 = the default: 16-byte lanes forward, owner-side sums backward) at channel counts that take the fast
+    paths (c % 4 == 0, powers of two) and that do not, against the operators' definitions (grouping_cuda_kernel.cu:5-25,
+    subtraction_cuda_kernel.cu:5-30, aggregation_cuda_kernel.cu:5-39, interpolation_cuda_kernel.cu:5-33) evaluated in float64.
+    Outputs the reference accumulates into are handed over pre-filled: what was there must still be added to."""
+    from toothgroupnetwork_amd import _lib
+    L, p = _lib.lib(), _lib.ptr
+    n, ns, c, wc = shape
+    g = torch.Generator().manual_seed(1000 + n)
+    R = lambda *sh: torch.randn(*sh, generator=g).to(dev)   # noqa: E731
+    x, y, pos, w, go3, go2 = R(n, c), R(n, c), R(n, ns, c), R(n, ns, wc), R(n, ns, c), R(n, c)
+    idx = torch.randint(0, n, (n, ns), generator=g, dtype=torch.int32).to(dev)
+    il = idx.long()
+    k = 3
+    ik, wk = idx[:, :k].contiguous(), torch.rand(n, k, generator=g).to(dev)
+    d = lambda t: t.double()   # noqa: E731
+    wfull = d(w)[:, :, torch.arange(c, device=dev) % wc]                       # weight[n, j, ci % w_c]
+    base2, base3w = R(n, c), R(n, ns, wc)
+    close = lambda a, b, tol=2e-5: torch.testing.assert_close(d(a), b, rtol=tol, atol=tol)   # noqa: E731
+    with _lib.tuning(gather_v4=variant):
+        st = _lib.stream
+        out = torch.empty(n, ns, c, device=dev)
+        _lib.check(L.tgn_grouping_forward(n, ns, c, p(x), p(idx), p(out), st()))
+        assert torch.equal(out, x[il])
+        _lib.check(L.tgn_subtraction_forward(n, ns, c, p(x), p(y), p(idx), p(out), st()))
+        assert torch.equal(out, x[:, None, :] - y[il])
+        o = base2.clone()
+        _lib.check(L.tgn_aggregation_forward(n, ns, c, wc, p(x), p(pos), p(w), p(idx), p(o), st()))
+        close(o, d(base2) + ((d(x)[il] + d(pos)) * wfull).sum(1))
+        o = base2.clone()
+        _lib.check(L.tgn_interpolation_forward(n, c, k, p(x), p(ik), p(wk), p(o), st()))
+        close(o, d(base2) + (d(x)[ik.long()] * d(wk)[:, :, None]).sum(1))
+        # backward: scatters accumulate into what the caller hands over
+        gi = base2.clone()
+        _lib.check(L.tgn_grouping_backward(n, ns, c, p(go3), p(idx), p(gi), st()))
+        close(gi, d(base2).index_put((il.reshape(-1),), d(go3).reshape(-1, c), accumulate=True))
+        gi = base2.clone()
+        _lib.check(L.tgn_interpolation_backward(n, c, k, p(go2), p(ik), p(wk), p(gi), st()))
+        close(gi, d(base2).index_put((ik.long().reshape(-1),), (d(go2)[:, None, :] * d(wk)[:, :, None]).reshape(-1, c), accumulate=True))
+        g1, g2 = base2.clone(), torch.zeros(n, c, device=dev)
+        _lib.check(L.tgn_subtraction_backward(n, ns, c, p(idx), p(go3), p(g1), p(g2), st()))
+        close(g1, d(base2) + d(go3).sum(1))
+        close(g2, torch.zeros(n, c, device=dev, dtype=torch.float64).index_put((il.reshape(-1),), -d(go3).reshape(-1, c), accumulate=True))
+        ga, gp, gw = torch.zeros(n, c, device=dev), torch.full((n, ns, c), 7.0, device=dev), base3w.clone()
+        _lib.check(L.tgn_aggregation_backward(n, ns, c, wc, p(x), p(pos), p(w), p(idx), p(go2), p(ga), p(gp), p(gw), st()))
+        gwfull = d(go2)[:, None, :] * wfull
+        close(ga, torch.zeros(n, c, device=dev, dtype=torch.float64).index_put((il.reshape(-1),), gwfull.reshape(-1, c), accumulate=True), 1e-4)
+        close(gp, gwfull)                                                        # assigned, not accumulated (aggregation_cuda_kernel.cu:35)
+        t = d(go2)[:, None, :] * (d(x)[il] + d(pos))                             # (n, ns, c) -> summed over the channels that share a weight
+        want_w = torch.zeros(n, ns, wc, device=dev, dtype=torch.float64).index_add_(2, torch.arange(c, device=dev) % wc, t)
+        close(gw, d(base3w) + want_w, 1e-4)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("C", [256, 64, 30, 7])
+def test_three_interpolate_with_fused_epilogue_equals_the_separate_passes(dev, C):
+    """tgn_three_interpolate_ex: [relu](interpolation (+ add)) in one kernel -- bit for bit what three_interpolate followed by
+    torch's add and relu give (same operation order), with 16-byte lanes (C % 4 == 0) and with dword lanes; `add` is consumed
+    in place."""
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    B, N, S = 3, 1500, 200
+    g = torch.Generator().manual_seed(C)
+    xyz1 = T(np.stack([synth.arch_cloud(N, 10 + b, False) for b in range(B)]), dev)
+    xyz2 = xyz1[:, torch.randperm(N, generator=g)[:S].to(dev)].contiguous()
+    f2 = torch.randn(B, S, C, generator=g).to(dev)
+    add = torch.randn(B, N, C, generator=g).to(dev)
+    dist, idx = U.three_nn(xyz1, xyz2)
+    plain = U.three_interpolate(f2, dist, idx)
+    assert torch.equal(U.three_interpolate_add_relu(f2, dist, idx), plain)
+    assert torch.equal(U.three_interpolate_add_relu(f2, dist, idx, relu=True), torch.relu(plain))
+    buf = add.clone()
+    got = U.three_interpolate_add_relu(f2, dist, idx, add=buf, relu=True)
+    assert got.data_ptr() == buf.data_ptr() and torch.equal(got, torch.relu(plain + add))
+    assert torch.equal(U.three_interpolate_add_relu(f2, dist, idx.int(), add=add.clone()), plain + add)

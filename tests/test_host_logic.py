@@ -322,7 +322,7 @@ def test_tuning_table_round_trip_and_unknown_key():
     pack as nt * 256 + p, the context manager restores, an unknown key is an error (not silently a no-op)."""
     from toothgroupnetwork_amd import _lib
     L = _lib.lib()
-    for key, default in (("fps_plain", 0), ("fps_bucket_min", -1), ("fps_cell_bits", 4), ("ball_bitmap", 1), ("sa_tile", 0), ("knn_grid_scale", 1000)):
+    for key, default in (("fps_plain", 0), ("fps_bucket_min", -1), ("fps_cell_bits", 4), ("ball_bitmap", 1), ("sa_tile", 0), ("knn_grid_scale", 1000), ("gather_v4", 5)):
         assert L.tgn_get_tuning(key.encode(), -12345) == default, key
     with _lib.tuning(fps_bucket_config=(512, 48), fps_plain=1):
         assert L.tgn_get_tuning(b"fps_bucket_config", 0) == 512 * 256 + 48

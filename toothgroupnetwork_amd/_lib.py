@@ -98,6 +98,7 @@ SIGNATURES = {
     "tgn_scatter_add_points": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P]),
     "tgn_three_nn": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "tgn_three_interpolate": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P]),
+    "tgn_three_interpolate_ex": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, _P]),
     "tgn_take_index_error": (c_int, [_P]),
     "tgn_clear_index_error": (c_int, [_P]),
     "tgn_square_distance": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P]),

@@ -352,7 +352,6 @@ __global__ __launch_bounds__(256) void aggregation_bwd_v4_kernel(long long n, in
     for (long long p = (long long)blockIdx.x * ry + ty; p < n; p += (long long)gridDim.x * ry) {
         const int *__restrict__ ip = idx + p * nsample;
         const f4 go = grad_output[(size_t)p * c4 + tx];
-#pragma unroll 2
         for (int j = 0; j < nsample; ++j) {
             const size_t ii = (size_t)p * nsample + j;
             const f4 w = weight[ii * w4 + wq];
@@ -368,6 +367,62 @@ __global__ __launch_bounds__(256) void aggregation_bwd_v4_kernel(long long n, in
                 t.w += __shfl_xor(t.w, m, kWave);
             }
             if (tx < w4) grad_weight[ii * w4 + tx] = grad_weight[ii * w4 + tx] + t;  // one owner per weight quad
+        }
+    }
+}
+
+// ---- the two reducing backward kernels with one lane per CHANNEL ---------------------------------------------------------
+// An fp32 atomic instruction whose lanes cover whole 128-byte lines (32 consecutive floats of one target row) is one request
+// per line; the 16-byte-lane form above spreads a row over four instructions that each touch every fourth dword.  So the
+// scatters keep dword lanes, and only the owner-side sums (grad_input1, grad_weight) change.
+__global__ __launch_bounds__(256) void subtraction_bwd_own_kernel(long long n, int nsample, int c, int cx_log2,
+                                                                   const int *__restrict__ idx,
+                                                                   const float *__restrict__ grad_output,
+                                                                   float *__restrict__ grad_input1,
+                                                                   float *__restrict__ grad_input2) {
+    TGN_V4_LANES
+    for (long long p = (long long)blockIdx.x * ry + ty; p < n; p += (long long)gridDim.x * ry) {
+        const int *__restrict__ ip = idx + p * nsample;
+        for (int ci = tx; ci < c; ci += cx) {
+            const float *__restrict__ src = grad_output + (size_t)p * nsample * c + ci;
+            float s = 0.0f;
+#pragma unroll 4
+            for (int j = 0; j < nsample; ++j) {
+                const float g = src[(size_t)j * c];
+                s += g;
+                atomicAdd(grad_input2 + (size_t)ip[j] * c + ci, -g);
+            }
+            grad_input1[(size_t)p * c + ci] += s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void aggregation_bwd_own_kernel(long long n, int nsample, int w_c, int cx_log2,
+                                                                   const float *__restrict__ input,
+                                                                   const float *__restrict__ position,
+                                                                   const float *__restrict__ weight,
+                                                                   const int *__restrict__ idx,
+                                                                   const float *__restrict__ grad_output,
+                                                                   float *__restrict__ grad_input,
+                                                                   float *__restrict__ grad_position,
+                                                                   float *__restrict__ grad_weight) {
+    // c == cx lanes (a power of two <= 64), w_c a power of two dividing it: lanes tx, tx + w_c, ... share weight tx % w_c
+    TGN_V4_LANES
+    const int c = cx;
+    const int wci = tx & (w_c - 1);
+    for (long long p = (long long)blockIdx.x * ry + ty; p < n; p += (long long)gridDim.x * ry) {
+        const int *__restrict__ ip = idx + p * nsample;
+        const float go = grad_output[(size_t)p * c + tx];
+        for (int j = 0; j < nsample; ++j) {
+            const size_t ii = (size_t)p * nsample + j;
+            const float w = weight[ii * w_c + wci];
+            const size_t in_i = (size_t)ip[j] * c + tx;
+            const float gw = go * w;
+            float t = go * (input[in_i] + position[ii * c + tx]);
+            atomicAdd(grad_input + in_i, gw);
+            grad_position[ii * c + tx] = gw;
+            for (int m = w_c; m < cx; m <<= 1) t += __shfl_xor(t, m, kWave);
+            if (tx < w_c) grad_weight[ii * w_c + tx] += t;
         }
     }
 }
@@ -496,6 +551,74 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(long long rows, 
     }
 }
 
+// three_interpolate with 16-byte lanes and the epilogue of the eval-mode feature propagation fused in
+// (pointnet2_utils.py:337-347 with the first convolution commuted onto the coarse points): out = [relu](interp (+ add)).
+// `add` may be `out` itself (every element is read and written by the same lane).
+template <typename IdxT>
+__global__ __launch_bounds__(256) void three_interpolate_v4_kernel(long long rows, int N, int S, int c4, int cx_log2,
+                                                                    const f4 *__restrict__ points2,
+                                                                    const float *__restrict__ dist,
+                                                                    const IdxT *__restrict__ idx, const f4 *add, int relu,
+                                                                    f4 *out, float *__restrict__ weight) {
+    TGN_V4_LANES
+    for (long long r = (long long)blockIdx.x * ry + ty; r < rows; r += (long long)gridDim.x * ry) {
+        const int b = (int)(r / N);
+        const float r0 = 1.0f / (dist[r * 3 + 0] + 1e-8f);
+        const float r1 = 1.0f / (dist[r * 3 + 1] + 1e-8f);
+        const float r2 = 1.0f / (dist[r * 3 + 2] + 1e-8f);
+        const float norm = (r0 + r1) + r2;
+        const float w0 = r0 / norm, w1 = r1 / norm, w2 = r2 / norm;
+        if (weight && tx == 0) {
+            weight[r * 3 + 0] = w0;
+            weight[r * 3 + 1] = w1;
+            weight[r * 3 + 2] = w2;
+        }
+        const f4 *f0 = points2 + ((size_t)b * S + (long long)idx[r * 3 + 0]) * c4;
+        const f4 *f1 = points2 + ((size_t)b * S + (long long)idx[r * 3 + 1]) * c4;
+        const f4 *f2 = points2 + ((size_t)b * S + (long long)idx[r * 3 + 2]) * c4;
+        for (int ci = tx; ci < c4; ci += cx) {
+            f4 v = ((f0[ci] * w0) + (f1[ci] * w1)) + (f2[ci] * w2);
+            if (add) v = v + add[(size_t)r * c4 + ci];
+            if (relu) {
+                v.x = fmaxf(v.x, 0.0f);
+                v.y = fmaxf(v.y, 0.0f);
+                v.z = fmaxf(v.z, 0.0f);
+                v.w = fmaxf(v.w, 0.0f);
+            }
+            out[(size_t)r * c4 + ci] = v;
+        }
+    }
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void three_interpolate_epilogue_kernel(long long rows, int N, int S, int C, int cx_log2,
+                                                                          const float *__restrict__ points2,
+                                                                          const float *__restrict__ dist,
+                                                                          const IdxT *__restrict__ idx, const float *add,
+                                                                          int relu, float *out, float *__restrict__ weight) {
+    TGN_ROW_LOOP(rows) {   // dword lanes: channel counts that are no multiple of 4 / unaligned rows
+        const int b = (int)(r / N);
+        const float r0 = 1.0f / (dist[r * 3 + 0] + 1e-8f);
+        const float r1 = 1.0f / (dist[r * 3 + 1] + 1e-8f);
+        const float r2 = 1.0f / (dist[r * 3 + 2] + 1e-8f);
+        const float norm = (r0 + r1) + r2;
+        const float w0 = r0 / norm, w1 = r1 / norm, w2 = r2 / norm;
+        if (weight && tx == 0) {
+            weight[r * 3 + 0] = w0;
+            weight[r * 3 + 1] = w1;
+            weight[r * 3 + 2] = w2;
+        }
+        const float *f0 = points2 + ((size_t)b * S + (long long)idx[r * 3 + 0]) * C;
+        const float *f1 = points2 + ((size_t)b * S + (long long)idx[r * 3 + 1]) * C;
+        const float *f2 = points2 + ((size_t)b * S + (long long)idx[r * 3 + 2]) * C;
+        for (int ci = tx; ci < C; ci += cx) {
+            float v = ((f0[ci] * w0) + (f1[ci] * w1)) + (f2[ci] * w2);
+            if (add) v = v + add[(size_t)r * C + ci];
+            out[(size_t)r * C + ci] = relu ? fmaxf(v, 0.0f) : v;
+        }
+    }
+}
+
 }  // namespace tgn
 
 using namespace tgn;
@@ -504,7 +627,7 @@ TGN_API int tgn_grouping_forward(int m, int nsample, int c, const float *input, 
                                  tgn_stream_t stream) {
     const long long rows = (long long)m * nsample;
     if (rows <= 0 || c <= 0) return TGN_OK;
-    if (c % 4 == 0 && aligned16(input) && aligned16(output)) {
+    if ((tuning(kTuneGatherV4) & 1) && c % 4 == 0 && aligned16(input) && aligned16(output)) {
         const Vec4Shape v = vec4_shape(rows, c, kV4Rows);
         hipLaunchKernelGGL(gather_rows_v4_kernel<false>, dim3(v.blocks), dim3(256), 0, (hipStream_t)stream, rows, nsample, c / 4,
                            v.cx_log2, (const f4 *)nullptr, (const f4 *)input, idx, (f4 *)output);
@@ -520,7 +643,7 @@ TGN_API int tgn_grouping_backward(int m, int nsample, int c, const float *grad_o
                                   float *grad_input, tgn_stream_t stream) {
     const long long rows = (long long)m * nsample;
     if (rows <= 0 || c <= 0) return TGN_OK;
-    if (c % 4 == 0 && aligned16(grad_output)) {
+    if ((tuning(kTuneGatherV4) & 2) && c % 4 == 0 && aligned16(grad_output)) {
         const Vec4Shape v = vec4_shape(rows, c, 1);
         hipLaunchKernelGGL(grouping_bwd_v4_kernel, dim3(v.blocks), dim3(256), 0, (hipStream_t)stream, rows, c / 4, v.cx_log2,
                            (const f4 *)grad_output, idx, grad_input);
@@ -535,7 +658,7 @@ TGN_API int tgn_grouping_backward(int m, int nsample, int c, const float *grad_o
 TGN_API int tgn_interpolation_forward(int n, int c, int k, const float *input, const int *idx, const float *weight,
                                       float *output, tgn_stream_t stream) {
     if (n <= 0 || c <= 0) return TGN_OK;
-    if (c % 4 == 0 && aligned16(input) && aligned16(output)) {
+    if ((tuning(kTuneGatherV4) & 1) && c % 4 == 0 && aligned16(input) && aligned16(output)) {
         const Vec4Shape v = vec4_shape(n, c, 1);
         hipLaunchKernelGGL(interpolation_fwd_v4_kernel, dim3(v.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, c / 4, k,
                            v.cx_log2, (const f4 *)input, idx, weight, (f4 *)output);
@@ -550,7 +673,7 @@ TGN_API int tgn_interpolation_forward(int n, int c, int k, const float *input, c
 TGN_API int tgn_interpolation_backward(int n, int c, int k, const float *grad_output, const int *idx,
                                        const float *weight, float *grad_input, tgn_stream_t stream) {
     if (n <= 0 || c <= 0) return TGN_OK;
-    if (c % 4 == 0 && aligned16(grad_output)) {
+    if ((tuning(kTuneGatherV4) & 2) && c % 4 == 0 && aligned16(grad_output)) {
         const Vec4Shape v = vec4_shape(n, c, 1);
         hipLaunchKernelGGL(interpolation_bwd_v4_kernel, dim3(v.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, c / 4, k,
                            v.cx_log2, (const f4 *)grad_output, idx, weight, grad_input);
@@ -566,7 +689,7 @@ TGN_API int tgn_subtraction_forward(int n, int nsample, int c, const float *inpu
                                     const int *idx, float *output, tgn_stream_t stream) {
     const long long rows = (long long)n * nsample;
     if (rows <= 0 || c <= 0) return TGN_OK;
-    if (c % 4 == 0 && aligned16(input1) && aligned16(input2) && aligned16(output)) {
+    if ((tuning(kTuneGatherV4) & 1) && c % 4 == 0 && aligned16(input1) && aligned16(input2) && aligned16(output)) {
         const Vec4Shape v = vec4_shape(rows, c, kV4Rows);
         hipLaunchKernelGGL(gather_rows_v4_kernel<true>, dim3(v.blocks), dim3(256), 0, (hipStream_t)stream, rows, nsample, c / 4,
                            v.cx_log2, (const f4 *)input1, (const f4 *)input2, idx, (f4 *)output);
@@ -582,7 +705,13 @@ TGN_API int tgn_subtraction_backward(int n, int nsample, int c, const int *idx, 
                                      float *grad_input1, float *grad_input2, tgn_stream_t stream) {
     const long long rows = (long long)n * nsample;
     if (rows <= 0 || c <= 0) return TGN_OK;
-    if (c % 4 == 0 && aligned16(grad_output) && aligned16(grad_input1)) {
+    if (tuning(kTuneGatherV4) & 4) {
+        const RowShape s = row_shape(n, c);
+        hipLaunchKernelGGL(subtraction_bwd_own_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, nsample, c,
+                           s.cx_log2, idx, grad_output, grad_input1, grad_input2);
+        return check_launch("subtraction_bwd_own_kernel");
+    }
+    if ((tuning(kTuneGatherV4) & 2) && c % 4 == 0 && aligned16(grad_output) && aligned16(grad_input1)) {
         const Vec4Shape v = vec4_shape(n, c, 1);
         hipLaunchKernelGGL(subtraction_bwd_v4_kernel, dim3(v.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, nsample,
                            c / 4, v.cx_log2, idx, (const f4 *)grad_output, (f4 *)grad_input1, grad_input2);
@@ -601,7 +730,7 @@ TGN_API int tgn_aggregation_forward(int n, int nsample, int c, int w_c, const fl
         set_error("tgn_aggregation_forward: w_c must be positive");
         return TGN_ERR_INVALID_ARGUMENT;
     }
-    if (c % 4 == 0 && w_c % 4 == 0 && aligned16(input) && aligned16(position) && aligned16(weight) && aligned16(output)) {
+    if ((tuning(kTuneGatherV4) & 1) && c % 4 == 0 && w_c % 4 == 0 && aligned16(input) && aligned16(position) && aligned16(weight) && aligned16(output)) {
         const Vec4Shape v = vec4_shape(n, c, 1);
         hipLaunchKernelGGL(aggregation_fwd_v4_kernel, dim3(v.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, nsample,
                            c / 4, w_c / 4, v.cx_log2, (const f4 *)input, (const f4 *)position, (const f4 *)weight, idx,
@@ -623,7 +752,13 @@ TGN_API int tgn_aggregation_backward(int n, int nsample, int c, int w_c, const f
         set_error("tgn_aggregation_backward: w_c must be positive");
         return TGN_ERR_INVALID_ARGUMENT;
     }
-    {
+    if ((tuning(kTuneGatherV4) & 4) && c <= 64 && (c & (c - 1)) == 0 && (w_c & (w_c - 1)) == 0 && w_c <= c) {
+        const RowShape s = row_shape(n, c);
+        hipLaunchKernelGGL(aggregation_bwd_own_kernel, dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, nsample, w_c,
+                           s.cx_log2, input, position, weight, idx, grad_output, grad_input, grad_position, grad_weight);
+        return check_launch("aggregation_bwd_own_kernel");
+    }
+    if (tuning(kTuneGatherV4) & 2) {
         const int c4 = c / 4, w4 = w_c / 4;
         const bool pow2 = c % 4 == 0 && w_c % 4 == 0 && c4 <= 64 && (c4 & (c4 - 1)) == 0 && (w4 & (w4 - 1)) == 0 && w4 <= c4;
         if (pow2 && aligned16(input) && aligned16(position) && aligned16(weight) && aligned16(grad_output) &&
@@ -724,6 +859,36 @@ TGN_API int tgn_three_interpolate(int B, int N, int S, int C, const float *point
         hipLaunchKernelGGL((three_interpolate_kernel<int>), dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, N, S,
                            C, s.cx_log2, points2, dist, (const int *)idx, out, weight);
     return check_launch("three_interpolate_kernel");
+}
+
+TGN_API int tgn_three_interpolate_ex(int B, int N, int S, int C, const float *points2, const float *dist, const void *idx,
+                                     int idx_is_int64, const float *add, int relu, float *out, float *weight,
+                                     tgn_stream_t stream) {
+    const long long rows = (long long)B * N;
+    if (rows <= 0 || C <= 0) return TGN_OK;
+    if (!points2 || !dist || !idx || !out) {
+        set_error("tgn_three_interpolate_ex: null pointer");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    if (C % 4 == 0 && aligned16(points2) && aligned16(out) && (!add || aligned16(add))) {
+        const Vec4Shape v = vec4_shape(rows, C, 1);
+        if (idx_is_int64)
+            hipLaunchKernelGGL((three_interpolate_v4_kernel<long long>), dim3(v.blocks), dim3(256), 0, (hipStream_t)stream, rows, N, S,
+                               C / 4, v.cx_log2, (const f4 *)points2, dist, (const long long *)idx, (const f4 *)add, relu, (f4 *)out,
+                               weight);
+        else
+            hipLaunchKernelGGL((three_interpolate_v4_kernel<int>), dim3(v.blocks), dim3(256), 0, (hipStream_t)stream, rows, N, S, C / 4,
+                               v.cx_log2, (const f4 *)points2, dist, (const int *)idx, (const f4 *)add, relu, (f4 *)out, weight);
+        return check_launch("three_interpolate_v4_kernel");
+    }
+    const RowShape s = row_shape(rows, C);
+    if (idx_is_int64)
+        hipLaunchKernelGGL((three_interpolate_epilogue_kernel<long long>), dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, N,
+                           S, C, s.cx_log2, points2, dist, (const long long *)idx, add, relu, out, weight);
+    else
+        hipLaunchKernelGGL((three_interpolate_epilogue_kernel<int>), dim3(s.blocks), dim3(256), 0, (hipStream_t)stream, rows, N, S, C,
+                           s.cx_log2, points2, dist, (const int *)idx, add, relu, out, weight);
+    return check_launch("three_interpolate_epilogue_kernel");
 }
 
 // ---- reference ABI (default stream, void) ---------------------------------------------------------

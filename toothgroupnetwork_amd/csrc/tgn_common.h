@@ -33,6 +33,8 @@ enum Tuning {
     kTuneKnnMemset,         // "knn_memset": 1 = clear the redo counter with hipMemsetAsync (reproduces the graph-replay fault)
     kTuneKnnGridScale,      // "knn_grid_scale": kNN grid cell size, per mille of the estimated k-neighbour radius (1000)
     kTuneSaTile,            // "sa_tile": 0 = pick, 128 / 256 = force the workgroup tile of tgn_sa_mlp2_max_bf16x3
+    kTuneGatherV4,          // "gather_v4": gather-family variants, bit 0: forward kernels with 16-byte lanes; bit 1: backward kernels with
+                            // 16-byte lanes; bit 2: subtraction / aggregation backward with dword lanes and owner-side sums (wins over bit 1)
     kTuneCount
 };
 int tuning(Tuning t);

@@ -20,8 +20,23 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _derived, point_transformer as PT, pointops
+import functools
+
+from . import _derived, _lib, point_transformer as PT, pointops
 from .pointnet2_utils import PointNetFeaturePropagation, PointNetSetAbstraction, PointNetSetAbstractionMsg
+
+
+def _one_index_check(forward):
+    """The gather kernels latch out-of-range indices in a device word that the checked operators read back after their launch -- a
+    stream synchronisation each (the price of raising IndexError like torch's advanced indexing, pointnet2_utils.py:56-60).  A whole
+    network forward issues six to twelve of them, and at the small levels the GPU then idles behind the host (~0.4 ms of a 4.9 ms
+    PointNet++ forward, profiles/r05_pnpp_forward_sequence.txt): the network mirrors read the word ONCE, when the forward is
+    through.  The IndexError is the same; it is raised at the end of the forward instead of inside the offending level."""
+    @functools.wraps(forward)
+    def wrapped(self, *args, **kwargs):
+        with _lib.deferred_index_check(type(self).__name__ + " forward"):
+            return forward(self, *args, **kwargs)
+    return wrapped
 
 
 class PointNetPPSeg(nn.Module):
@@ -59,6 +74,7 @@ class PointNetPPSeg(nn.Module):
             return F.linear(y, W2, b2).permute(0, 2, 1)
         return conv2(F.relu(bn1(conv1(x))))
 
+    @_one_index_check
     def forward(self, xyz_in):
         """xyz_in: [features (B, C, N)] with xyz in the first three channels -> the reference's output list
         [l0_points, l3_points, l0_xyz, l3_xyz, offset, dist(, cls)] (pointnet_pp.py:60-68)."""
@@ -119,6 +135,7 @@ class TsgCentroidNet(nn.Module):
         nn.init.zeros_(self.offset_conv_2.weight)
         nn.init.zeros_(self.dist_conv_2.weight)
 
+    @_one_index_check
     def forward(self, feats):
         """feats (B, 6, N), xyz first -> [l0_points, l3_points, l0_xyz, l3_xyz, offset (B,3,256), dist (B,1,256)] (:29-46)"""
         up, xyz, pts = _run_trunk(self, "", feats)
@@ -145,6 +162,7 @@ class TsgSegNet(nn.Module):
         nn.init.zeros_(self.fc2.weight)
         nn.init.zeros_(self.fc2.bias)
 
+    @_one_index_check
     def forward(self, feats):
         """feats (B, 36, N), xyz first -> (pd_1 (B,2,N), weight_1 (B,1,N), pd_2 (B,1,N), id_pred (B,17)) (:45-79)"""
         up1, _, _ = _run_trunk(self, "_1", feats)
@@ -208,6 +226,7 @@ class PointTransformerSeg(nn.Module):
         self.cls_head = MultiHead(planes, k, planes[0])
         self.offset_head = MultiHead(planes, 3, planes[0])
 
+    @_one_index_check
     def forward(self, inputs):
         """inputs: [features (B, C, N)] -> [cls (B, k, N), offset (1, 3, N) or None, None, x1 (B*N, planes[0])]
         (cbl_point_transformer_module.py:196-216 without the training criterion)."""

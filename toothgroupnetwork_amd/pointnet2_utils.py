@@ -383,6 +383,25 @@ class _ThreeInterpolate(Function):
         return grad.view(B, S, C), None, None
 
 
+def three_interpolate_add_relu(points2, dist, idx, add=None, relu=False):
+    """[relu](three_interpolate(points2, dist, idx) (+ add)) in ONE kernel, no autograd: the epilogue of the eval-mode feature
+    propagation (first convolution commuted onto the coarse points; `add` = the skip features' share of that convolution plus the
+    folded bias).  `add` (B,N,C) is overwritten with the result when given (it is a temporary there)."""
+    require_cuda(points2, dist, idx)
+    if idx.dtype not in (torch.int64, torch.int32):
+        idx = idx.long()
+    points2, dist, idx = _f32c(points2), _f32c(dist), idx.contiguous()
+    B, S, C = points2.shape
+    N = dist.shape[1]
+    if add is not None:
+        add = _f32c(add)
+        assert tuple(add.shape) == (B, N, C)
+    out = add if add is not None else torch.empty(B, N, C, dtype=torch.float32, device=points2.device)
+    check(lib().tgn_three_interpolate_ex(B, N, S, C, ptr(points2), ptr(dist), ptr(idx), int(idx.dtype == torch.int64), ptr(add),
+                                         int(bool(relu)), ptr(out), None, stream()), "three_interpolate_ex")
+    return out
+
+
 def three_interpolate(points2, dist, idx):
     """inverse-(squared)-distance weighted sum of the 3 neighbours (pointnet2_utils.py:337-340) -> (B,N,C)."""
     require_cuda(points2, dist, idx)
@@ -827,10 +846,11 @@ class PointNetFeaturePropagation(nn.Module):
                 srcs = _derived.sources(*self.mlp_convs, *self.mlp_bns)
                 layers = _derived.cached(self.mlp_bns[0], "fp_eval", srcs, None, fold)
                 W0, b0 = layers[0]
-                y = three_interpolate(F.linear(points2, W0[:, D1:]), dist, idx)  # (B, N, C1)
-                if points1 is not None:
-                    y = y + F.linear(points1.permute(0, 2, 1), W0[:, :D1])
-                y = torch.relu_(y.add_(b0))
+                # relu(interpolation of the transformed coarse rows + the skip features' share + bias): the bias rides in the skip
+                # GEMM, sum and ReLU in the interpolation kernel -- no elementwise pass over the (B, N, C1) tensor
+                coarse = F.linear(points2, W0[:, D1:]) if points1 is not None else F.linear(points2, W0[:, D1:], b0)
+                skip = F.linear(points1.permute(0, 2, 1), W0[:, :D1], b0) if points1 is not None else None
+                y = three_interpolate_add_relu(coarse, dist, idx, add=skip, relu=True)      # (B, N, C1)
                 for Wi, bi in layers[1:]:
                     y = torch.relu_(F.linear(y, Wi, bi))
                 return y.permute(0, 2, 1)
