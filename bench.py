@@ -13,9 +13,12 @@ timing, one RCCL all_gather of the per-rank timing vector at the end.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (FPS level 1), timed with HIP
-events on the launch stream inside the timed region; `cpu_baseline` is the C oracle (a scalar port of
-the reference algorithm, OpenMP over clouds/queries) on a bounded sample of the same workload.
+`python bench.py --gpus N` without torchrun starts its N ranks itself (toothgroupnetwork_amd.launch); a rank
+count other than --gpus is an error.  Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel
+(FPS level 1), timed with HIP events on the launch stream inside the timed region, against the measured
+latency floor of one FPS iteration (tools/fps_floor.hip); `cpu_baseline` is the reference's CPU path restated
+torch call for torch call (oracle/torch_cpu.py) on a bounded sample of the same workload, with the oracle's
+C/OpenMP port beside it; `ranks` / `backend` / `rccl_version` say who took part.
 """
 import argparse
 import json
@@ -50,8 +53,8 @@ def make_inputs(B, device, seed, shape):
     return xyz, feats, scans
 
 
-def cpu_baseline(scans, budget_meshes, shape):
-    """The oracle (C port of the reference algorithm) on a bounded sample, all host cores (OpenMP)."""
+def cpu_baseline_c_port(scans, budget_meshes, shape):
+    """The oracle's C restatement of the algorithm on a bounded sample, all host cores (OpenMP): the strong CPU line."""
     from oracle import cpu as O
     cores = O.num_threads()
     sample = scans[:budget_meshes]
@@ -73,9 +76,36 @@ def cpu_baseline(scans, budget_meshes, shape):
     return {"value": sample.shape[0] / dt, "unit": "meshes/s", "cores": cores, "kind": "port",
             "sample": f"{sample.shape[0]} scans x {len(shape['npoint'])} levels through oracle/pointops_oracle.c, "
                       f"{cores} OpenMP threads, {dt:.1f} s",
-            "note": "C/OpenMP port of the reference algorithm (oracle/), stronger than the reference's own torch-CPU path "
-                    "(BASELINE.md section 2: ~5.8 s per mesh for level 1 alone on 8 threads); the reference checkout is not "
-                    "present on the bench host, so its code cannot be timed here"}
+            "note": "C/OpenMP restatement of the algorithm (oracle/): far stronger than the reference's own torch-CPU path"}
+
+
+def cpu_baseline(scans, shape, budget_s=14.0, max_meshes=6):
+    """The reference's CPU path of this workload -- `farthest_point_sample_np` (start forced to 0), `query_ball_point`, the
+    gather / centre / cat lines of `sample_and_group` (pointnet2_utils.py:103-169) -- restated torch call for torch call in
+    oracle/torch_cpu.py (pinned bit for bit to fixtures the reference's own functions produced) and timed HERE, on the bench
+    host's cores, one scan at a time like the reference's batch-1 loop: scans until `budget_s` is used (at least one).
+    Single-branch shapes only (Shape A); the C/OpenMP port rides along as `c_openmp_port`."""
+    from oracle import torch_cpu as TC
+    cores = torch.get_num_threads()
+    per_scan, levels = [], None
+    t_all = time.perf_counter()
+    for i in range(max_meshes):
+        t0 = time.perf_counter()
+        lv = TC.headline_levels(scans[i % scans.shape[0]], shape["npoint"], shape["radius"], shape["nsample"], shape["d"], seed=i)
+        per_scan.append(time.perf_counter() - t0)
+        levels = lv if levels is None else [tuple(a + b for a, b in zip(x, y)) for x, y in zip(levels, lv)]
+        if time.perf_counter() - t_all > budget_s:
+            break
+    n = len(per_scan)
+    dt = float(np.median(per_scan))
+    return {"value": 1.0 / dt, "unit": "meshes/s", "cores": cores, "kind": "port",
+            "sample": f"{n} scan(s) x {len(shape['npoint'])} levels, one at a time, {cores} torch threads, median {dt:.2f} s per scan "
+                      f"({time.perf_counter() - t_all:.1f} s in all)",
+            "seconds_per_scan": [round(v, 3) for v in per_scan],
+            "seconds_per_level_fps_ball_group": [[round(v / n, 3) for v in x] for x in levels],
+            "what": "the reference's own CPU path (pointnet2_utils.py:103-169) restated torch call for torch call (oracle/torch_cpu.py, "
+                    "pinned to the reference's outputs by tests/test_oracle_golden.py); the reference checkout itself is not present on "
+                    "the bench host"}
 
 
 def fps_latency_floor():
@@ -334,18 +364,22 @@ def main(argv=None):
     if rank == 0 and world == 1 and args.cpu_meshes != 0:
         from oracle import cpu as O
         budget = args.cpu_meshes if args.cpu_meshes > 0 else max(8, 2 * O.num_threads())
-        out["cpu_baseline"] = cpu_baseline(scans if scans.shape[0] >= budget else
-                                           np.concatenate([scans] * (budget // scans.shape[0] + 1))[:budget], budget, shape)
-        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-        try:   # the reference's OWN torch-CPU path, timed where its checkout exists (tools/ref_cpu_baseline.py, build container)
-            ref = json.load(open(os.path.join(REPO, "profiles", "r04_reference_cpu.json")))
-            if args.shape == "A" and not args.fused:
-                out["cpu_baseline"]["reference_torch_cpu"] = {
+        c_port = cpu_baseline_c_port(scans if scans.shape[0] >= budget else
+                                     np.concatenate([scans] * (budget // scans.shape[0] + 1))[:budget], budget, shape)
+        if args.shape == "A" and not args.fused:
+            out["cpu_baseline"] = cpu_baseline(scans, shape)
+            out["cpu_baseline"]["c_openmp_port"] = c_port
+            out["speedup_vs_c_openmp_port"] = value / c_port["value"]
+            try:   # the reference's OWN functions, timed where its checkout exists (tools/ref_cpu_baseline.py, build container)
+                ref = json.load(open(os.path.join(REPO, "profiles", "r04_reference_cpu.json")))
+                out["cpu_baseline"]["reference_in_build_container"] = {
                     "kind": "reference", "unit": "meshes/s", "source": "profiles/r04_reference_cpu.json (tools/ref_cpu_baseline.py; NOT this host)",
-                    "host": ref["host"], **{k: v["meshes_per_s"] for k, v in ref["results"].items()},
-                    "what": ref["what"]}
-        except Exception:
-            pass
+                    "host": ref["host"], **{k: v["meshes_per_s"] for k, v in ref["results"].items()}, "what": ref["what"]}
+            except Exception:
+                pass
+        else:
+            out["cpu_baseline"] = c_port
+        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
     if rank == 0 and world == 1 and args.secondary and args.shape == "A" and not args.fused and not args.fps_prefix:
         # in a process of its own, under a time limit: a fault or a hang in a non-headline configuration (graph-captured training
         # step, the matrix-core kernels) must not take the headline line with it

@@ -421,6 +421,10 @@ int tgn_three_interpolate_ex(int B, int N, int S, int C, const float *points2, c
  * it synchronises `stream`.  (The Python operators call it and raise IndexError.)
  */
 int tgn_take_index_error(tgn_stream_t stream);
+/* The same over every stream of the current device (synchronises the DEVICE, ORs and clears all of its flags): for planners
+ * that launch unchecked on streams of their own (HotPath), graphs replayed on another stream than they were captured on
+ * (a graph keeps the capture stream's flag), and TGN_INDEX_CHECK=off sections. */
+int tgn_take_index_error_device(void);
 /* Clears the flag in stream order without synchronising: what a checked operator issues in front of its own launch, so
  * that a bit latched by an earlier UNCHECKED launch is not attributed to it. */
 int tgn_clear_index_error(tgn_stream_t stream);

@@ -317,6 +317,26 @@ def test_effective_cpus_honours_the_cgroup_quota(tmp_path):
     assert sharding.effective_cpus(str(tmp_path)) == have
 
 
+def test_cpus_for_this_rank_divides_mask_and_quota_once_each(tmp_path, monkeypatch):
+    """sharding.cpus_for_this_rank: the quota is shared by all ranks of the node, the NUMA-narrowed affinity mask only by the ranks
+    on that node (round 4 divided the narrowed mask by all ranks: 2 x 64 cores and 8 ranks gave 8 loader threads, not 16)."""
+    from toothgroupnetwork_amd import sharding
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    monkeypatch.setattr(sharding, "_affinity_count", lambda: 64)
+    monkeypatch.setattr(sharding, "_PIN", {"before": 128, "after": 64})
+    assert sharding.cpus_for_this_rank(8, str(tmp_path)) == 16          # 4 of the 8 ranks share this node's 64 cores
+    assert sharding.cpus_for_this_rank(1, str(tmp_path)) == 64
+    monkeypatch.setattr(sharding, "_affinity_count", lambda: 32)
+    monkeypatch.setattr(sharding, "_PIN", {"before": 128, "after": 32})
+    assert sharding.cpus_for_this_rank(8, str(tmp_path)) == 16          # NPS4: 2 ranks per 32-core node
+    monkeypatch.setattr(sharding, "_PIN", {})
+    monkeypatch.setattr(sharding, "_affinity_count", lambda: 128)
+    assert sharding.cpus_for_this_rank(8, str(tmp_path)) == 16          # not pinned: the whole mask over all ranks
+    (tmp_path / "cpu.max").write_text("1600000 100000\n")               # a 16-core quota for the whole node
+    assert sharding.cpus_for_this_rank(8, str(tmp_path)) == 2
+    assert sharding.cpus_for_this_rank(1, str(tmp_path)) == 16
+
+
 def test_tuning_table_round_trip_and_unknown_key():
     """tgn_set_tuning / tgn_get_tuning (include/tgn_pointops.h): host-side table, no GPU needed.  Known keys round-trip, (nt, p) pairs
     pack as nt * 256 + p, the context manager restores, an unknown key is an error (not silently a no-op)."""

@@ -100,6 +100,7 @@ SIGNATURES = {
     "tgn_three_interpolate": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P]),
     "tgn_three_interpolate_ex": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, _P]),
     "tgn_take_index_error": (c_int, [_P]),
+    "tgn_take_index_error_device": (c_int, []),
     "tgn_clear_index_error": (c_int, [_P]),
     "tgn_square_distance": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P]),
     # section 4 (host pointers)
@@ -236,17 +237,27 @@ def require_cuda(*tensors):
 
 
 # What the gather family does about an index outside [-N, N) -- where the reference's advanced indexing raises
-# (pointnet2_utils.py:56-60; an empty ball yields index N, :136-141).  The kernels latch a per-device flag;
-#   TGN_INDEX_CHECK=sync (default): index_points / group_points read the flag after their launch (one 4-byte
+# (pointnet2_utils.py:56-60; an empty ball yields index N, :136-141).  The kernels latch a flag that belongs to the
+# (device, STREAM) they were launched on;
+#   TGN_INDEX_CHECK=sync (default): index_points / group_points read their stream's flag after their launch (one 4-byte
 #       device->host copy + stream sync) and raise IndexError like the reference's CPU path;
 #   TGN_INDEX_CHECK=off: no check, no sync (rows with a bad index are filled from point 0 / zeros);
-#       take_index_error() can be called by hand at any synchronisation point.
+#       take_index_error() reads the CURRENT stream's flag by hand at a synchronisation point; launches that ran on other
+#       streams (HotPath's three, a graph replayed elsewhere than it was captured) are covered by
+#       take_index_error_device(), which synchronises the device and reads every flag of it.
 INDEX_CHECK = os.environ.get("TGN_INDEX_CHECK", "sync").lower()
 
 
 def take_index_error():
-    """True (and the flag is cleared) if a gather on the current device saw an out-of-range index since the last call."""
+    """True (and the flag is cleared) if a gather launched on the CURRENT torch stream of the current device saw an out-of-range
+    index since the last call.  Synchronises that stream."""
     return bool(lib().tgn_take_index_error(stream()))
+
+
+def take_index_error_device():
+    """True (and every flag of the device is cleared) if a gather on ANY stream of the current device saw an out-of-range index
+    since the flags were last read.  Synchronises the device."""
+    return bool(lib().tgn_take_index_error_device())
 
 
 _check_state = threading.local()

@@ -54,7 +54,13 @@ int *index_error_word(hipStream_t stream) {
     }
     for (int i = 0; i < e.used; ++i)
         if (e.owner[i] == stream) return e.block + i;
-    if (e.used == kWordsPerDevice) return e.block;
+    if (e.used == kWordsPerDevice) {
+        static std::atomic<bool> warned{false};
+        if (!warned.exchange(true))
+            fprintf(stderr, "libtgn_pointops: more than %d streams on device %d use the gather family; further streams share "
+                            "index-error word 0 (a bit may be reported to, or cleared by, another stream's check)\n", kWordsPerDevice, dev);
+        return e.block;
+    }
     e.owner[e.used] = stream;
     return e.block + e.used++;
 }
@@ -126,6 +132,27 @@ TGN_API int tgn_take_index_error(tgn_stream_t stream) {
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 0;
     if (h) (void)hipMemsetAsync(w, 0, sizeof(int), (hipStream_t)stream);
     return h;
+}
+
+// The same over EVERY stream of the current device: synchronises the device, returns the OR of all its words and clears them.
+// For callers that launch on streams of their own without checking (HotPath's three streams, captured graphs replayed on
+// another stream, TGN_INDEX_CHECK=off sections) and want one answer at a synchronisation point.
+TGN_API int tgn_take_index_error_device(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= tgn::kMaxDevices) return 0;
+    int *block = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(tgn::g_err_mutex);
+        block = tgn::g_err[dev].block;
+    }
+    if (!block) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) return 0;
+    int h[tgn::kWordsPerDevice];
+    if (hipMemcpy(h, block, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    int any = 0;
+    for (int i = 0; i < tgn::kWordsPerDevice; ++i) any |= h[i];
+    if (any) (void)hipMemset(block, 0, sizeof(h));
+    return any;
 }
 
 // Forget whatever earlier launches latched, in stream order (no synchronisation): a checked operator calls this in front of

@@ -273,6 +273,12 @@ class HotPath:
             return [self._sa(lv, br, cur_xyz, pts, st) for br in lv["branches"]]
         return [self._group(lv, br, cur_xyz, feats[i], st) for br in lv["branches"]]
 
+    def take_index_error(self):
+        """HotPath launches unchecked on streams of its own (the ball queries it runs produce valid indices by construction;
+        a caller-supplied index tensor would not): True if any of its kernels latched an out-of-range gather index since the
+        flags were last read.  Synchronises the device (every stream's flag is read: _lib.take_index_error_device)."""
+        return _lib.take_index_error_device()
+
     def enable_kernel_timing(self, steps, stride=1):
         """HIP events on the launch stream around each kernel class (start/stop), on every `stride`-th step: a timing
         event is a barrier packet in its queue, and a dozen of them per step cost the pipelined schedule ~5 %."""

@@ -846,10 +846,12 @@ class PointNetFeaturePropagation(nn.Module):
                 srcs = _derived.sources(*self.mlp_convs, *self.mlp_bns)
                 layers = _derived.cached(self.mlp_bns[0], "fp_eval", srcs, None, fold)
                 W0, b0 = layers[0]
-                # relu(interpolation of the transformed coarse rows + the skip features' share + bias): the bias rides in the skip
-                # GEMM, sum and ReLU in the interpolation kernel -- no elementwise pass over the (B, N, C1) tensor
-                coarse = F.linear(points2, W0[:, D1:]) if points1 is not None else F.linear(points2, W0[:, D1:], b0)
-                skip = F.linear(points1.permute(0, 2, 1), W0[:, :D1], b0) if points1 is not None else None
+                # relu(interpolation of the transformed coarse rows + the skip features' share + bias): the bias rides in the COARSE
+                # GEMM (S contiguous rows; the interpolation weights sum to one, so it comes through unchanged up to one rounding --
+                # the skip features arrive as a channel-first view, where torch would add a bias in a pass of its own), sum and ReLU
+                # in the interpolation kernel -- no elementwise pass over the (B, N, C1) tensor
+                coarse = F.linear(points2, W0[:, D1:], b0)
+                skip = F.linear(points1.permute(0, 2, 1), W0[:, :D1]) if points1 is not None else None
                 y = three_interpolate_add_relu(coarse, dist, idx, add=skip, relu=True)      # (B, N, C1)
                 for Wi, bi in layers[1:]:
                     y = torch.relu_(F.linear(y, Wi, bi))

@@ -194,7 +194,7 @@ def preprocess_scans(pairs, save_path, batch=16, fps_batch=None, workers=None, s
         local = max(int(os.environ.get("LOCAL_WORLD_SIZE", "1")), 1)
         # loader threads: the cores this rank can really use (affinity mask and cgroup CPU quota, shared by the ranks of the node),
         # at most 16 -- one process's loaders scale linearly to 16 threads (84 scans/s each) and not beyond
-        workers = int(os.environ.get("TGN_PREPROCESS_WORKERS", "0")) or max(1, min(16, sharding.effective_cpus() // local))
+        workers = int(os.environ.get("TGN_PREPROCESS_WORKERS", "0")) or max(1, min(16, sharding.cpus_for_this_rank(local)))
     if samplers is None:
         samplers = max(int(os.environ.get("TGN_PREPROCESS_SAMPLERS", "2")), 1)
     stats = dict(scans=0, sampled=0, points_in=0, checksum=0.0, batches=0, seconds_load=0.0, seconds_fps=0.0)

@@ -57,10 +57,22 @@ def effective_cpus(cgroup_root="/sys/fs/cgroup"):
     MI355X boxes whose sandbox grants 16 cores' worth of time -- and sizing thread pools by it oversubscribes the quota: the
     loaders of the preprocess runner then throttle each other (measured: 1 240 scans/s from 16 loader threads, 840 from 128;
     profiles/r04_preprocess_host_scaling.txt)."""
+    n = _affinity_count()
+    quota = cpu_quota(cgroup_root)
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(n, 1)
+
+
+def _affinity_count():
     try:
-        n = len(os.sched_getaffinity(0))
+        return len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
-        n = os.cpu_count() or 1
+        return os.cpu_count() or 1
+
+
+def cpu_quota(cgroup_root="/sys/fs/cgroup"):
+    """cores' worth of CPU time the container may use (cgroup v2 `cpu.max`, v1 cfs quota / period), or None if unlimited"""
     quota = None
     try:
         q, period = open(os.path.join(cgroup_root, "cpu.max")).read().split()[:2]
@@ -74,8 +86,25 @@ def effective_cpus(cgroup_root="/sys/fs/cgroup"):
                 quota = q / period
         except (OSError, ValueError):
             pass
+    return quota
+
+
+_PIN = {}   # affinity-mask sizes before / after pin_to_gpu_numa narrowed this process's mask
+
+
+def cpus_for_this_rank(local_world, cgroup_root="/sys/fs/cgroup"):
+    """Host cores one of `local_world` ranks of a node should size its thread pools by.  The CPU quota is shared by all ranks of
+    the node; the affinity mask, once pin_to_gpu_numa has narrowed it to the GPU's NUMA node, only by the ranks whose GPUs hang
+    off that node (local_world x mask-after / mask-before of them, GPUs being spread evenly over the nodes) -- dividing the
+    narrowed mask by ALL ranks counted the split twice (2 x 64 cores, 8 ranks: 8 loaders instead of 16)."""
+    local_world = max(int(local_world), 1)
+    aff = _affinity_count()
+    before = max(_PIN.get("before", aff), aff)
+    sharing = max(1, min(local_world, int(round(local_world * aff / before))))
+    n = aff // sharing
+    quota = cpu_quota(cgroup_root)
     if quota is not None:
-        n = min(n, max(1, int(quota + 0.5)))
+        n = min(n, int(quota + 0.5) // local_world)
     return max(n, 1)
 
 
@@ -90,10 +119,13 @@ def pin_to_gpu_numa(device_index, sysfs="/sys/bus/pci/devices"):
         pr = torch.cuda.get_device_properties(device_index)
         bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
         cpus = parse_cpulist(open(os.path.join(sysfs, bdf, "local_cpulist")).read())
-        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        current = os.sched_getaffinity(0)
+        allowed = sorted(set(cpus) & set(current))
         if not allowed:
             return None
+        _PIN.setdefault("before", len(current))
         os.sched_setaffinity(0, allowed)
+        _PIN["after"] = len(allowed)
         return allowed
     except Exception:
         return None
