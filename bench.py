@@ -79,29 +79,42 @@ def cpu_baseline_c_port(scans, budget_meshes, shape):
             "note": "C/OpenMP restatement of the algorithm (oracle/): far stronger than the reference's own torch-CPU path"}
 
 
-def cpu_baseline(scans, shape, budget_s=14.0, max_meshes=6):
+def cpu_baseline(scans, shape, budget_s=8.0, max_meshes=4):
     """The reference's CPU path of this workload -- `farthest_point_sample_np` (start forced to 0), `query_ball_point`, the
     gather / centre / cat lines of `sample_and_group` (pointnet2_utils.py:103-169) -- restated torch call for torch call in
     oracle/torch_cpu.py (pinned bit for bit to fixtures the reference's own functions produced) and timed HERE, on the bench
     host's cores, one scan at a time like the reference's batch-1 loop: scans until `budget_s` is used (at least one).
     Single-branch shapes only (Shape A); the C/OpenMP port rides along as `c_openmp_port`."""
     from oracle import torch_cpu as TC
-    cores = torch.get_num_threads()
+    # BASELINE.md section 3: all the cores the process can really use, and one thread.  "All" is the affinity mask cut down by the
+    # container's CPU quota (sharding.effective_cpus): torch's default of one thread per hardware thread (128 here) under a
+    # 16-core quota spends its time being throttled -- 13.6 s for level 1's sampling instead of ~2 s
+    cores = sharding.effective_cpus()
+    before = torch.get_num_threads()
     per_scan, levels = [], None
     t_all = time.perf_counter()
-    for i in range(max_meshes):
+    try:
+        torch.set_num_threads(cores)
+        for i in range(max_meshes):
+            t0 = time.perf_counter()
+            lv = TC.headline_levels(scans[i % scans.shape[0]], shape["npoint"], shape["radius"], shape["nsample"], shape["d"], seed=i)
+            per_scan.append(time.perf_counter() - t0)
+            levels = lv if levels is None else [tuple(a + b for a, b in zip(x, y)) for x, y in zip(levels, lv)]
+            if time.perf_counter() - t_all > budget_s:
+                break
+        torch.set_num_threads(1)
         t0 = time.perf_counter()
-        lv = TC.headline_levels(scans[i % scans.shape[0]], shape["npoint"], shape["radius"], shape["nsample"], shape["d"], seed=i)
-        per_scan.append(time.perf_counter() - t0)
-        levels = lv if levels is None else [tuple(a + b for a, b in zip(x, y)) for x, y in zip(levels, lv)]
-        if time.perf_counter() - t_all > budget_s:
-            break
+        TC.headline_levels(scans[0], shape["npoint"], shape["radius"], shape["nsample"], shape["d"], seed=0)
+        one_thread_s = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(before)
     n = len(per_scan)
     dt = float(np.median(per_scan))
     return {"value": 1.0 / dt, "unit": "meshes/s", "cores": cores, "kind": "port",
-            "sample": f"{n} scan(s) x {len(shape['npoint'])} levels, one at a time, {cores} torch threads, median {dt:.2f} s per scan "
-                      f"({time.perf_counter() - t_all:.1f} s in all)",
+            "sample": f"{n} scan(s) x {len(shape['npoint'])} levels, one at a time, {cores} torch threads, median {dt:.2f} s per scan; "
+                      f"one more scan on 1 thread ({one_thread_s:.2f} s); {time.perf_counter() - t_all:.1f} s in all",
             "seconds_per_scan": [round(v, 3) for v in per_scan],
+            "one_thread": {"value": 1.0 / one_thread_s, "unit": "meshes/s", "cores": 1},
             "seconds_per_level_fps_ball_group": [[round(v / n, 3) for v in x] for x in levels],
             "what": "the reference's own CPU path (pointnet2_utils.py:103-169) restated torch call for torch call (oracle/torch_cpu.py, "
                     "pinned to the reference's outputs by tests/test_oracle_golden.py); the reference checkout itself is not present on "
