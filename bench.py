@@ -203,6 +203,8 @@ def main(argv=None):
     ap.add_argument("--secondary", type=int, default=1, help="1 (default, N = 1 only): after the headline, also measure the non-headline "
                     "configurations of BASELINE.json (Shape B, the fused levels, kNN, large-cloud FPS, Point-Transformer forward, training "
                     "step), in a child process, and attach them as `secondary` (tools/secondary_bench.py; ~1-2 minutes); 0: skip")
+    ap.add_argument("--group-max-blocks", type=int, default=None, help="bound the grouping kernels' grid (default: 256 in the phased schedule -- their "
+                    "place beside the FPS level-1 workgroups --, unbounded on one stream); counter passes use --pipeline 0 --group-max-blocks 256")
     ap.add_argument("--secondary-timeout", type=float, default=420.0, help="seconds the secondary child process may take")
     args = ap.parse_args(argv)
 
@@ -217,7 +219,7 @@ def main(argv=None):
     B = args.batch
     shape = hotpath.SHAPE_A if args.shape == "A" else hotpath.SHAPE_B
     xyz, feats, scans = make_inputs(B, device, seed=100 + rank, shape=shape)
-    gopts = dict(fused=bool(args.fused))
+    gopts = dict(fused=bool(args.fused), group_max_blocks=args.group_max_blocks)
     hp = hotpath.HotPath(B, device, shape=shape, pipeline=bool(args.pipeline), fps_prefix=bool(args.fps_prefix), **gopts)
     for _ in range(max(args.warmup, 1)):                     # (the first run also measures the schedule's plan, hotpath.plan_schedule)
         hp.run(xyz, feats, inputs_on_current_stream=False)   # the synthetic scans are resident before any step

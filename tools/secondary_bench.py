@@ -283,7 +283,26 @@ def gather_family(device, n=24000, ns=36, c=32, wc=4, k=3, m_coarse=6000, batch_
                          roofline=_roof("hbm", nbytes / ms / 1e6, HBM_PEAK_GBS, "GB/s"))
     out["interpolation_fwd"]["note"] = out["interpolation_bwd"]["note"] = \
         "a few MB per launch: ~1 us of HBM time, so the launch itself is the floor at this size"
+    # The backward kernels scatter into data-dependent rows: fp32 atomics, one dword per element, executed by the L2 channels' atomic
+    # units -- their ceiling, not HBM's, bounds these kernels.  tools/atomic_floor.hip measures it (register operands, whole-line
+    # instructions, the same table size); `roofline_atomic` = this kernel's dword-atomics per second against that.
+    floor = atomic_floor()
+    out["atomic_floor"] = floor
+    atomics = {"grouping_bwd": rows * c, "subtraction_bwd": rows * c, "aggregation_bwd": rows * c, "interpolation_bwd": n * k * c}
+    for name, cnt in atomics.items():
+        rate = cnt / (out[name]["us"] * 1e-6) / 1e9
+        out[name]["roofline_atomic"] = _roof("l2_atomic", rate, floor.get("line_gatomics_per_s"), "G dword-atomics/s", atomics_per_launch=cnt)
     return out
+
+
+def atomic_floor():
+    import subprocess
+    exe = os.path.join(REPO, "tools", "_bin", "atomic_floor")
+    try:
+        r = subprocess.run([exe, "--json"], capture_output=True, text=True, timeout=120)
+        return {**json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["atomic_floor"], "source": "tools/_bin/atomic_floor on this GPU"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"atomic_floor unavailable: {type(e).__name__}: {str(e)[:100]}"}
 
 
 def measure_all(make_inputs, device, budget_s=240.0, checkpoint=None):

@@ -104,7 +104,7 @@ class HotPath:
     kernels of step k on stream G."""
 
     def __init__(self, B, device, shape=SHAPE_A, index_dtype=torch.int32, pipeline=False, fps_prefix=False, fused=False,
-                 plan=None):
+                 plan=None, group_max_blocks=None):
         self.B, self.device, self.shape = B, device, shape
         self.fused = bool(fused)
         # fps_prefix: hand every FPS level the certificate of the level that produced its input (FPS of an FPS result
@@ -116,7 +116,9 @@ class HotPath:
         self.pipeline = bool(pipeline)
         self.phased = self.pipeline and not self.fused
         # the gated groupings run beside the FPS level-1 workgroups: 256 "blocks" = one wave per SIMD
-        self.group_max_blocks = 256 if self.phased else 0
+        # (group_max_blocks: force the bound also on one stream -- counter passes that want the grouping's HBM traffic at the grid it
+        # has in the phased schedule, tools/gpu_pmc.sh)
+        self.group_max_blocks = int(group_max_blocks) if group_max_blocks is not None else (256 if self.phased else 0)
         self.sets = [self._alloc(B, device, shape, index_dtype) for _ in range(2 if pipeline else 1)]
         self.levels = self.sets[0]
         self.idx64 = int(index_dtype == torch.int64)
