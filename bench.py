@@ -327,7 +327,7 @@ def main(argv=None):
         # HBM bytes per launch: NOT measured in this run -- read from the PMC passes committed under profiles/ (tools/gpu_pmc.sh,
         # separate rocprofv3 --pmc runs of the same workload; labelled `traffic_source`)
         pmc = {}
-        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(REPO, "profiles", name)))
                 pmc_name = name

@@ -17,7 +17,7 @@ import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
-tag = sys.argv[3] if len(sys.argv) > 3 else "r04"
+tag = sys.argv[3] if len(sys.argv) > 3 else "r05"
 LEVELS = 3
 
 
@@ -44,7 +44,9 @@ def classify(name):
 
 
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python bench.py "
-                 "--pipeline 0 --steps 2 --warmup 1 --cpu-meshes 0 --no-kernel-timing (one stream: the dispatch order identifies the level); 256 scans per launch; bytes = counter x 1024, "
+                 "--pipeline 0 --group-max-blocks 256 --steps 2 --warmup 1 --cpu-meshes 0 --no-kernel-timing (one stream: the dispatch order identifies the level; the groupings at the "
+                 "256-block grid they have in the phased schedule -- rounds 1-4 measured them at the unbounded grid, where 32 scans per XCD thrash its L2: group_l1 fetched "
+                 "977 MB there and 176 MB here); 256 scans per launch; bytes = counter x 1024, "
                  "NOT doubled (MI355X_MICROARCH.md notes FETCH_SIZE under-reports wide streaming reads by 2x on gfx950; "
                  "these kernels read 4 B per lane).  Mean over the dispatches of each kernel class and level.",
        "per_kernel": {}}

@@ -522,9 +522,12 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int B, int N, int S, cons
         }
         __syncthreads();
         if (active) {
-            // strict '<' in ascending index order keeps the earlier index on ties
-            auto insert = [&](float d, int k) {
+            for (int i = 0; i < cnt; ++i) {
+                const float4 p = tile[i];
+                const float d = sqdist_expanded(cx, cy, cz, s1, p.x, p.y, p.z, p.w);
+                // strict '<' in ascending index order keeps the earlier index on ties
                 if (d < d2) {
+                    const int k = t0 + i;
                     if (d < d1) {
                         d2 = d1;
                         i2 = i1;
@@ -542,29 +545,6 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int B, int N, int S, cons
                         i2 = k;
                     }
                 }
-            };
-            // eight support points per trip: the eight LDS reads are in flight together and the eight distances are independent, so a
-            // wave that is alone on its SIMD (the coarse levels: 4 096 - 8 192 queries in all) no longer pays one LDS round trip and one
-            // dependent chain per pair (fp2 / fp3 of the reference net: 61 / 33 us -> see profiles/r05_pnpp_forward_summary.txt); the
-            // running top three is only touched when one of the eight beats the current third
-            constexpr int U = 8;
-            int i = 0;
-            for (; i + U <= cnt; i += U) {
-                float d[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const float4 p = tile[i + u];
-                    d[u] = sqdist_expanded(cx, cy, cz, s1, p.x, p.y, p.z, p.w);
-                }
-                const float m = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
-                if (m < d2) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) insert(d[u], t0 + i + u);
-                }
-            }
-            for (; i < cnt; ++i) {
-                const float4 p = tile[i];
-                insert(sqdist_expanded(cx, cy, cz, s1, p.x, p.y, p.z, p.w), t0 + i);
             }
         }
     }
