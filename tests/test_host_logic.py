@@ -337,6 +337,26 @@ def test_cpus_for_this_rank_divides_mask_and_quota_once_each(tmp_path, monkeypat
     assert sharding.cpus_for_this_rank(1, str(tmp_path)) == 16
 
 
+def test_config_object_is_the_one_place_for_python_side_switches():
+    """toothgroupnetwork_amd.config: one object, seeded from the environment once; override() for a block; the module-level names of
+    rounds 1-4 (U.FUSED_SA, P.KNN_GRID, _lib.INDEX_CHECK, ...) are live aliases of its fields, reads AND writes."""
+    from toothgroupnetwork_amd import _lib, config, pointnet2_utils as U, pointops as P
+    c = config.cfg
+    assert (U.FUSED_SA, U.COMMUTE_FP, U.SA_BF16X3) == (c.fused_sa, c.commute_fp, c.sa_bf16x3)
+    assert (P.KNN_GRID, P.KNN_GRID_MIN_POINTS, P._KNN_CACHE_SIZE, _lib.INDEX_CHECK) == (c.knn_grid, c.knn_grid_min_points, c.knn_cache_size, c.index_check)
+    with config.override(fused_sa=False, knn_cache_size=0, index_check="off"):
+        assert U.FUSED_SA is False and P._KNN_CACHE_SIZE == 0 and _lib.INDEX_CHECK == "off" and not _lib._checking()
+    assert U.FUSED_SA is c.fused_sa and _lib.INDEX_CHECK == c.index_check
+    keep = c.commute_fp
+    U.COMMUTE_FP = not keep                      # a legacy write lands in the config object
+    assert c.commute_fp is (not keep)
+    U.COMMUTE_FP = keep
+    with pytest.raises(AttributeError):
+        config.override(no_such_switch=1)
+    fresh = config.Config()
+    assert fresh.fused_sa and fresh.sa_bf16x3 and fresh.knn_grid_min_points == 3000 and fresh.index_check == "sync"
+
+
 def test_tuning_table_round_trip_and_unknown_key():
     """tgn_set_tuning / tgn_get_tuning (include/tgn_pointops.h): host-side table, no GPU needed.  Known keys round-trip, (nt, p) pairs
     pack as nt * 256 + p, the context manager restores, an unknown key is an error (not silently a no-op)."""

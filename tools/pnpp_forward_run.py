@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """nets.PointNetPPSeg (pointnet_pp.py get_model) forward, 8 x 24 000-point scans, eval: N forwards for a rocprofv3 kernel
-trace (tools/gpu_r5_a.sh -> profiles/r05_pnpp_forward_kernel_stats.csv).  Prints ms per forward (HIP events)."""
+trace (tools/gpu_r5_evidence.sh -> profiles/r05_pnpp_forward_kernel_stats.csv).  Prints ms per forward (HIP events)."""
 import os
 import sys
 

@@ -10,6 +10,8 @@ import threading
 
 import torch
 
+from . import config
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TGN_LIB_PATH") or os.path.join(_HERE, "csrc", "libtgn_pointops.so")   # TGN_LIB_PATH: A/B builds (tools/)
 
@@ -245,7 +247,7 @@ def require_cuda(*tensors):
 #       take_index_error() reads the CURRENT stream's flag by hand at a synchronisation point; launches that ran on other
 #       streams (HotPath's three, a graph replayed elsewhere than it was captured) are covered by
 #       take_index_error_device(), which synchronises the device and reads every flag of it.
-INDEX_CHECK = os.environ.get("TGN_INDEX_CHECK", "sync").lower()
+#   The mode is config.cfg.index_check; _lib.INDEX_CHECK stays as a live alias of it.
 
 
 def take_index_error():
@@ -264,7 +266,7 @@ _check_state = threading.local()
 
 
 def _checking():
-    return INDEX_CHECK != "off" and not torch.cuda.is_current_stream_capturing()   # (a host read cannot be captured)
+    return config.cfg.index_check != "off" and not torch.cuda.is_current_stream_capturing()   # (a host read cannot be captured)
 
 
 def begin_index_check():
@@ -311,3 +313,6 @@ def as_int(v):
     if isinstance(v, torch.Tensor):
         return int(v.item())
     return int(v)
+
+
+config.legacy_attributes(__name__, {"INDEX_CHECK": "index_check"})

@@ -9,6 +9,13 @@ What differs is how the work is done: FPS, ball query, the gather+centre+concat 
 and three_interpolate are single HIP kernels (include/tgn_pointops.h section 3) instead of chains of
 torch kernels that materialise (B,S,N) matrices and sort them.  The shared MLPs stay nn.Conv/BatchNorm
 layers with the reference's parameter names, so state_dicts are interchangeable.
+
+Retained reference fallbacks.  About 25 lines of the reference's own torch logic live on here, on paths the fast kernels do
+not cover, because they ARE the semantics to preserve there: the three ``nn.Module`` constructors (sub-module names and order
+decide the state_dict keys), the train-mode tails ``F.relu(bn(conv(x)))`` of the set-abstraction / feature-propagation
+stacks (pointnet2_utils.py:229-236, :289-294, :345-351 -- BatchNorm needs batch statistics there), the general-C form of
+``square_distance`` (:36-40; the kernel covers C = 3) and the sort-based three-nearest-neighbour weights for DIFFERENTIABLE
+coordinates (:333-340; no reference model has them).  Everything on the eval and C = 3 paths is this package's own.
 """
 import os
 from time import time
@@ -19,7 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.autograd import Function
 
-from . import _derived, _lib
+from . import _derived, _lib, config
 from . import _fps_prefix
 from ._fps_prefix import PrefixBook
 from ._lib import as_int, check, lib, ptr, require_cuda, stream
@@ -413,16 +420,16 @@ def three_interpolate(points2, dist, idx):
 # ---------------------------------------------------------------------------------------------
 # fused set abstraction (eval mode): the first shared-MLP layer without the grouped (B,S,K,3+D) tensor
 # ---------------------------------------------------------------------------------------------
-FUSED_SA = os.environ.get("TGN_FUSED_SA", "1") != "0"
-COMMUTE_FP = os.environ.get("TGN_COMMUTE_FP", "1") != "0"   # feature propagation: first convolution on the coarse points (below)
-# second layer of the chained set-abstraction kernel on the bf16 matrix cores at fp32 accuracy (three-way bf16 split of both operands,
-# six products: include/tgn_pointops.h, tgn_sa_mlp2_max_bf16x3); 0: the exact-fp32 MFMA form
-SA_BF16X3 = os.environ.get("TGN_SA_BF16X3", "1") != "0"
+# The switches of this module live in toothgroupnetwork_amd.config (cfg.fused_sa, cfg.commute_fp -- feature propagation: first
+# convolution on the coarse points, below --, cfg.sa_bf16x3 -- second layer of the chained set-abstraction kernel on the bf16 matrix
+# cores at fp32 accuracy: three-way bf16 split of both operands, six products, include/tgn_pointops.h tgn_sa_mlp2_max_bf16x3; False:
+# the exact-fp32 MFMA form).  FUSED_SA / COMMUTE_FP / SA_BF16X3 remain as live aliases of those fields (reads and writes).
+config.legacy_attributes(__name__, {"FUSED_SA": "fused_sa", "COMMUTE_FP": "commute_fp", "SA_BF16X3": "sa_bf16x3"})
 
 
 def _can_fuse(module, *tensors):
     """Eval-mode, no autograd through the inputs: BatchNorm is a fixed affine map and can be folded."""
-    if not FUSED_SA or module.training:
+    if not config.cfg.fused_sa or module.training:
         return False
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
         return False
@@ -593,11 +600,11 @@ def sa_level_mlp2_max(xyz, new_xyz, points, idx, convs, bns, xyz_first, out=None
         f = fold_first_layer(convs[0], bns[0], D, xyz_first)
         C1p = (f["C1"] + 15) // 16 * 16
         W2f, b2 = fold_second_layer(convs[1], bns[1], C1p)
-        return dict(C1p=C1p, W2f=W2f, b2=b2, b1=_pad_cols(f["b2"], C1p), W2s=split_second_layer(W2f) if SA_BF16X3 else None,
+        return dict(C1p=C1p, W2f=W2f, b2=b2, b1=_pad_cols(f["b2"], C1p), W2s=split_second_layer(W2f) if config.cfg.sa_bf16x3 else None,
                     W1=_pad_cols(f["Wd"] if direct else f["Wxs"], C1p),      # direct: (16, C1p) rows [x, y, z, features..., 0]
                     Wt=None if direct else _pad_cols(f["Wt"], C1p),
-                    Wts=split_point_transform(_pad_cols(f["Wt"], C1p)) if (SA_BF16X3 and not direct) else None)
-    ops = _derived.cached(bns[1], "mlp2", _derived.sources(convs[0], bns[0], convs[1], bns[1]), (D, bool(xyz_first), direct, SA_BF16X3),
+                    Wts=split_point_transform(_pad_cols(f["Wt"], C1p)) if (config.cfg.sa_bf16x3 and not direct) else None)
+    ops = _derived.cached(bns[1], "mlp2", _derived.sources(convs[0], bns[0], convs[1], bns[1]), (D, bool(xyz_first), direct, config.cfg.sa_bf16x3),
                           operands)
     C1p, W2f, b2, b1, W1 = ops["C1p"], ops["W2f"], ops["b2"], ops["b1"], ops["W1"]
     C2 = b2.shape[0]
@@ -818,7 +825,7 @@ class PointNetFeaturePropagation(nn.Module):
         B, N, C = xyz1.shape
         _, S, _ = xyz2.shape
 
-        if (COMMUTE_FP and S > 1 and S < N and len(self.mlp_convs) > 0 and not (xyz1.requires_grad or xyz2.requires_grad)
+        if (config.cfg.commute_fp and S > 1 and S < N and len(self.mlp_convs) > 0 and not (xyz1.requires_grad or xyz2.requires_grad)
                 and points2.dtype == torch.float32):
             # The first 1x1 convolution commutes with the interpolation (a weighted sum whose weights do not depend on the
             # features): W * [p1, sum_i w_i f2[idx_i]] + b = W1 * p1 + sum_i w_i (W2 * f2)[idx_i] + b.  The coarse features are

@@ -15,7 +15,7 @@ import torch
 from torch.autograd import Function
 from torch.utils.weak import WeakTensorKeyDictionary
 
-from . import _lib
+from . import _lib, config
 from . import _fps_prefix
 from ._fps_prefix import PrefixBook
 from ._lib import as_int, check, lib, ptr, require_cuda, stream
@@ -175,7 +175,7 @@ def _knn_raw(nsample, xyz, new_xyz, offset, new_offset):
     idx = torch.empty(m, nsample, dtype=torch.int32, device=xyz.device)
     dist2 = torch.empty(m, nsample, dtype=torch.float32, device=xyz.device)
     b, n = offset.shape[0], xyz.shape[0]
-    if KNN_GRID and nsample <= 63 and b > 0 and n >= KNN_GRID_MIN_POINTS * b:
+    if config.cfg.knn_grid and nsample <= 63 and b > 0 and n >= config.cfg.knn_grid_min_points * b:
         # big segments: per-segment grids, a query looks at the cells around it (same result)
         nbytes = int(lib().tgn_knnquery_grid_workspace_bytes(b, n, m))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device) if nbytes else None
@@ -189,8 +189,9 @@ def _knn_raw(nsample, xyz, new_xyz, offset, new_offset):
     return idx, dist2
 
 
-KNN_GRID = os.environ.get("TGN_KNN_GRID", "1") != "0"
-KNN_GRID_MIN_POINTS = int(os.environ.get("TGN_KNN_GRID_MIN", "3000"))   # average points per segment
+# cfg.knn_grid / cfg.knn_grid_min_points (average points per segment) / cfg.knn_cache_size: toothgroupnetwork_amd.config; the
+# module-level names of rounds 1-4 stay as live aliases
+config.legacy_attributes(__name__, {"KNN_GRID": "knn_grid", "KNN_GRID_MIN_POINTS": "knn_grid_min_points", "_KNN_CACHE_SIZE": "knn_cache_size"})
 
 
 # kNN memo.  The reference recomputes identical neighbour lists again and again: PointTransformerLayer calls
@@ -201,11 +202,10 @@ KNN_GRID_MIN_POINTS = int(os.environ.get("TGN_KNN_GRID_MIN", "3000"))   # averag
 # without a version counter (torch.inference_mode) bypass the memo.  Writes that torch cannot see -- through
 # `.data`, raw pointers, the pointops_cuda shim -- do not bump the version: call knn_cache_clear() after them.
 _KNN_CACHE = OrderedDict()
-_KNN_CACHE_SIZE = int(os.environ.get("TGN_KNN_CACHE", "16"))
 
 
 def _knn_cached(nsample, xyz, new_xyz, offset, new_offset):
-    if _KNN_CACHE_SIZE <= 0:
+    if config.cfg.knn_cache_size <= 0:
         return _knn_raw(nsample, xyz, new_xyz, offset, new_offset)
     tensors = (xyz, xyz if new_xyz is None else new_xyz, offset, new_offset)
     try:
@@ -220,7 +220,7 @@ def _knn_cached(nsample, xyz, new_xyz, offset, new_offset):
         return hit[1], hit[2]
     idx, dist2 = _knn_raw(nsample, xyz, new_xyz, offset, new_offset)
     _KNN_CACHE[key] = (tensors, idx, dist2)
-    while len(_KNN_CACHE) > _KNN_CACHE_SIZE:
+    while len(_KNN_CACHE) > config.cfg.knn_cache_size:
         _KNN_CACHE.popitem(last=False)
     return idx, dist2
 
