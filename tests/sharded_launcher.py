@@ -20,4 +20,4 @@ if __name__ == "__main__":
     spec = importlib.util.spec_from_file_location("preprocess_sharded", os.path.join(REPO, "tools", "preprocess_sharded.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    mod.main(sys.argv[1:], fps_batch=oracle_fps_batch)
+    mod.main(sys.argv[1:], fps_batch=oracle_fps_batch, script=os.path.abspath(__file__))

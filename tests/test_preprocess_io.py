@@ -167,6 +167,24 @@ def test_sharded_runner_two_ranks_gloo(tmp_path, golden_r2):
     _check_outputs(str(tmp_path / "out"), golden_r2)
 
 
+def test_sharded_runner_starts_its_own_ranks_and_refuses_a_mismatch(tmp_path, golden_r2):
+    """`--gpus 2` without torchrun: the runner replaces itself by two ranks (toothgroupnetwork_amd.launch) and says who they were;
+    under torchrun with another rank count it exits non-zero instead of reporting a smaller job as the one asked for."""
+    write_dataset(str(tmp_path))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONDONTWRITEBYTECODE"] = "1"
+    args = [os.path.join(REPO, "tests", "sharded_launcher.py"), "--source_obj_data_path", str(tmp_path / "obj"), "--source_json_data_path",
+            str(tmp_path / "json"), "--save_data_path", str(tmp_path / "out"), "--backend", "gloo"]
+    out = subprocess.run([sys.executable] + args + ["--gpus", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["self_spawned"] is True and [r["rank"] for r in res["ranks"]] == [0, 1] and res["backend"] == "gloo"
+    _check_outputs(str(tmp_path / "out"), golden_r2)
+    bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29633"] + args + ["--gpus", "3"], capture_output=True, text=True, timeout=600, env=env)
+    assert bad.returncode != 0 and "refusing to report" in bad.stderr
+
+
 @pytest.mark.gpu
 def test_gpu_pipeline_writes_the_reference_files(dev, tmp_path, golden_r2, oracle):
     """the product path end to end on the GPU (batched FPS kernel): byte-identical .npy files; and the label transfer

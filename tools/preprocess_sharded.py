@@ -2,6 +2,7 @@
 """BASELINE.json config 5: preprocess_data.py over a directory of scans, sharded over the GPUs of one node.
 
     python tools/preprocess_sharded.py --source_obj_data_path OBJ --source_json_data_path JSON --save_data_path OUT
+    python tools/preprocess_sharded.py --gpus 8 --synthetic 512 --save_data_path /tmp/out      (starts its 8 ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \\
         tools/preprocess_sharded.py --synthetic 512 --save_data_path /tmp/out
 
@@ -17,7 +18,7 @@ import sys
 import tempfile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from toothgroupnetwork_amd import preprocess, sharding, synth  # noqa: E402
+from toothgroupnetwork_amd import launch, preprocess, sharding, synth  # noqa: E402
 
 
 def _write_one(job):
@@ -56,7 +57,7 @@ def write_synthetic(root, n, rank, world):
             raise RuntimeError("writing the synthetic scans failed")
 
 
-def main(argv=None, fps_batch=None):
+def main(argv=None, fps_batch=None, script=None):
     """fps_batch: the sampler handed to preprocess.preprocess_sharded (None = the GPU kernel, the only one this runner
     knows; tests of the control flow pass their own callable through tests/sharded_launcher.py)."""
     ap = argparse.ArgumentParser()
@@ -67,12 +68,18 @@ def main(argv=None, fps_batch=None):
     ap.add_argument("--batch", type=int, default=32, help="most scans per FPS launch (a launch costs ~50 ms whatever its size -- the sampling chain of one raw scan -- "
                     "so the loop takes what the loaders have ready, between a quarter of this and this)")
     ap.add_argument("--backend", default=None)
+    ap.add_argument("--gpus", type=int, default=0, help="ranks of this run: without torchrun the script starts them itself; a rank count "
+                    "other than this is an error (0: whatever the environment says -- the torchrun form of rounds 1-4)")
     args = ap.parse_args(argv)
+    if args.gpus and script is not False:
+        launch.ensure_ranks(args.gpus, script or os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv), backend=args.backend)
     if args.synthetic:                                          # (before the GPU / process group exist: it forks)
         root = os.environ.get("TGN_SYNTH_DIR") or os.path.join(tempfile.gettempdir(), f"tgn_synth_{args.synthetic}")
         env_rank, _, env_world = sharding.env_rank_world()
         write_synthetic(root, args.synthetic, env_rank, env_world)
     rank, local_rank, world, device = sharding.init_from_env(backend=args.backend)
+    if args.gpus:
+        launch.require_world(args.gpus, world)
     if args.synthetic:
         sharding.barrier()
         args.source_obj_data_path, args.source_json_data_path = os.path.join(root, "obj"), os.path.join(root, "json")
@@ -87,12 +94,11 @@ def main(argv=None, fps_batch=None):
         warm = time.perf_counter() - t0
     res = preprocess.preprocess_sharded(pairs, args.save_data_path, rank, world, batch=args.batch, fps_batch=fps_batch,
                                         device=device if device.type == "cuda" else None)
+    who = launch.describe_ranks(device)
     if rank == 0:
         print(json.dumps({"metric": "preprocessed scans/sec (OBJ parse + normals + FPS N_raw->24000 + npy)", "value": res["meshes_per_s"],
-                          "unit": "scans/s", "n_gpus": world, "gpu_warmup_s_excluded": round(warm, 3), **res}))
-    import torch.distributed as dist
-    if world > 1 and dist.is_initialized():
-        dist.destroy_process_group()
+                          "unit": "scans/s", "n_gpus": world, "gpu_warmup_s_excluded": round(warm, 3), **res, **who}))
+    launch.shutdown()
 
 
 if __name__ == "__main__":
