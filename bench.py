@@ -215,6 +215,9 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU implementation")
     launch.require_world(args.gpus, world)          # a rank count other than --gpus is an error (exit status 2), never a warning
+    # host threads: the cores this rank can really use (a 128-thread host under a 16-core quota runs small CPU ops 10x slower on 128
+    # threads than on 16; torchrun's children get OMP_NUM_THREADS=1 anyway)
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), sharding.cpus_for_this_rank(int(os.environ.get("LOCAL_WORLD_SIZE", world))))))
     who = launch.describe_ranks(device)             # per-rank device records + backend + RCCL version (set-up time, untimed)
     B = args.batch
     shape = hotpath.SHAPE_A if args.shape == "A" else hotpath.SHAPE_B

@@ -57,6 +57,10 @@ def main(argv=None, step_factory=None, script=None):
                         backend=args.backend)
     rank, local_rank, world, device = sharding.init_from_env(backend=args.backend)
     launch.require_world(args.gpus, world)
+    import torch
+    # host threads of this rank: its share of the cores it can really use (torchrun sets OMP_NUM_THREADS=1 for its children; a single
+    # process would otherwise run every small CPU op on one thread per hardware thread of the box)
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), sharding.cpus_for_this_rank(int(os.environ.get("LOCAL_WORLD_SIZE", world))))))
     if step_factory is None and device.type != "cuda":
         raise SystemExit("forward_sharded.py needs a ROCm GPU: the operators have no CPU implementation")
     root = args.input_data_dir_path

@@ -29,3 +29,8 @@ python tools/forward_sequence.py $(find $O/tr -name "*kernel_trace.csv" | head -
 cp $(find $O/tr -name "*kernel_stats.csv" | head -1) $O/pnpp_forward_kernel_stats.csv
 rm -rf $O/tr
 timeout 600 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 300 python tools/forward_sharded.py --gpus 1 --synthetic 32 --model pointnetpp 2>/dev/null | tail -1 | cut -c1-400 > $O/forward_sharded_1rank.json; cat $O/forward_sharded_1rank.json | cut -c1-300
+timeout 300 python tools/forward_sharded.py --gpus 2 --backend gloo --synthetic 32 --model pointnetpp 2>/dev/null | tail -1 | cut -c1-700 > $O/forward_sharded_2gloo_ranks_one_gpu.json; cut -c1-300 $O/forward_sharded_2gloo_ranks_one_gpu.json
+timeout 600 python bench.py --gpus 2 --backend gloo --steps 10 --warmup 3 --cpu-meshes 0 --secondary 0 2>/dev/null | tail -1 > $O/bench_2gloo_ranks_one_gpu.json; python -c "
+import json; d=json.load(open('$O/bench_2gloo_ranks_one_gpu.json')); print({k:d[k] for k in ('value','n_gpus','backend','self_spawned','distinct_devices')}, [ (r['rank'],r['device_index'],r['pci_bus_id']) for r in d['ranks']])"

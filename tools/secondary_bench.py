@@ -341,6 +341,8 @@ if __name__ == "__main__":
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     json_out = sys.argv[sys.argv.index("--json-out") + 1] if "--json-out" in sys.argv else None
+    from toothgroupnetwork_amd import sharding
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), sharding.effective_cpus())))   # (the CPU quota, not the hardware thread count)
 
     def _save(res):
         tmp = json_out + ".tmp"
