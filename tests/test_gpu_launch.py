@@ -69,3 +69,32 @@ def test_forward_sharded_two_ranks_equal_one_rank(dev, tmp_path, model):
     assert set(a["avg"]) == {"tooth_class_loss_1_val", "total_val"}
     for k in a["avg"]:
         assert a["avg"][k] > 0 and b["avg"][k] == pytest.approx(a["avg"][k], rel=1e-6)
+
+
+def test_rccl_initialises_and_runs_the_metric_gather_with_one_rank(dev):
+    """The boxes this suite runs on have one GPU, so the N > 1 tests above use gloo.  RCCL itself can still be brought up with ONE
+    rank: backend "nccl" (= RCCL on ROCm) initialised the way sharding.init_from_env does it (device_id), the collective of the
+    sharded runners (all_gather_into_tensor of an fp64 vector on the device), a barrier, and the rank record bench.py prints."""
+    code = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["TGN_REPO"])
+import torch, torch.distributed as dist
+from toothgroupnetwork_amd import launch
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+vec = torch.tensor([3.0, 0.25, 7.0], dtype=torch.float64, device=dev)
+out = torch.empty(3, dtype=torch.float64, device=dev)
+dist.all_gather_into_tensor(out, vec)
+dist.barrier()
+torch.cuda.synchronize()
+objs = [None]
+dist.all_gather_object(objs, {"rank": dist.get_rank()})
+print(json.dumps({"out": out.cpu().tolist(), "backend": str(dist.get_backend()), "rccl": launch.rccl_version(), "objs": objs}))
+dist.destroy_process_group()
+'''
+    env = {**ENV, "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29657", "TGN_REPO": REPO, "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = _json_line(out.stdout)
+    assert res["out"] == [3.0, 0.25, 7.0] and res["backend"] == "nccl" and res["rccl"] and res["objs"] == [{"rank": 0}]
