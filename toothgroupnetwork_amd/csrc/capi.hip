@@ -118,7 +118,7 @@ TGN_API int tgn_get_tuning(const char *key, int fallback) {
     return fallback;
 }
 
-TGN_API const char *tgn_version(void) { return "tgn_pointops 0.3.0 (gfx950)"; }
+TGN_API const char *tgn_version(void) { return "tgn_pointops 0.5.0 (gfx950)"; }
 TGN_API const char *tgn_last_error(void) { return tgn::g_error; }
 TGN_API void tgn_set_default_stream(tgn_stream_t stream) { tgn::g_default_stream = (hipStream_t)stream; }
 
