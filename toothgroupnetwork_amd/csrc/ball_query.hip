@@ -83,6 +83,7 @@ constexpr int kGridCells = 16384;   // cells per cloud (LDS histogram: 64 KiB)
 constexpr int kGridThreads = 1024;
 constexpr int kHitCap = 512;        // per-wave hit buffer (indices)
 constexpr int kGridMaxK = 256;
+constexpr int kGridPermCap = 32768;   // clouds up to here sort through an LDS permutation of 16-bit point numbers
 
 struct GridHeader {   // one per cloud, 64 bytes
     float lo[3];
@@ -118,6 +119,7 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 __global__ __launch_bounds__(kGridThreads) void ball_grid_build_kernel(int N, float r2, const float *__restrict__ xyz,
                                                                         unsigned char *__restrict__ ws) {
     __shared__ int cnt[kGridCells];
+    extern __shared__ unsigned short perm[];        // sorted position -> point: 2 N bytes of dynamic LDS for clouds of <= kGridPermCap points (step 4)
     __shared__ float red[7][kGridThreads / kWave];
     __shared__ int wave_tot[kGridThreads / kWave];
     __shared__ GridHeader hdr_s;
@@ -237,7 +239,26 @@ __global__ __launch_bounds__(kGridThreads) void ball_grid_build_kernel(int N, fl
     }
     if (tid == kGridThreads - 1) cell_start[kGridCells] = thread_base + sum;
     __syncthreads();
-    // 4. scatter (order inside a cell is arbitrary: the query kernel rank-selects by index)
+    // 4. scatter (order inside a cell is arbitrary: the query kernel rank-selects by index).
+    // Clouds of <= 32 768 points: the scatter goes into an LDS permutation (2 bytes per point) and the records are then written
+    // in sorted order -- whole lines, 16 B per lane -- with the coordinates gathered from the cloud (288 KB at 24 000 points: L2 /
+    // L1 hits).  Scattering the 16-byte records themselves wrote 225 MB per 256 scans for 98 MB of records: partially filled
+    // lines evicted and fetched again (profiles/r05_pmc_traffic.json).
+    if (N <= kGridPermCap) {
+        for (int k = tid; k < N; k += kGridThreads) {
+            const int cx = cell_coord(pts[(size_t)k * 3 + 0], h.lo[0], h.inv_h, h.g[0]);
+            const int cy = cell_coord(pts[(size_t)k * 3 + 1], h.lo[1], h.inv_h, h.g[1]);
+            const int cz = cell_coord(pts[(size_t)k * 3 + 2], h.lo[2], h.inv_h, h.g[2]);
+            perm[atomicAdd(&cnt[(cz * h.g[1] + cy) * h.g[0] + cx], 1)] = (unsigned short)k;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int pos = tid; pos < N; pos += kGridThreads) {
+            const int k = perm[pos];
+            rec[pos] = make_float4(pts[(size_t)k * 3 + 0], pts[(size_t)k * 3 + 1], pts[(size_t)k * 3 + 2], __int_as_float(k));
+        }
+        return;
+    }
     for (int k = tid; k < N; k += kGridThreads) {
         const float px = pts[(size_t)k * 3 + 0], py = pts[(size_t)k * 3 + 1], pz = pts[(size_t)k * 3 + 2];
         const int cx = cell_coord(px, h.lo[0], h.inv_h, h.g[0]);
@@ -692,7 +713,13 @@ static int ball_query_impl(int B, int N, int S, int nsample, float r2, const flo
     const bool grid = use_grid(N, S, nsample) && workspace && workspace_bytes >= (size_t)B * grid_cloud_bytes(N);
     if (grid) {
         if (build) {
-            hipLaunchKernelGGL(ball_grid_build_kernel, dim3(B), dim3(kGridThreads), 0, st, N, r2, xyz,
+            const size_t perm_bytes = N <= kGridPermCap ? ((size_t)N * 2 + 15) / 16 * 16 : 0;   // the LDS permutation of step 4
+            static bool attr_set = false;
+            if (!attr_set) {   // 64 KiB cell table + up to 64 KiB permutation: past the 64-KiB default of dynamic + static LDS
+                (void)hipFuncSetAttribute((const void *)ball_grid_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kGridPermCap * 2);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(ball_grid_build_kernel, dim3(B), dim3(kGridThreads), perm_bytes, st, N, r2, xyz,
                                (unsigned char *)workspace);
             if (int rc = check_launch("ball_grid_build_kernel")) return rc;
         }
