@@ -478,6 +478,19 @@ def test_three_nn_ties_and_small_support(dev, oracle):
     assert np.array_equal(d.cpu().numpy(), od) and np.array_equal(i.cpu().numpy(), oi)
 
 
+@pytest.mark.parametrize("B,N,S", [(1, 70, 17), (3, 333, 255), (2, 1000, 1023), (4, 512, 1024), (1, 64, 16), (2, 40000, 300)])
+def test_three_nn_both_kernels_against_the_oracle_with_ties(dev, oracle, B, N, S):
+    """few queries (B N <= 32 768, 16 <= S <= 1024): four waves share 64 queries and merge their top threes in wave order; many
+    queries: one thread per query.  Both must give the index-ordered scan's answer on lattices with duplicated points (exact ties)."""
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    rng = np.random.default_rng(B * 1000 + S)
+    xyz2 = (rng.integers(-4, 5, size=(B, S, 3)) * 0.125).astype(np.float32)          # coarse lattice: many equal distances, duplicates
+    xyz1 = (rng.integers(-8, 9, size=(B, N, 3)) * 0.0625).astype(np.float32)
+    d, i = U.three_nn(T(xyz1, dev), T(xyz2, dev))
+    od, oi = oracle.three_nn(xyz1, xyz2)
+    assert np.array_equal(d.cpu().numpy(), od) and np.array_equal(i.cpu().numpy(), oi)
+
+
 def test_three_interpolate_backward(dev):
     from toothgroupnetwork_amd import pointnet2_utils as U
     B, N, S, C = 2, 300, 50, 7

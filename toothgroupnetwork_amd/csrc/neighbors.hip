@@ -559,6 +559,81 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int B, int N, int S, cons
     }
 }
 
+// Few queries (the coarse levels of a feature-propagation stack: 4 096 - 8 192 queries against 256 - 512 support points): one query per
+// thread leaves a wave alone on its SIMD, paying an LDS round trip and a dependent chain per pair (~285 cycles each).  Here the FOUR
+// waves of a workgroup share 64 queries and scan a quarter of the support cloud each -- in ascending index ranges, wave w below wave
+// w + 1 --, park their top three in LDS, and wave 0 merges the twelve candidates by the same strict-'<' insertion in wave order: the
+// earlier index still wins ties, so the result is the one-thread scan's, bit for bit.  Single tile: S <= kTnnTile.
+template <typename IdxT>
+__global__ __launch_bounds__(256) void three_nn_split_kernel(int B, int N, int S, const float *__restrict__ xyz1,
+                                                              const float *__restrict__ xyz2, float *__restrict__ dist,
+                                                              IdxT *__restrict__ idx) {
+    __shared__ float4 tile[kTnnTile];
+    __shared__ float pd[4][3][kWave];
+    __shared__ int pi[4][3][kWave];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int q = blockIdx.x * kWave + lane;
+    const bool active = q < N;
+    float cx = 0.f, cy = 0.f, cz = 0.f, s1 = 0.f;
+    if (active) {
+        const float *c = xyz1 + ((size_t)b * N + q) * 3;
+        cx = c[0];
+        cy = c[1];
+        cz = c[2];
+        s1 = sumsq3(cx, cy, cz);
+    }
+    for (int i = threadIdx.x; i < S; i += blockDim.x) {
+        const float *p = xyz2 + ((size_t)b * S + i) * 3;
+        const float px = p[0], py = p[1], pz = p[2];
+        tile[i] = make_float4(px, py, pz, sumsq3(px, py, pz));
+    }
+    __syncthreads();
+    float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
+    int i0 = 0, i1 = 0, i2 = 0;
+    auto insert = [&](float d, int k) {   // strict '<' in ascending index order keeps the earlier index on ties
+        if (d < d2) {
+            if (d < d1) {
+                d2 = d1;
+                i2 = i1;
+                if (d < d0) {
+                    d1 = d0;
+                    i1 = i0;
+                    d0 = d;
+                    i0 = k;
+                } else {
+                    d1 = d;
+                    i1 = k;
+                }
+            } else {
+                d2 = d;
+                i2 = k;
+            }
+        }
+    };
+    const int part = (S + 3) / 4, lo = wv * part, hi = min(S, lo + part);
+    for (int i = lo; i < hi; ++i) {
+        const float4 p = tile[i];
+        insert(sqdist_expanded(cx, cy, cz, s1, p.x, p.y, p.z, p.w), i);
+    }
+    pd[wv][0][lane] = d0, pd[wv][1][lane] = d1, pd[wv][2][lane] = d2;
+    pi[wv][0][lane] = i0, pi[wv][1][lane] = i1, pi[wv][2][lane] = i2;
+    __syncthreads();
+    if (wv == 0 && active) {   // (my own three are already in place: the other nine follow in wave order)
+        for (int w = 1; w < 4; ++w)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) insert(pd[w][r][lane], pi[w][r][lane]);
+        const size_t o = ((size_t)b * N + q) * 3;
+        dist[o + 0] = d0;
+        dist[o + 1] = d1;
+        dist[o + 2] = d2;
+        idx[o + 0] = (IdxT)i0;
+        idx[o + 1] = (IdxT)i1;
+        idx[o + 2] = (IdxT)i2;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // square_distance (pointnet2_utils.py:20-41), C = 3.  HBM-bound on the (B,N,M) store: a thread owns
 // one dst column for kSqdRows src rows, so every store instruction writes 256 contiguous bytes per wave.
@@ -797,6 +872,16 @@ TGN_API int tgn_three_nn(int B, int N, int S, const float *xyz1, const float *xy
     if (S < 0 || !xyz1 || !xyz2 || !dist || !idx) {
         set_error("tgn_three_nn: bad argument");
         return TGN_ERR_INVALID_ARGUMENT;
+    }
+    if (S <= kTnnTile && S >= 16 && (long long)B * N <= 32768) {   // few queries: four waves per 64 queries (three_nn_split_kernel)
+        dim3 grid4((N + kWave - 1) / kWave, B);
+        if (idx_is_int64)
+            hipLaunchKernelGGL((three_nn_split_kernel<long long>), grid4, dim3(256), 0, (hipStream_t)stream, B, N, S, xyz1, xyz2, dist,
+                               (long long *)idx);
+        else
+            hipLaunchKernelGGL((three_nn_split_kernel<int>), grid4, dim3(256), 0, (hipStream_t)stream, B, N, S, xyz1, xyz2, dist,
+                               (int *)idx);
+        return check_launch("three_nn_split_kernel");
     }
     dim3 grid((N + 255) / 256, B);
     if (idx_is_int64)
