@@ -34,6 +34,21 @@ def test_bench_gpus_2_spawns_two_ranks_itself(dev):
     assert res["config"]["meshes_per_step_per_gpu"] == 16
 
 
+def test_bench_under_torchrun_the_drivers_form(dev):
+    """the command line the driver uses for N > 1 (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...), with gloo so that both ranks may share this box's one GPU"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29653", os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+           "--batch", "16", "--cpu-meshes", "0", "--secondary", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=ENV)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints ONE JSON line
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["self_spawned"] is False and res["scaling"] == "weak" and res["steps"] == 3
+    assert res["value"] == pytest.approx(16 * 3 * 2 / max(res["per_rank_seconds"]), rel=1e-6)    # whole-job rate over the slowest rank
+
+
 def test_bench_rank_mismatch_exits_nonzero(dev):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29651", os.path.join(REPO, "bench.py"), "--gpus", "4", "--backend", "gloo", "--steps", "1", "--warmup", "1",
