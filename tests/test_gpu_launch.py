@@ -46,7 +46,7 @@ def test_bench_under_torchrun_the_drivers_form(dev):
     assert len(lines) == 1                                   # rank 0 prints ONE JSON line
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["self_spawned"] is False and res["scaling"] == "weak" and res["steps"] == 3
-    assert res["value"] == pytest.approx(16 * 3 * 2 / max(res["per_rank_seconds"]), rel=1e-6)    # whole-job rate over the slowest rank
+    assert res["value"] == pytest.approx(16 * 3 * 2 / max(res["per_rank_seconds"]), rel=1e-3)    # whole-job rate over the slowest rank
 
 
 def test_bench_rank_mismatch_exits_nonzero(dev):

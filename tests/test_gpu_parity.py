@@ -970,3 +970,24 @@ def test_three_interpolate_with_fused_epilogue_equals_the_separate_passes(dev, C
     got = U.three_interpolate_add_relu(f2, dist, idx, add=buf, relu=True)
     assert got.data_ptr() == buf.data_ptr() and torch.equal(got, torch.relu(plain + add))
     assert torch.equal(U.three_interpolate_add_relu(f2, dist, idx.int(), add=add.clone()), plain + add)
+
+
+def test_linear_relu_epilogue_is_bit_identical_to_the_two_calls(dev):
+    """pointnet2_utils.linear_relu (feature-propagation tails and heads in eval mode): the GEMM with the ReLU in its epilogue equals
+    F.linear + relu_ bit for bit; non-contiguous rows and inputs that need grad take the two calls."""
+    import torch.nn.functional as F
+
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    g = torch.Generator().manual_seed(3)
+    for (B, N, K, C) in ((2, 3000, 256, 128), (1, 24000, 128, 32), (3, 77, 35, 17)):
+        x, W, b = torch.randn(B, N, K, generator=g).to(dev), torch.randn(C, K, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+        want = torch.relu(F.linear(x, W, b))
+        with torch.no_grad():
+            assert torch.equal(U.linear_relu(x, W, b), want)
+            xt = x.permute(0, 2, 1).contiguous().permute(0, 2, 1)            # same values, rows not contiguous: the two calls
+            assert torch.equal(U.linear_relu(xt, W, b), torch.relu(F.linear(xt, W, b)))   # (torch picks another GEMM for this layout)
+            torch.testing.assert_close(U.linear_relu(xt, W, b), want, rtol=1e-4, atol=1e-4)
+        xg = x.clone().requires_grad_()
+        y = U.linear_relu(xg, W, b)
+        y.sum().backward()
+        assert torch.equal(y.detach(), want) and xg.grad is not None

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 import functools
 
 from . import _derived, _lib, point_transformer as PT, pointops
-from .pointnet2_utils import PointNetFeaturePropagation, PointNetSetAbstraction, PointNetSetAbstractionMsg
+from .pointnet2_utils import PointNetFeaturePropagation, PointNetSetAbstraction, PointNetSetAbstractionMsg, linear_relu
 
 
 def _one_index_check(forward):
@@ -70,7 +70,7 @@ class PointNetPPSeg(nn.Module):
                 b1 = (conv1.bias.detach().float() * s + t).contiguous()
                 return W1, b1, conv2.weight.detach().squeeze(-1).float().contiguous(), conv2.bias.detach().float().contiguous()
             W1, b1, W2, b2 = _derived.cached(bn1, "head_eval", _derived.sources(conv1, bn1, conv2), None, fold)
-            y = torch.relu_(F.linear(x.permute(0, 2, 1), W1, b1))
+            y = linear_relu(x.permute(0, 2, 1), W1, b1)       # (ReLU in the GEMM's epilogue where the rows are contiguous)
             return F.linear(y, W2, b2).permute(0, 2, 1)
         return conv2(F.relu(bn1(conv1(x))))
 

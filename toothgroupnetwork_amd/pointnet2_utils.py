@@ -390,6 +390,17 @@ class _ThreeInterpolate(Function):
         return grad.view(B, S, C), None, None
 
 
+def linear_relu(x, W, b):
+    """relu(x @ W.T + b) over the last axis of contiguous fp32 rows, the ReLU in the GEMM's epilogue (hipBLASLt through
+    torch._addmm_activation: bit-identical to F.linear followed by relu_, one pass over the output less); any other input takes
+    those two calls."""
+    if (hasattr(torch, "_addmm_activation") and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and W.dtype == torch.float32
+            and b is not None and not (torch.is_grad_enabled() and (x.requires_grad or W.requires_grad or b.requires_grad))):
+        y = torch._addmm_activation(b, x.reshape(-1, x.shape[-1]), W.t(), use_gelu=False)
+        return y.view(*x.shape[:-1], W.shape[0])
+    return torch.relu_(F.linear(x, W, b))
+
+
 def three_interpolate_add_relu(points2, dist, idx, add=None, relu=False):
     """[relu](three_interpolate(points2, dist, idx) (+ add)) in ONE kernel, no autograd: the epilogue of the eval-mode feature
     propagation (first convolution commuted onto the coarse points; `add` = the skip features' share of that convolution plus the
@@ -861,7 +872,7 @@ class PointNetFeaturePropagation(nn.Module):
                 skip = F.linear(points1.permute(0, 2, 1), W0[:, :D1]) if points1 is not None else None
                 y = three_interpolate_add_relu(coarse, dist, idx, add=skip, relu=True)      # (B, N, C1)
                 for Wi, bi in layers[1:]:
-                    y = torch.relu_(F.linear(y, Wi, bi))
+                    y = linear_relu(y, Wi, bi)
                 return y.permute(0, 2, 1)
             y = three_interpolate(F.linear(points2, W[:, D1:]), dist, idx)      # (B, N, C1)
             if points1 is not None:
