@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.autograd import Function
 
-from . import _derived, _lib, pointops
+from . import _derived, _lib, pointnet2_utils as _U, pointops
 from ._lib import check, lib, ptr, stream
 
 _fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
@@ -247,6 +247,10 @@ def mlp_eval(seq, x):
     while i < len(layers):
         m = layers[i]
         if isinstance(m, nn.Linear) and i + 1 < len(layers) and isinstance(layers[i + 1], nn.BatchNorm1d):
+            if i + 2 < len(layers) and isinstance(layers[i + 2], nn.ReLU) and not x.requires_grad:
+                x = _U.linear_relu(x, *folded_linear(m, layers[i + 1]))      # the ReLU in the GEMM's epilogue: one launch
+                i += 3
+                continue
             x = F.linear(x, *folded_linear(m, layers[i + 1]))
             i += 2
         elif isinstance(m, nn.ReLU):
@@ -374,7 +378,7 @@ class TransitionDown(nn.Module):
         p, x, o = pxo  # (n, 3), (n, c), (b)
         if self.stride == 1:
             if _frozen(self, x) and x.dtype == torch.float32:
-                return [p, torch.relu_(F.linear(x, *folded_linear(self.linear, self.bn))), o]
+                return [p, _U.linear_relu(x, *folded_linear(self.linear, self.bn)), o]
             return [p, bn_rows(self.bn, _lin(self.linear, x), relu=True), o]
         pre, self._presampled = getattr(self, "_presampled", None), None
         if pre is not None and pre[0] is p and pre[1] is o:
@@ -458,7 +462,7 @@ class PointTransformerBlock(nn.Module):
         identity = x
         if _frozen(self, x) and x.dtype == torch.float32:
             # eval: bn1 / bn3 folded into their linears (a GEMM with bias each), bn2 one fused normalisation kernel
-            x = torch.relu_(F.linear(x, *folded_linear(self.linear1, self.bn1)))
+            x = _U.linear_relu(x, *folded_linear(self.linear1, self.bn1))
             x = self.transformer2([p, x, o], post_bn=self.bn2)
             x = F.linear(x, *folded_linear(self.linear3, self.bn3)).add_(identity)
             return [p, torch.relu_(x), o]
