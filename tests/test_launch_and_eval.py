@@ -91,6 +91,22 @@ def test_forward_sharded_two_gloo_ranks_equal_the_serial_loop(tmp_path, how):
         assert res["avg"][k] == pytest.approx(v, rel=1e-12, abs=1e-12)
 
 
+def test_forward_sharded_more_ranks_than_scans(tmp_path):
+    """one scan, two ranks: rank 1's shard is empty -- its vector is all zeros, the schema is still the step's fixed key tuple, and
+    the averages are the one scan's"""
+    from toothgroupnetwork_amd import eval_sharded
+    root = str(tmp_path / "pre")
+    eval_sharded.write_synthetic_preprocessed(root, 1, n_points=400)
+    want, n = _serial(root)
+    out = subprocess.run([sys.executable, LAUNCHER, "--gpus", "2", "--backend", "gloo", "--input_data_dir_path", root],
+                         capture_output=True, text=True, timeout=600, env=ENV)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = _json_line(out.stdout)
+    assert n == 1 and res["scans"] == 1 and res["per_rank_steps"] == [1, 0]
+    for k, v in want.items():
+        assert res["avg"][k] == pytest.approx(v, rel=1e-12, abs=1e-12)
+
+
 def test_forward_sharded_rank_mismatch_is_an_error(tmp_path):
     from toothgroupnetwork_amd import eval_sharded
     root = str(tmp_path / "pre")
