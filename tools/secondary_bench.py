@@ -143,8 +143,11 @@ def fps_large(device):
         ms = _events(run, 3, 1)
         out[f"{nscan}_scan{'s' if nscan > 1 else ''}"] = dict(
             value=nscan * 1e3 / ms, unit="scans/s", ms=ms,
-            roofline=_roof("latency", 1e3 * ms / 23999, None, "us per FPS iteration", hbm_algorithmic_GBs=(12 * 100000 + 96000) * nscan / ms / 1e6,
-                           note="serial chain of 23 999 block-wide arg-maxes per scan, one workgroup per scan out of an L2-resident workspace"))
+            roofline=dict(_roof("latency", 1e3 * ms / 23999, fps_floor_us(), "us per FPS iteration (frac = floor / achieved)",
+                                hbm_algorithmic_GBs=(12 * 100000 + 96000) * nscan / ms / 1e6,
+                                note="serial chain of 23 999 block-wide arg-maxes per scan, one workgroup per scan out of an L2-resident workspace; "
+                                     "peak = the dependent chain of one iteration with the data work removed (tools/fps_floor.hip)"),
+                          frac=(fps_floor_us() / (1e3 * ms / 23999)) if fps_floor_us() else None))
     return dict(config="tgn_furthestsampling_dense_ws 100 000 -> 24 000 points (large-cloud owner-wave bucket kernel)", **out)
 
 
@@ -160,9 +163,13 @@ def pt_forward(device):
     out.update(_graph_ms(lambda x: net([x]), inp))
     if "graph_ms" in out:
         out["graph_scans_per_s"] = 1e3 / out["graph_ms"]
-    out["roofline"] = _roof("latency", out.get("graph_ms", eager), None, "ms per forward",
-                            note="the 24 000 -> 6000 sampling chain (5 999 serial arg-maxes in one workgroup, ~4.8 ms) is the floor of a "
-                                 "single-scan forward; the rest is ~350 small launches")
+    floor_ms = 5999 * fps_floor_us() * 1e-3 if fps_floor_us() else None
+    best = out.get("graph_ms", eager)
+    out["roofline"] = dict(_roof("latency", best, floor_ms, "ms per forward (frac = floor / achieved)",
+                                 note="a single-scan forward is bound by its sampling chain: 24 000 -> 6000 = 5 999 serial block-wide arg-maxes in one "
+                                      "workgroup (the coarser levels sample an FPS result: identity, certificate checked on the device); peak = those "
+                                      "iterations at the measured chain floor (tools/fps_floor.hip); the rest is ~330 small launches"),
+                           frac=(floor_ms / best) if floor_ms else None)
     return out
 
 
@@ -293,6 +300,21 @@ def gather_family(device, n=24000, ns=36, c=32, wc=4, k=3, m_coarse=6000, batch_
         rate = cnt / (out[name]["us"] * 1e-6) / 1e9
         out[name]["roofline_atomic"] = _roof("l2_atomic", rate, floor.get("line_gatomics_per_s"), "G dword-atomics/s", atomics_per_launch=cnt)
     return out
+
+
+_FPS_FLOOR = {}
+
+
+def fps_floor_us():
+    """us per FPS iteration of the dependent chain alone (tools/fps_floor.hip), measured once per process; None if the tool is missing"""
+    if "v" not in _FPS_FLOOR:
+        import subprocess
+        try:
+            r = subprocess.run([os.path.join(REPO, "tools", "_bin", "fps_floor"), "--json"], capture_output=True, text=True, timeout=120)
+            _FPS_FLOOR["v"] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["fps_floor"]["chain_us"]
+        except Exception:  # noqa: BLE001
+            _FPS_FLOOR["v"] = None
+    return _FPS_FLOOR["v"]
 
 
 def atomic_floor():
