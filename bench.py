@@ -35,12 +35,15 @@ import torch  # noqa: E402
 
 from toothgroupnetwork_amd import hotpath, launch, sharding, synth  # noqa: E402
 
+METRIC = "meshes/sec (24k-pt FPS+ball_query+group fwd)"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured-achievable
 
 
-def make_inputs(B, device, seed, shape):
-    """B synthetic 24 000-point scans (xyz + normals) and synthetic level-2/3 features, resident in HBM."""
-    n_unique = min(B, 16)  # 16 distinct arch scans, tiled: generation cost stays bounded
+def make_inputs(B, device, seed, shape, unique=0):
+    """B synthetic 24 000-point scans (xyz + normals) and synthetic level-2/3 features, resident in HBM.  Every scan of the batch is
+    a distinct draw (FPS is data dependent and a step ends with its slowest workgroup: the maximum over B draws, not over a
+    few repeated ones); `unique` > 0 tiles that many distinct scans instead (rounds 1-5 used 16: generation is ~20 ms per scan)."""
+    n_unique = min(B, unique) if unique > 0 else B
     scans = synth.scan_batch(n_unique, shape["n"], "arch", seed=seed)
     scans = np.concatenate([scans] * ((B + n_unique - 1) // n_unique), axis=0)[:B]
     pts = torch.from_numpy(scans).to(device)
@@ -178,12 +181,21 @@ def run_secondary(timeout_s):
             pass
 
 
+def single_gpu_legs_only(args, world):
+    """N > 1 measures the headline and nothing else: the CPU baseline, the secondary configurations and the prefix-identity
+    re-run are single-GPU legs (they would run on rank 0 while the other ranks wait in a collective)"""
+    if world > 1:
+        args.secondary, args.cpu_meshes, args.no_alt = 0, 0, True
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="scans per step per GPU (one FPS workgroup per scan)")
+    ap.add_argument("--unique", type=int, default=0, help="distinct synthetic scans per batch (0 = all of them distinct, the default; "
+                    "16 = what rounds 1-5 tiled to 256)")
     ap.add_argument("--cpu-meshes", type=int, default=-1, help="CPU-baseline sample size (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-stride", type=int, default=4, help="per-kernel HIP events on every n-th timed step (each event is a barrier "
@@ -209,27 +221,32 @@ def main(argv=None):
     args = ap.parse_args(argv)
 
     if argv is None:
-        # `python bench.py --gpus N` (no torchrun): this process replaces itself by N ranks of the same command line
-        launch.ensure_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:], backend=args.backend)
-    rank, local_rank, world, device = sharding.init_from_env(backend=args.backend)
+        # `python bench.py --gpus N` (no torchrun): this process runs N ranks of the same command line under torchrun and exits with
+        # their status (asking for more GPUs than the node has: the error line, status 2)
+        launch.ensure_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:], backend=args.backend, metric=METRIC)
+    launch.begin(METRIC)                            # this rank's status record; on rank 0 the watcher that guarantees ONE JSON line
+    launch.require_world(args.gpus, sharding.env_rank_world()[2])    # a rank count other than --gpus is an error (status 2), never a warning
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU implementation")
-    launch.require_world(args.gpus, world)          # a rank count other than --gpus is an error (exit status 2), never a warning
+        launch.fail("bench.py needs a ROCm GPU: the hot path has no CPU implementation", stage_name="spawn")
+    rank, local_rank, world, device = sharding.init_from_env(backend=args.backend)   # stages numa_pin, rccl_init (gloo if RCCL cannot come up)
     # host threads: the cores this rank can really use (a 128-thread host under a 16-core quota runs small CPU ops 10x slower on 128
     # threads than on 16; torchrun's children get OMP_NUM_THREADS=1 anyway)
     torch.set_num_threads(max(1, min(torch.get_num_threads(), sharding.cpus_for_this_rank(int(os.environ.get("LOCAL_WORLD_SIZE", world))))))
     who = launch.describe_ranks(device)             # per-rank device records + backend + RCCL version (set-up time, untimed)
     B = args.batch
     shape = hotpath.SHAPE_A if args.shape == "A" else hotpath.SHAPE_B
-    xyz, feats, scans = make_inputs(B, device, seed=100 + rank, shape=shape)
+    single_gpu_legs_only(args, world)
+    xyz, feats, scans = make_inputs(B, device, seed=100 + 1000 * rank, shape=shape, unique=args.unique)
     gopts = dict(fused=bool(args.fused), group_max_blocks=args.group_max_blocks)
     hp = hotpath.HotPath(B, device, shape=shape, pipeline=bool(args.pipeline), fps_prefix=bool(args.fps_prefix), **gopts)
+    launch.stage("calibrate")
     for _ in range(max(args.warmup, 1)):                     # (the first run also measures the schedule's plan, hotpath.plan_schedule)
         hp.run(xyz, feats, inputs_on_current_stream=False)   # the synthetic scans are resident before any step
     torch.cuda.synchronize()
     if not args.no_kernel_timing:
         hp.enable_kernel_timing(args.steps, stride=max(args.timing_stride, 1))
 
+    launch.stage("timed")
     sharding.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -238,15 +255,17 @@ def main(argv=None):
     torch.cuda.synchronize()
     sharding.barrier()
     elapsed = time.perf_counter() - t0
+    launch.stage("gather", seconds=round(elapsed, 6))
     per_rank_s = sharding.gather_metrics([elapsed], device=device).reshape(-1).cpu().tolist()   # the one collective of the run
     elapsed = max(per_rank_s)
+    launch.stage("report")
 
     total_meshes = B * args.steps * world
     value = total_meshes / elapsed
     bytes_per_mesh, per_level = hotpath.algorithmic_bytes(fused=bool(args.fused), **shape)
 
     out = {
-        "metric": "meshes/sec (24k-pt FPS+ball_query+group fwd)",
+        "metric": METRIC,
         "value": value,
         "unit": "meshes/s",
         "n_gpus": world,
@@ -274,7 +293,7 @@ def main(argv=None):
                    **({"fused_levels": "the reference network's own set-abstraction stack (pointnet_pp.py:13-15): per branch a two-layer "
                                        "shared MLP [9->128->128, 259->256->512, 1027->784->1024], one chained kernel per branch, the "
                                        "branches written side by side; nothing of size S*K is written"} if (args.fused and args.shape == "B") else {}),
-                   "meshes_per_step_per_gpu": B, "sharding": f"independent meshes x {world} ranks, no data-path collective",
+                   "meshes_per_step_per_gpu": B, "distinct_scans_per_gpu": int(min(B, args.unique) if args.unique > 0 else B), "sharding": f"independent meshes x {world} ranks, no data-path collective",
                    "index_dtype": "int32",
                    "fps_levels_2_3": "identity shortcut (FPS of an FPS result; certificate checked on device)"
                    if args.fps_prefix else "iterated like level 1",
@@ -407,10 +426,9 @@ def main(argv=None):
         torch.cuda.empty_cache()
         out["secondary"] = run_secondary(args.secondary_timeout)
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+        launch.emit(out)
+    launch.shutdown()
 
 
 if __name__ == "__main__":
-    main()
+    launch.guard(main)

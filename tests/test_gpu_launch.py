@@ -55,7 +55,10 @@ def test_bench_rank_mismatch_exits_nonzero(dev):
            "--batch", "8", "--cpu-meshes", "0", "--secondary", "0"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=ENV)
     assert out.returncode != 0 and "refusing to report" in out.stderr
-    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # the error record -- never a 2-rank measurement under a 4-GPU label
+    res = json.loads(lines[0])
+    assert res["stage"] == "spawn" and "--gpus 4 but 2 rank(s)" in res["error"] and "value" not in res
 
 
 def test_bench_more_gpus_than_the_node_has_is_an_error(dev):
@@ -63,7 +66,11 @@ def test_bench_more_gpus_than_the_node_has_is_an_error(dev):
     n = torch.cuda.device_count() + 1
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1"],
                          capture_output=True, text=True, timeout=600, env=ENV)
-    assert out.returncode != 0 and f"--gpus {n}" in out.stderr
+    assert out.returncode == 2 and f"--gpus {n}" in out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # over-subscription: the error line, stage "spawn", nothing started
+    res = json.loads(lines[0])
+    assert res["stage"] == "spawn" and f"--gpus {n}" in res["error"] and res["n_gpus"] == n and res["ranks"] == []
 
 
 @pytest.mark.parametrize("model", ["pointnetpp", "pointtransformer"])

@@ -23,15 +23,16 @@ def test_ensure_ranks_spawns_only_when_needed():
     from toothgroupnetwork_amd import launch
     calls = []
     fake = lambda path, argv, env: calls.append((path, argv, env))   # noqa: E731
-    launch.ensure_ranks(1, "bench.py", ["--gpus", "1"], env={}, execv=fake)
-    launch.ensure_ranks(4, "bench.py", ["--gpus", "4"], env={"WORLD_SIZE": "4", "RANK": "0"}, execv=fake)
+    launch.ensure_ranks(1, "bench.py", ["--gpus", "1"], env={}, run=fake)
+    launch.ensure_ranks(4, "bench.py", ["--gpus", "4"], env={"WORLD_SIZE": "4", "RANK": "0"}, run=fake)
     assert calls == []                                   # one GPU, or already under torchrun: nothing to start
-    launch.ensure_ranks(4, "bench.py", ["--gpus", "4", "--steps", "3"], backend="gloo", env={"PATH": "/bin"}, execv=fake)
+    launch.ensure_ranks(4, "bench.py", ["--gpus", "4", "--steps", "3"], backend="gloo", env={"PATH": "/bin"}, run=fake)
     (path, argv, env), = calls
     assert path == sys.executable and argv[:3] == [sys.executable, "-m", "torch.distributed.run"]
     assert argv[argv.index("--nproc-per-node") + 1] == "4" and argv[argv.index("--master-addr") + 1] == "127.0.0.1"
     assert argv[-5:] == ["bench.py", "--gpus", "4", "--steps", "3"]
     assert env["TGN_SELF_SPAWNED"] == "1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["PATH"] == "/bin"
+    assert env["TGN_RUN_DIR"]                            # the ranks' status files and the supervisor meet there
 
 
 def test_require_world_is_an_error_not_a_warning(capsys):
@@ -51,7 +52,10 @@ def test_bench_refuses_a_rank_count_other_than_gpus():
            "--master-port", "29641", os.path.join(REPO, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--backend", "gloo"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=ENV)
     assert out.returncode != 0
-    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                               # ONE line also on failure: the error record, never a measurement
+    res = json.loads(lines[0])
+    assert res["stage"] == "spawn" and "error" in res and "value" not in res
 
 
 def _serial(root):
@@ -128,3 +132,34 @@ def test_loss_meter_and_print_dict_follow_the_reference():
     assert m.step_num == 2 and m.get_avg_results() == {"a_val": 2.0, "b_val": 2.0, "total_val": 4.0}
     m.init()
     assert m.step_num == 0 and m.loss_meter_dict == {}
+
+
+@pytest.mark.parametrize("net,prefix", [("PointNetPPSeg", "first_sem_model."), ("PointTransformerSeg", "first_ins_cent_model.")])
+def test_forward_sharded_loads_a_reference_style_checkpoint(tmp_path, net, prefix):
+    """the reference saves `self.module.state_dict()` of its wrapper module (base_model.py:33-37): the network's keys carry the
+    wrapper's attribute name (pointnet_pp.py:78, point_transformer.py:9) and the loss's buffers ride along as `criterion.*`;
+    tools/forward_sharded.py --checkpoint must load such a file into the bare network mirror, and a bare state_dict still loads"""
+    import importlib.util
+
+    import torch
+
+    from toothgroupnetwork_amd import eval_sharded, nets
+    torch.manual_seed(3)
+    src = getattr(nets, net)()
+    wrapped = {prefix + k: v.clone() for k, v in src.state_dict().items()}
+    wrapped["criterion.class_weight"] = torch.ones(17)
+    stripped = eval_sharded.reference_state_dict(wrapped)
+    assert set(stripped) == set(src.state_dict()) and eval_sharded.reference_state_dict(src.state_dict()) is not None
+    path = str(tmp_path / "ckpt.h5")
+    torch.save(wrapped, path)
+    spec = importlib.util.spec_from_file_location("forward_sharded", os.path.join(REPO, "tools", "forward_sharded.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    name = "pointnetpp" if net == "PointNetPPSeg" else "pointtransformer"
+    step = mod.build_step(name, torch.device("cpu"), checkpoint=path, seed=99)       # (seed 99: other weights unless the file is loaded)
+    for k, v in src.state_dict().items():
+        assert torch.equal(step.module.state_dict()[k], v), k
+    bare = str(tmp_path / "bare.h5")
+    torch.save(src.state_dict(), bare)
+    step = mod.build_step(name, torch.device("cpu"), checkpoint=bare, seed=98)
+    assert all(torch.equal(step.module.state_dict()[k], v) for k, v in src.state_dict().items())

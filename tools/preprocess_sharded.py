@@ -20,6 +20,8 @@ import tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from toothgroupnetwork_amd import launch, preprocess, sharding, synth  # noqa: E402
 
+METRIC = "preprocessed scans/sec (OBJ parse + normals + FPS N_raw->24000 + npy)"
+
 
 def _write_one(job):
     root, i = job
@@ -72,19 +74,22 @@ def main(argv=None, fps_batch=None, script=None):
                     "other than this is an error (0: whatever the environment says -- the torchrun form of rounds 1-4)")
     args = ap.parse_args(argv)
     if args.gpus and script is not False:
-        launch.ensure_ranks(args.gpus, script or os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv), backend=args.backend)
+        launch.ensure_ranks(args.gpus, script or os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv), backend=args.backend,
+                            metric=METRIC)
+    launch.begin(METRIC)
+    if args.gpus:
+        launch.require_world(args.gpus, sharding.env_rank_world()[2])
     if args.synthetic:                                          # (before the GPU / process group exist: it forks)
         root = os.environ.get("TGN_SYNTH_DIR") or os.path.join(tempfile.gettempdir(), f"tgn_synth_{args.synthetic}")
         env_rank, _, env_world = sharding.env_rank_world()
         write_synthetic(root, args.synthetic, env_rank, env_world)
     rank, local_rank, world, device = sharding.init_from_env(backend=args.backend)
-    if args.gpus:
-        launch.require_world(args.gpus, world)
     if args.synthetic:
         sharding.barrier()
         args.source_obj_data_path, args.source_json_data_path = os.path.join(root, "obj"), os.path.join(root, "json")
     pairs = preprocess.list_scans(args.source_obj_data_path, args.source_json_data_path)
     warm = 0.0
+    launch.stage("calibrate")
     if fps_batch is None and device.type == "cuda":
         # first use of the GPU by this process (context, code object, allocator) -- ~0.3 s that belong to no scan
         import time
@@ -92,14 +97,16 @@ def main(argv=None, fps_batch=None, script=None):
         t0 = time.perf_counter()
         resample.fps_batch([synth.arch_cloud(30000, seed=1, with_normals=False)], preprocess.N_SAMPLED)
         warm = time.perf_counter() - t0
+    launch.stage("timed")
     res = preprocess.preprocess_sharded(pairs, args.save_data_path, rank, world, batch=args.batch, fps_batch=fps_batch,
                                         device=device if device.type == "cuda" else None)
+    launch.stage("report")
     who = launch.describe_ranks(device)
     if rank == 0:
-        print(json.dumps({"metric": "preprocessed scans/sec (OBJ parse + normals + FPS N_raw->24000 + npy)", "value": res["meshes_per_s"],
-                          "unit": "scans/s", "n_gpus": world, "gpu_warmup_s_excluded": round(warm, 3), **res, **who}))
+        launch.emit({"metric": METRIC, "value": res["meshes_per_s"],
+                     "unit": "scans/s", "n_gpus": world, "gpu_warmup_s_excluded": round(warm, 3), **res, **who})
     launch.shutdown()
 
 
 if __name__ == "__main__":
-    main()
+    launch.guard(main)

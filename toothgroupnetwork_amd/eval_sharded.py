@@ -21,7 +21,7 @@ import time
 import numpy as np
 import torch
 
-from . import sharding
+from . import launch, sharding
 
 
 class LossMeter:
@@ -102,27 +102,64 @@ class PointTransformerStep(_ClassStep):
         super().__init__(module, device, weight=weight, output_index=0)
 
 
+def reference_state_dict(state):
+    """A checkpoint the reference wrote holds `self.module.state_dict()` of its wrapper module (base_model.py:33-37), whose
+    network sits under `first_sem_model.` (pointnet_pp.py:78) or `first_ins_cent_model.` (point_transformer.py:9) next to the
+    loss's `criterion.*` entries; the network mirrors here (nets.py) are the bare networks.  Strips that prefix and drops the
+    criterion entries; a state_dict of a bare network passes through unchanged."""
+    prefixes = ("first_sem_model.", "first_ins_cent_model.")
+    if not any(k.startswith(prefixes) for k in state):
+        return state
+    out = {}
+    for k, v in state.items():
+        if k.startswith("criterion."):
+            continue
+        for p in prefixes:
+            if k.startswith(p):
+                k = k[len(p):]
+                break
+        out[k] = v
+    return out
+
+
 def eval_sharded(paths, step, rank, world, device=None, load=load_item):
     """Trainer.test's loop over this rank's share of `paths` and the one gather.  Returns, on every rank,
     {"avg": LossMeter averages over ALL scans, "steps": scans evaluated, "per_rank_steps", "per_rank_seconds",
-     "scans_per_s": steps / slowest rank's seconds}."""
+     "scans_per_s": steps / slowest rank's seconds}.
+    A scan that fails on one rank (a load error, a step whose keys differ from its schema, a gather index out of range)
+    does not leave the other ranks waiting in the collective: the rank stops its loop, carries an error flag in the
+    gathered vector, and EVERY rank raises after the gather, naming the ranks that failed."""
     keys = tuple(step.keys)
     meter = LossMeter()
     mine = sharding.shard_indices(len(paths), rank, world, "round_robin")
     sharding.barrier()
     t0 = time.perf_counter()
+    failure = None
     for i in mine:
-        loss_map = step(i, load(paths[i]))
-        if tuple(sorted(loss_map)) != tuple(sorted(keys)):
-            raise KeyError(f"step returned keys {sorted(loss_map)}, its schema says {sorted(keys)}")
+        try:
+            loss_map = step(i, load(paths[i]))
+            if tuple(sorted(loss_map)) != tuple(sorted(keys)):
+                raise KeyError(f"step returned keys {sorted(loss_map)}, its schema says {sorted(keys)}")
+        except Exception as e:  # noqa: BLE001
+            failure = (i, e)
+            launch.note(scan_error=f"scan {i} ({os.path.basename(str(paths[i]))}): {type(e).__name__}: {str(e)[:200]}")
+            break
         meter.aggr(loss_map)
     if device is not None and device.type == "cuda":
-        torch.cuda.synchronize(device)
+        try:
+            torch.cuda.synchronize(device)
+        except Exception as e:  # noqa: BLE001
+            failure = failure or (-1, e)
     seconds = time.perf_counter() - t0
-    vec = [float(meter.step_num), seconds] + [float(meter.loss_meter_dict.get(k, 0.0)) for k in keys]
+    vec = [float(meter.step_num), seconds, 0.0 if failure is None else 1.0] + [float(meter.loss_meter_dict.get(k, 0.0)) for k in keys]
+    launch.stage("gather")
     mat = sharding.gather_metrics(vec, device=device).cpu()           # the one collective of the run
+    failed = [r for r in range(mat.shape[0]) if float(mat[r, 2]) != 0.0]
+    if failed:
+        mine_txt = f"; here: scan {failure[0]}: {type(failure[1]).__name__}: {failure[1]}" if failure is not None else ""
+        raise RuntimeError(f"evaluation failed on rank(s) {failed}{mine_txt}") from (failure[1] if failure is not None else None)
     steps = int(round(float(mat[:, 0].sum())))
-    sums = mat[:, 2:].sum(0).tolist()
+    sums = mat[:, 3:].sum(0).tolist()
     slowest = float(mat[:, 1].max())
     return {"avg": {k: (s / steps if steps else float("nan")) for k, s in zip(keys, sums)}, "steps": steps,
             "per_rank_steps": [int(round(v)) for v in mat[:, 0].tolist()],

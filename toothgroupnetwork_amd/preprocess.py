@@ -21,7 +21,7 @@ import time
 
 import numpy as np
 
-from . import _lib, sharding
+from . import _lib, launch, sharding
 
 Y_AXIS_MAX = 33.15232091532151       # preprocess_data.py:16-17
 Y_AXIS_MIN = -36.9843781139949
@@ -299,6 +299,7 @@ def preprocess_sharded(pairs, save_path, rank, world, batch=16, fps_batch=None, 
     t0 = time.perf_counter()
     st = preprocess_scans(mine, save_path, batch=batch, fps_batch=fps_batch)
     dt = time.perf_counter() - t0
+    launch.stage("gather")
     mat = sharding.gather_metrics([st["scans"], st["sampled"], st["points_in"], st["checksum"], dt, st["seconds_load"],
                                    st["seconds_fps"], st["batches"]], device=device).cpu().numpy()
     tot = mat.sum(0)

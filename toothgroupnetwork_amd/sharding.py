@@ -108,40 +108,179 @@ def cpus_for_this_rank(local_world, cgroup_root="/sys/fs/cgroup"):
     return max(n, 1)
 
 
-def pin_to_gpu_numa(device_index, sysfs="/sys/bus/pci/devices"):
+def cpulist_string(cpus):
+    """[0, 1, 2, 3, 8] -> '0-3,8' (the sysfs syntax parse_cpulist reads)"""
+    cpus = sorted(set(int(c) for c in cpus))
+    parts, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        parts.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(parts)
+
+
+def pin_record():
+    """what pin_to_gpu_numa did for this process: {"pinned": bool, "cpus": cpulist or None, "n": count, "reason": why not}
+    (bench.py / the sharded runners print it per rank)"""
+    return dict(_PIN.get("record", {"pinned": False, "cpus": None, "n": _affinity_count(), "reason": "not attempted (single rank or no GPU)"}))
+
+
+def pin_to_gpu_numa(device_index, sysfs="/sys/bus/pci/devices", bdf=None):
     """Restrict this process's host threads to the CPUs of the NUMA node its GPU hangs off (the PCI device's
     local_cpulist): one process per GPU on an 8-GPU node otherwise lets the OBJ parser / OpenMP threads of eight ranks
-    wander over both sockets (the preprocess runner is half host time).  Best effort: returns the CPU list, or None when
-    sysfs has no answer; TGN_NUMA_PIN=0 disables it."""
-    if os.environ.get("TGN_NUMA_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+    wander over both sockets (the preprocess runner is half host time).  Best effort and never fatal: returns the CPU
+    list, or None -- the affinity mask is then left as it was -- when sysfs has no answer or the node's CPUs do not
+    intersect the mask the process was given (a container pinned elsewhere); what happened is kept for pin_record().
+    TGN_NUMA_PIN=0 disables it."""
+    def give_up(reason):
+        _PIN["record"] = {"pinned": False, "cpus": None, "n": _affinity_count(), "reason": reason}
         return None
+
+    if os.environ.get("TGN_NUMA_PIN", "1") == "0":
+        return give_up("disabled (TGN_NUMA_PIN=0)")
+    if not hasattr(os, "sched_setaffinity"):
+        return give_up("no sched_setaffinity on this platform")
     try:
-        pr = torch.cuda.get_device_properties(device_index)
-        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
-        cpus = parse_cpulist(open(os.path.join(sysfs, bdf, "local_cpulist")).read())
+        if bdf is None:
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        text = open(os.path.join(sysfs, bdf, "local_cpulist")).read()
+        cpus = parse_cpulist(text)
         current = os.sched_getaffinity(0)
         allowed = sorted(set(cpus) & set(current))
         if not allowed:
-            return None
+            return give_up(f"local_cpulist of {bdf} ({text.strip() or 'empty'}) does not intersect the affinity mask "
+                           f"({cpulist_string(current)}): left unpinned")
         _PIN.setdefault("before", len(current))
         os.sched_setaffinity(0, allowed)
         _PIN["after"] = len(allowed)
+        _PIN["record"] = {"pinned": True, "cpus": cpulist_string(allowed), "n": len(allowed), "reason": None, "pci_bus_id": bdf}
         return allowed
-    except Exception:
-        return None
+    except Exception as e:  # noqa: BLE001
+        return give_up(f"{type(e).__name__}: {str(e)[:160]}")
 
 
-def init_from_env(backend=None):
+# the process group the ONE collective of a sharded run goes over, and how it came about
+_GROUP = {"backend": None, "note": None}
+
+
+def backend_description():
+    """"nccl", "gloo", or "gloo (rccl init failed: ...)" when the RCCL group could not be brought up and the <= 1 KB gather
+    runs over gloo instead (the data path has no collective: the measured throughput is the same run either way)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return "none (single process)"
+    b = _GROUP["backend"] or str(dist.get_backend())
+    return f"{b} ({_GROUP['note']})" if _GROUP["note"] else b
+
+
+def _agree(run_dir, name, rank, world, ok, timeout_s):
+    """file-based agreement of the node's ranks (no collective -- this runs when the collective layer is what failed):
+    every rank writes `<name>_<rank>` = "1" / "0" into the shared run directory and waits for all of them; returns the
+    list of flags, None for ranks that did not answer in time"""
+    import time
+    try:
+        with open(os.path.join(run_dir, f"{name}_{rank}.tmp"), "w") as f:
+            f.write("1" if ok else "0")
+        os.replace(os.path.join(run_dir, f"{name}_{rank}.tmp"), os.path.join(run_dir, f"{name}_{rank}"))
+    except OSError:
+        return [None] * world
+    deadline = time.time() + timeout_s
+    while True:
+        flags = []
+        for r in range(world):
+            try:
+                flags.append(open(os.path.join(run_dir, f"{name}_{r}")).read().strip() == "1")
+            except OSError:
+                flags.append(None)
+        if all(f is not None for f in flags) or time.time() > deadline:
+            return flags
+        time.sleep(0.05)
+
+
+def _init_rccl(rank, world, device, timeout):
+    """backend "nccl" with an eager communicator and one probe collective; raises whatever RCCL raises"""
+    dist.init_process_group(backend="nccl", rank=rank, world_size=world, timeout=timeout, device_id=device)
+    probe = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(probe)
+    torch.cuda.synchronize(device)
+    if int(probe.item()) != world:
+        raise RuntimeError(f"probe all_reduce over RCCL returned {probe.item()} instead of {world}")
+
+
+def _init_gloo(rank, world, timeout, run_dir=None, fallback=False):
+    """backend "gloo".  As the fallback of a failed RCCL init the rendezvous goes through a FileStore in the run directory:
+    the TCP store may be in whatever state the failed attempt left it in, and the ranks need not have failed at the same point"""
+    if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # (the container hostname may not resolve)
+    if fallback and run_dir:
+        store = dist.FileStore(os.path.join(run_dir, "gloo_fallback_store"), world)
+        dist.init_process_group(backend="gloo", store=store, rank=rank, world_size=world, timeout=timeout, group_name="tgn_gloo_fallback")
+    else:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=timeout)
+
+
+def bring_up_group(rank, world, device, backend, timeout_s):
+    """the process group of a sharded run (see init_from_env): RCCL with a time limit and a probe, gloo for everybody if RCCL
+    does not come up on every rank"""
+    import datetime
+
+    from . import launch
+    timeout = datetime.timedelta(seconds=timeout_s)
+    _GROUP["backend"], _GROUP["note"] = backend, None
+    if backend == "nccl":
+        launch.stage("rccl_init", dist_timeout_s=timeout_s)
+        why = None
+        try:
+            _init_rccl(rank, world, device, timeout)
+        except Exception as e:  # noqa: BLE001
+            why = f"{type(e).__name__}: {str(e).strip().splitlines()[-1] if str(e).strip() else ''}"[:240]
+        run_dir = launch.run_dir()
+        flags = _agree(run_dir, "rccl_ok", rank, world, why is None, timeout_s)
+        if not all(f is True for f in flags):
+            bad = [r for r, f in enumerate(flags) if f is not True]
+            if why is None:
+                why = f"rank(s) {bad} could not bring RCCL up"
+            launch.note(rccl_error=why, rccl_failed_ranks=bad)
+            if dist.is_initialized():
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+            launch.stage("gloo_init")
+            _init_gloo(rank, world, timeout, run_dir=run_dir, fallback=True)
+            _GROUP["backend"], _GROUP["note"] = "gloo", f"rccl init failed: {why}"
+    else:
+        launch.stage("gloo_init" if backend == "gloo" else "rccl_init", dist_timeout_s=timeout_s)
+        if backend == "gloo":
+            _init_gloo(rank, world, timeout)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
+    launch.stage("setup", backend=backend_description())
+
+
+def init_from_env(backend=None, timeout_s=None):
     """Initialise torch.distributed from the torchrun environment (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).
     Returns (rank, local_rank, world, device).  world == 1 needs no process group.  With several ranks on one node every
-    rank's host threads are pinned to its GPU's NUMA node (pin_to_gpu_numa)."""
+    rank's host threads are pinned to its GPU's NUMA node (pin_to_gpu_numa; best effort, recorded).
+
+    Backend "nccl" (RCCL; the default on GPUs) is brought up with a time limit (TGN_DIST_TIMEOUT_S, default 180 s) and probed
+    with one all_reduce.  If that raises on any rank, ALL ranks -- they agree through files in the run directory, not
+    through the layer that just failed -- drop it and bring up gloo instead; `backend_description()` then reads
+    "gloo (rccl init failed: ...)".  The sharded runners exchange nothing while computing and gather <= 1 KB at the end,
+    so the run and its throughput are the same; only the transport of that one vector differs.  A rank that cannot
+    join either group fails with stage "rccl_init" / "gloo_init" in its status record (launch.py)."""
+    from . import launch
     rank, local_rank, world = env_rank_world()
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
         device = torch.device("cuda", torch.cuda.current_device())
         if world > 1:
+            launch.stage("numa_pin")
             pin_to_gpu_numa(device.index)
+            launch.note(numa_pin=pin_record())
     else:
         device = torch.device("cpu")
     if world > 1 and not dist.is_initialized():
@@ -149,10 +288,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if use_cuda else "gloo"  # "nccl" is RCCL on ROCm
-        kwargs = {}
-        if use_cuda and backend == "nccl":
-            kwargs["device_id"] = device
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("TGN_DIST_TIMEOUT_S", "180"))
+        bring_up_group(rank, world, device, backend, timeout_s)
     return rank, local_rank, world, device
 
 
