@@ -323,6 +323,52 @@ def test_ball_query_dense_balls_and_large_clouds(dev, oracle):
         assert np.array_equal(got, want), (n, radius, ns)
 
 
+@pytest.mark.parametrize("variant", [2, 1, 0])
+def test_ball_query_every_grid_kernel_ragged_chunks_and_bad_queries(dev, oracle, variant):
+    """The three grid kernels (2: chunks of 16 queries, the default; 1: round 2's bitmap kernel; 0: rank-select) on shapes that
+    exercise the chunking: S not a multiple of 16, fewer queries than a chunk, many clouds (chunks never straddle two), every
+    bitmap size (N <= 8192, 16384, 24576, 32768), NaN / Inf queries in the middle of a chunk (index-order scan for those
+    queries only), a NaN point in one cloud of the batch (that cloud takes the scan path, its neighbours do not), K = 256."""
+    from toothgroupnetwork_amd import _lib, pointnet2_utils as U
+    with _lib.tuning(ball_bitmap=variant):
+        for B, n, S, radius, ns in [(3, 4096, 37, 0.1, 32), (9, 3000, 5, 0.15, 16), (2, 9000, 100, 0.08, 32), (1, 24000, 333, 0.05, 32),
+                                    (2, 20000, 64, 0.06, 64), (1, 32768, 130, 0.05, 32), (11, 2500, 17, 0.3, 256)]:
+            xyz = np.stack([synth.arch_cloud(n, 40 + b, False) for b in range(B)])
+            q = np.ascontiguousarray(xyz[:, :: max(n // S, 1)][:, :S]).copy()
+            assert q.shape[1] == S
+            got = U.query_ball_point(radius, ns, T(xyz, dev), T(q, dev)).cpu().numpy()
+            assert np.array_equal(got, oracle.query_ball_point(radius, ns, xyz, q)), (variant, B, n, S, "plain")
+            if S >= 5:
+                q[0, 1, 0] = np.nan
+                q[B - 1, S - 2, 2] = np.inf
+                q[0, 3] = 7.5                              # far outside the cloud: no hit -> N
+                got = U.query_ball_point(radius, ns, T(xyz, dev), T(q, dev)).cpu().numpy()
+                assert np.array_equal(got, oracle.query_ball_point(radius, ns, xyz, q)), (variant, B, n, S, "bad queries")
+            if B >= 2:
+                xyz[1, n // 2, 1] = np.nan
+                got = U.query_ball_point(radius, ns, T(xyz, dev), T(q, dev)).cpu().numpy()
+                assert np.array_equal(got, oracle.query_ball_point(radius, ns, xyz, q)), (variant, B, n, S, "NaN point")
+
+
+def test_ball_query_int32_rows_of_the_hot_path_equal_the_int64_rows(dev):
+    """the C entry point with idx_is_int64 = 0 (what hotpath.HotPath uses) against the int64 rows of the Python operator, through the
+    split build / prebuilt entry points, at the headline's level-1 and level-2 shapes"""
+    from toothgroupnetwork_amd import _lib, pointnet2_utils as U
+    L = _lib.lib()
+    for B, n, S, radius, ns in [(4, 24000, 4096, 0.05, 32), (4, 4096, 1024, 0.1, 32)]:
+        xyz = T(np.stack([synth.arch_cloud(n, 70 + b, False) for b in range(B)]), dev)
+        q = xyz[:, torch.randperm(n, generator=torch.Generator().manual_seed(1))[:S].to(dev)].contiguous()
+        want = U.query_ball_point(radius, ns, xyz, q)
+        nbytes = int(L.tgn_ball_query_workspace_bytes(B, n, S))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        got = torch.empty(B, S, ns, dtype=torch.int32, device=dev)
+        r2 = float(torch.tensor(radius ** 2, dtype=torch.float32).item())
+        st = _lib.stream()
+        _lib.check(L.tgn_ball_query_build(B, n, S, ns, r2, _lib.ptr(xyz), _lib.ptr(ws), nbytes, st), "build")
+        _lib.check(L.tgn_ball_query_prebuilt(B, n, S, ns, r2, _lib.ptr(xyz), _lib.ptr(q), _lib.ptr(got), 0, _lib.ptr(ws), nbytes, st), "query")
+        assert torch.equal(got.long(), want), (n, S)
+
+
 # ------------------------------------------------------------------- grouping / index_points / SA
 def test_sample_and_group_matches_golden(dev, golden):
     from toothgroupnetwork_amd import pointnet2_utils as U

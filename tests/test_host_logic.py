@@ -194,7 +194,8 @@ def test_the_phased_plan_follows_its_measurements():
     assert not H.plan_schedule(3.33, 3.25, 0.17, 3)["last_query_early"]        # no room left
     assert H.plan_schedule(3.33, 3.05, 0.15, 3)["last_query_early"]            # what the box measures for Shape A
     assert not H.plan_schedule(3.33, 0.1, 0.17, 1)["last_query_early"]         # a single level has nothing to move
-    assert H.plan_schedule(1.0, 0.5, 0.0, 2)["spacer_us"] == 0 and H.plan_schedule(9.0, 0.5, 2.0, 2)["spacer_us"] == 300
+    assert H.plan_schedule(1.0, 0.5, 0.0, 2)["spacer_us"] == 0 and H.plan_schedule(9.0, 0.5, 2.0, 2)["spacer_us"] == 600
+    assert H.plan_schedule(3.33, 2.95, 0.15, 3, grid_ms=0.16)["spacer_us"] == 250              # the grid build between phase 2 and FPS level 1
 
 
 def test_cpulist_parsing_and_numa_pinning_are_best_effort():
@@ -362,7 +363,7 @@ def test_tuning_table_round_trip_and_unknown_key():
     pack as nt * 256 + p, the context manager restores, an unknown key is an error (not silently a no-op)."""
     from toothgroupnetwork_amd import _lib
     L = _lib.lib()
-    for key, default in (("fps_plain", 0), ("fps_bucket_min", -1), ("fps_cell_bits", 4), ("ball_bitmap", 1), ("sa_tile", 0), ("knn_grid_scale", 1000), ("gather_v4", 5)):
+    for key, default in (("fps_plain", 0), ("fps_bucket_min", -1), ("fps_cell_bits", 4), ("ball_bitmap", 2), ("sa_tile", 0), ("knn_grid_scale", 1000), ("gather_v4", 5)):
         assert L.tgn_get_tuning(key.encode(), -12345) == default, key
     with _lib.tuning(fps_bucket_config=(512, 48), fps_plain=1):
         assert L.tgn_get_tuning(b"fps_bucket_config", 0) == 512 * 256 + 48

@@ -159,6 +159,85 @@ __global__ __launch_bounds__(NT) void fps_floor_kernel(const float *__restrict__
     }
 }
 
+// ---- the primitives alone ------------------------------------------------------------------------------------------------
+// What NO register-resident FPS with one workgroup per cloud can do without, per iteration: a value per lane that depends on the
+// previous winner (here: one subtract and one multiply), the 6-step DPP maximum of a wave, the lane that holds it (ballot, ctz), ONE
+// 8-byte record per wave {value bits, key}, ONE barrier, the 8 records read back, a 3-step DPP maximum, the winning wave (compare,
+// ctz), its key (one readlane), and only THEN the winner's coordinates: one 12-byte LDS read indexed by the key.  No box test, no
+// bucket metadata, no coordinates in the record, no result row.  The distance between this number and `chain` is what the production
+// kernel's bookkeeping costs on the chain (the box test in front, four readlanes + a 16-byte second record for the coordinates, the
+// result row); the distance between `chain` and production is the data work (bucket walk and refresh).
+__global__ __launch_bounds__(NT) void fps_primitive_kernel(const float *__restrict__ pts, int iters, float *__restrict__ out,
+                                                            unsigned long long *__restrict__ cycles) {
+    __shared__ uint2 rec[2][NW];
+    __shared__ float sx[NT * 3];
+    __shared__ unsigned pad[12 * 1024];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    if (tid == 0) pad[blockIdx.x & 1023] = 0u;
+    const float *pp = pts + ((size_t)(blockIdx.x & 7) * NW + wave) * kWave * 3 + lane * 3;
+    const float x0 = pp[0], y0 = pp[1];
+    sx[tid * 3 + 0] = pp[0];
+    sx[tid * 3 + 1] = pp[1];
+    sx[tid * 3 + 2] = pp[2];
+    __syncthreads();
+    float qx = 0.1f;
+    unsigned par = 0;
+    const long long c0 = clock64();
+    for (int j = 1; j < iters; ++j) {
+        const float d = x0 - qx;
+        const float v = d * d + y0 * 0.0f;                       // depends on the previous winner; >= 0
+        const float wm = wave_max_f32_dpp(v);
+        const unsigned long long eq = ballot64(v == wm);
+        const unsigned key = (unsigned)wave * kWave + (unsigned)__builtin_ctzll(eq);
+        rec[par][wave] = make_uint2(__float_as_uint(wm), key);   // (every lane writes the same 8 bytes)
+        __syncthreads();
+        const uint2 r0 = rec[par][lane & (NW - 1)];
+        par ^= 1u;
+        unsigned mb = r0.x;
+        asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                     : "+v"(mb));
+        mb = (unsigned)__builtin_amdgcn_readlane((int)mb, NW - 1);
+        const unsigned long long wmask = ballot64(r0.x == mb) & ((1ull << NW) - 1ull);
+        const unsigned kwin = (unsigned)__builtin_amdgcn_readlane((int)r0.y, (int)__builtin_ctzll(wmask));
+        qx = sx[kwin * 3 + 0] + sx[kwin * 3 + 1] * 0.0f + sx[kwin * 3 + 2] * 0.0f;   // the winner's coordinates: one dependent LDS read
+    }
+    const long long c1 = clock64();
+    __syncthreads();
+    if (tid == 0) {
+        out[blockIdx.x * 4 + 0] = qx + (float)pad[blockIdx.x & 1023];
+        cycles[blockIdx.x] = (unsigned long long)(c1 - c0);
+    }
+}
+
+static double run_primitive(int grid, int iters, const float *d_pts, float *d_out, unsigned long long *d_cyc, int reps, double *cyc_per_iter) {
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    std::vector<float> ms;
+    for (int r = 0; r < reps + 1; ++r) {
+        hipEventRecord(a, 0);
+        hipLaunchKernelGGL(fps_primitive_kernel, dim3(grid), dim3(NT), 0, 0, d_pts, iters, d_out, d_cyc);
+        hipEventRecord(b, 0);
+        hipEventSynchronize(b);
+        float t = 0;
+        hipEventElapsedTime(&t, a, b);
+        if (r) ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    std::vector<unsigned long long> cyc(grid);
+    hipMemcpy(cyc.data(), d_cyc, grid * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    unsigned long long mx = 0;
+    for (auto c : cyc) mx = std::max(mx, c);
+    *cyc_per_iter = (double)mx / (iters - 1);
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    return 1e3 * ms[ms.size() / 2] / (iters - 1);
+}
+
 static float frand(unsigned &s) {
     s = s * 1664525u + 1013904223u;
     return (float)(s >> 8) / 16777216.0f * 2.0f - 1.0f;
@@ -223,7 +302,9 @@ int main(int argc, char **argv) {
     hipMalloc(&d_cyc, 4096 * 8);
     hipMemcpy(d_boxes, boxes.data(), boxes.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(d_pts, pts.data(), pts.size() * 4, hipMemcpyHostToDevice);
-    double cy[4];
+    double cy[6];
+    const double prim_1 = run_primitive(1, iters, d_pts, d_out, d_cyc, reps, &cy[4]);
+    const double prim_n = run_primitive(ncu, iters, d_pts, d_out, d_cyc, reps, &cy[5]);
     const double chain_1 = run<false>(1, iters, d_boxes, d_pts, d_out, d_cyc, reps, &cy[0]);
     const double chain_n = run<false>(ncu, iters, d_boxes, d_pts, d_out, d_cyc, reps, &cy[1]);
     const double plus_1 = run<true>(1, iters, d_boxes, d_pts, d_out, d_cyc, reps, &cy[2]);
@@ -233,12 +314,14 @@ int main(int argc, char **argv) {
                pr.name, ncu, iters - 1);
         printf("%-78s %8s %8s\n", "", "1 WG", "1 WG/CU");
         printf("%-78s %8.4f %8.4f   (s_memtime ticks/iter %.0f / %.0f)\n",
+               "primitives: value -> 6-step DPP max -> 8-byte record -> barrier -> read -> 3-step DPP -> key -> xyz", prim_1, prim_n, cy[4], cy[5]);
+        printf("%-78s %8.4f %8.4f   (s_memtime ticks/iter %.0f / %.0f)\n",
                "chain: box test -> 6-step DPP max -> record -> barrier -> read -> 3-step DPP -> bcast", chain_1, chain_n, cy[0], cy[1]);
         printf("%-78s %8.4f %8.4f   (s_memtime ticks/iter %.0f / %.0f)\n",
                "chain+1: + the owner wave refreshes the one bucket that holds the new sample", plus_1, plus_n, cy[2], cy[3]);
     }
     printf("{\"fps_floor\": {\"device\": \"%s\", \"cus\": %d, \"iters\": %d, \"chain_us\": %.5f, \"chain_us_one_wg\": %.5f, "
-           "\"chain_plus_one_bucket_us\": %.5f, \"chain_plus_one_bucket_us_one_wg\": %.5f}}\n",
-           pr.name, ncu, iters - 1, chain_n, chain_1, plus_n, plus_1);
+           "\"chain_plus_one_bucket_us\": %.5f, \"chain_plus_one_bucket_us_one_wg\": %.5f, \"primitive_us\": %.5f, \"primitive_us_one_wg\": %.5f}}\n",
+           pr.name, ncu, iters - 1, chain_n, chain_1, plus_n, plus_1, prim_n, prim_1);
     return 0;
 }

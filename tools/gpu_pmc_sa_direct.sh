@@ -9,7 +9,7 @@ for SET in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_INSTS_VALU_MFMA
            "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INSTS_VMEM_RD"; do
   i=$((i+1))
   (cd /tmp && timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_sad/p$i -o pmc -- \
-      python $GRAFT_REPO_ROOT/tools/sa_direct_time.py > $GRAFT_REPO_ROOT/gpurun_out/pmc_sad/p$i.log 2>&1)
+      TGN_SA_TIME_ONLY=bf16x3 python $GRAFT_REPO_ROOT/tools/sa_direct_time.py > $GRAFT_REPO_ROOT/gpurun_out/pmc_sad/p$i.log 2>&1)
   tail -1 gpurun_out/pmc_sad/p$i.log
 done
 python - <<'PY'

@@ -38,17 +38,24 @@ for B, S, K, D, C1, C2, r in ((256, 4096, 32, 6, 64, 128, 0.05), (8, 1024, 32, 6
     def run():
         _lib.check(L.tgn_sa_mlp2_max_bf16x3(B, N, S, K, D, C1p, C2, None, _lib.ptr(xyz), _lib.ptr(pts), _lib.ptr(new_xyz), _lib.ptr(Wd), _lib.ptr(b1),
                                             _lib.ptr(gidx), 0, _lib.ptr(W2s), _lib.ptr(b2), _lib.ptr(out), C2, _lib.stream()), "sa")
-    run()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(7):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(4):
-            run()
-        b.record()
-        torch.cuda.synchronize()
-        ts.append(a.elapsed_time(b) / 4)
-    ms = sorted(ts)[3]
+    def run_fp32():     # the same level with the second layer on v_mfma_f32_32x32x2_f32 (no three-way bf16 split of the activations)
+        _lib.check(L.tgn_sa_mlp2_max(B, N, S, K, D, C1p, C2, None, _lib.ptr(xyz), _lib.ptr(pts), _lib.ptr(new_xyz), _lib.ptr(Wd), _lib.ptr(b1),
+                                     _lib.ptr(gidx), 0, _lib.ptr(W2f), _lib.ptr(b2), _lib.ptr(out), C2, _lib.stream()), "sa fp32")
+
     fl = 2.0 * B * S * K * (9 * C1 + C1 * C2)
-    print(f"B={B:4d} S={S} K={K} 9->{C1}->{C2}: {ms * 1e3:9.1f} us   {fl / ms / 1e9:7.1f} TFLOP/s fp32-equivalent   checksum {float(out.double().sum()):.6e}")
+    for name, fn in (("bf16x3", run), ("fp32 MFMA", run_fp32)):
+        if os.environ.get("TGN_SA_TIME_ONLY", name) != name:
+            continue
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(7):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(4):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) / 4)
+        ms = sorted(ts)[3]
+        print(f"B={B:4d} S={S} K={K} 9->{C1}->{C2} {name:10s}: {ms * 1e3:9.1f} us   {fl / ms / 1e9:7.1f} TFLOP/s fp32-equivalent   checksum {float(out.double().sum()):.6e}")

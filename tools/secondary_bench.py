@@ -110,6 +110,101 @@ def hot_path(make_inputs, device, shape_name, fused, B=256, steps=6, warmup=2):
     return out
 
 
+def hot_path_tree_ties(make_inputs, device, B=256, steps=8, warmup=3):
+    """The headline step with the FPS tie order of the reference's CUDA kernel (sampling_cuda_kernel.cu:5-10,64-123: the winner of a
+    distance tie is whoever the shared-memory reduction tree keeps) instead of first-index-wins -- the one FPS mode that is pinned
+    against the reference's own kernel (oracle/_ref), next to the default schedule measured the same way."""
+    shape = hotpath.SHAPE_A
+    xyz, feats, _ = make_inputs(B, device, 100, shape)
+    res = {}
+    for ties in ("first", "tree"):
+        hp = hotpath.HotPath(B, device, shape=shape, pipeline=True, fps_ties=ties)
+        for _ in range(warmup):
+            hp.run(xyz, feats, inputs_on_current_stream=False)
+        torch.cuda.synchronize()
+        hp.enable_kernel_timing(steps, stride=2)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            hp.run(xyz, feats, inputs_on_current_stream=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kt = {k: float(np.mean(v)) for k, v in hp.kernel_times_ms().items() if v}
+        res[ties] = dict(value=B * steps / dt, ms=1e3 * dt / steps, fps_l1_ms=kt.get("fps_l1"),
+                         us_per_fps_iteration=1e3 * kt["fps_l1"] / (shape["npoint"][0] - 1) if "fps_l1" in kt else None,
+                         kernel_ms={k: round(v, 4) for k, v in sorted(kt.items())})
+        del hp
+        torch.cuda.empty_cache()
+    t, f = res["tree"], res["first"]
+    return dict(value=t["value"], unit="meshes/s", ms=t["ms"], steps=steps, fps_l1_ms=t["fps_l1_ms"], us_per_fps_iteration=t["us_per_fps_iteration"],
+                first_index_ties=f, slowdown_vs_first_index=t["ms"] / f["ms"],
+                config=f"shape_A materialised, {B} scans per step, phased schedule, FPS with TGN_FPS_TREE_TIES at every level",
+                note="the tie key of the tree order is (bit-reversed reference thread, position within it) instead of the point index: one more "
+                     "compare per candidate where distances tie exactly, nothing else; the prefix-identity shortcut is off in this mode "
+                     "(include/tgn_pointops.h) and is not part of the headline either")
+
+
+def hot_path_with_h2d(make_inputs, device, B=256, steps=8, warmup=3):
+    """The headline step fed from HOST memory (BASELINE.md section 3 excludes the copy from the headline and asks for it separately;
+    the reference moves every scan host -> device, gen_utils.py:138, pointnet_pp_model.py:16-20): each step's 256 scans (xyz + normals,
+    147 MB) are copied from PINNED memory on a copy stream into one of two device buffers while the previous step computes; the
+    step's streams wait for the copy's event only.  Reported: meshes/s and GB/s over PCIe of that pipeline, the pipelined rate with
+    resident inputs measured the same way, and -- once -- what the same copy costs from pageable memory."""
+    shape = hotpath.SHAPE_A
+    xyz_d, feats_d, scans = make_inputs(B, device, 100, shape)
+    host = torch.from_numpy(scans).pin_memory()                         # (B, N, 6) fp32
+    nbytes = host.numel() * 4
+    hp = hotpath.HotPath(B, device, shape=shape, pipeline=True)
+    s_copy = torch.cuda.Stream(device=device)
+    # THREE input buffers: step k's scans are copied while step k-1 samples its own (FPS level 1 reads them for 3.3 ms) and step
+    # k-2's groupings still gather from theirs -- with two, the copy could only start when those groupings are through, one
+    # millisecond before its step begins (measured: 10.4 ms per step, the copy fully exposed)
+    NB = 3
+    pts = [torch.empty_like(feats_d[0]) for _ in range(NB)]
+    xyzs = [torch.empty_like(xyz_d) for _ in range(NB)]
+    ev_in = [torch.cuda.Event() for _ in range(NB)]
+    ev_after = [torch.cuda.Event() for _ in range(NB)]       # on the caller's stream behind run(): that step's results are complete
+
+    def step(k):
+        p = k % NB
+        with torch.cuda.stream(s_copy):
+            if k >= NB:
+                s_copy.wait_event(ev_after[p])                         # buffer p's last readers: step k-3's groupings
+            pts[p].copy_(host, non_blocking=True)
+            xyzs[p].copy_(pts[p][:, :, :3])                             # the (B, N, 3) coordinate block the samplers read
+            ev_in[p].record(s_copy)
+        hp.run(xyzs[p], [pts[p]] + feats_d[1:], inputs_on_current_stream=False, input_event=ev_in[p])
+        ev_after[p].record(torch.cuda.current_stream())
+
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n):
+            fn(k)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    for k in range(6):
+        step(k)
+    dt = timed(lambda k: step(k + 6), steps)
+    hp2 = hotpath.HotPath(B, device, shape=shape, pipeline=True)
+    for _ in range(warmup):
+        hp2.run(xyz_d, feats_d, inputs_on_current_stream=False)
+    dt_res = timed(lambda k: hp2.run(xyz_d, feats_d, inputs_on_current_stream=False), steps)
+    # the copy alone: pinned and pageable
+    copy_ms = _events(lambda: pts[0].copy_(host, non_blocking=True), 5, 1)
+    pageable = torch.from_numpy(scans.copy())
+    page_ms = _events(lambda: pts[0].copy_(pageable), 3, 1)
+    value = B * steps / dt
+    return dict(value=value, unit="meshes/s", ms=1e3 * dt / steps, steps=steps, pcie_GBs=nbytes * steps / dt / 1e9,
+                bytes_per_step=nbytes, resident_inputs={"value": B * steps / dt_res, "ms": 1e3 * dt_res / steps},
+                slowdown_vs_resident=dt / dt_res,
+                copy_alone={"pinned_ms": copy_ms, "pinned_GBs": nbytes / copy_ms / 1e6, "pageable_ms": page_ms, "pageable_GBs": nbytes / page_ms / 1e6},
+                config=f"shape_A materialised, {B} scans per step staged from pinned host memory on a copy stream (double-buffered), "
+                       "overlapped with the previous step",
+                roofline=_roof("pcie", nbytes * steps / dt / 1e9, 64.0, "GB/s",
+                               note="PCIe Gen5 x16 = 64 GB/s per direction (raw); the step needs bytes_per_step / ms_resident"))
+
+
 def knn(device):
     from toothgroupnetwork_amd import pointops as P
     xyz = torch.from_numpy(synth.arch_cloud(24000, 1, False)).to(device)
@@ -331,7 +426,9 @@ def measure_all(make_inputs, device, budget_s=240.0, checkpoint=None):
     """checkpoint(out): called after every entry (bench.py's child process rewrites its result file there)"""
     t0 = time.perf_counter()
     out = {}
-    plan = [("shape_B_materialised", lambda: hot_path(make_inputs, device, "B", False, steps=10, warmup=3)),
+    plan = [("shape_A_tree_ties", lambda: hot_path_tree_ties(make_inputs, device)),
+            ("shape_A_with_h2d", lambda: hot_path_with_h2d(make_inputs, device)),
+            ("shape_B_materialised", lambda: hot_path(make_inputs, device, "B", False, steps=10, warmup=3)),
             ("fused_shape_A", lambda: hot_path(make_inputs, device, "A", True, steps=10, warmup=3)),
             ("fused_shape_B", lambda: hot_path(make_inputs, device, "B", True, steps=8, warmup=3)),
             ("gather_family", lambda: gather_family(device)),

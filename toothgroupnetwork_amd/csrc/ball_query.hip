@@ -93,10 +93,12 @@ struct GridHeader {   // one per cloud, 64 bytes
     int pad[8];
 };
 
-__host__ __device__ inline size_t grid_cloud_bytes(int N) {
-    // header + cell_start[kGridCells+1] (padded to 16 B) + N float4 records
-    return sizeof(GridHeader) + (size_t)((kGridCells + 1 + 3) / 4 * 4) * sizeof(int) + (size_t)N * sizeof(float4);
-}
+// Per-cloud workspace: header | cell_start[kGridCells+1] (padded to 16 B) | N records float4(x, y, z, |p|^2) sorted by cell |
+// N int32 point indices in the same order.  The squared norm is the `sumsq3` the distance test needs (same expression, computed
+// once per point here instead of once per candidate and query); the index moved out of the record to make room for it.
+constexpr size_t kGridRecOff = sizeof(GridHeader) + (size_t)((kGridCells + 1 + 3) / 4 * 4) * sizeof(int);
+__host__ __device__ inline size_t grid_idx_off(int N) { return kGridRecOff + (size_t)N * sizeof(float4); }
+__host__ __device__ inline size_t grid_cloud_bytes(int N) { return grid_idx_off(N) + (size_t)((N + 3) / 4 * 4) * sizeof(int); }
 
 __device__ __forceinline__ int cell_coord(float p, float lo, float inv_h, int g) {
     // identical expression for points and queries; clamped to [-1, g] so far-away queries stay comparable
@@ -128,7 +130,8 @@ __global__ __launch_bounds__(kGridThreads) void ball_grid_build_kernel(int N, fl
     unsigned char *base = ws + (size_t)b * grid_cloud_bytes(N);
     GridHeader *hdr = (GridHeader *)base;
     int *cell_start = (int *)(base + sizeof(GridHeader));
-    float4 *rec = (float4 *)(base + sizeof(GridHeader) + (size_t)((kGridCells + 1 + 3) / 4 * 4) * sizeof(int));
+    float4 *rec = (float4 *)(base + kGridRecOff);
+    int *ridx = (int *)(base + grid_idx_off(N));
 
     // 1. bounding box, largest |coordinate|, non-finite census
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -255,7 +258,9 @@ __global__ __launch_bounds__(kGridThreads) void ball_grid_build_kernel(int N, fl
 #pragma unroll 4
         for (int pos = tid; pos < N; pos += kGridThreads) {
             const int k = perm[pos];
-            rec[pos] = make_float4(pts[(size_t)k * 3 + 0], pts[(size_t)k * 3 + 1], pts[(size_t)k * 3 + 2], __int_as_float(k));
+            const float px = pts[(size_t)k * 3 + 0], py = pts[(size_t)k * 3 + 1], pz = pts[(size_t)k * 3 + 2];
+            rec[pos] = make_float4(px, py, pz, sumsq3(px, py, pz));
+            ridx[pos] = k;
         }
         return;
     }
@@ -265,7 +270,8 @@ __global__ __launch_bounds__(kGridThreads) void ball_grid_build_kernel(int N, fl
         const int cy = cell_coord(py, h.lo[1], h.inv_h, h.g[1]);
         const int cz = cell_coord(pz, h.lo[2], h.inv_h, h.g[2]);
         const int pos = atomicAdd(&cnt[(cz * h.g[1] + cy) * h.g[0] + cx], 1);
-        rec[pos] = make_float4(px, py, pz, __int_as_float(k));
+        rec[pos] = make_float4(px, py, pz, sumsq3(px, py, pz));
+        ridx[pos] = k;
     }
 }
 
@@ -333,8 +339,8 @@ __global__ __launch_bounds__(256) void ball_grid_query_kernel(int B, int N, int 
             continue;
         }
         const int *__restrict__ cell_start = (const int *)(base + sizeof(GridHeader));
-        const float4 *__restrict__ rec =
-            (const float4 *)(base + sizeof(GridHeader) + (size_t)((kGridCells + 1 + 3) / 4 * 4) * sizeof(int));
+        const float4 *__restrict__ rec = (const float4 *)(base + kGridRecOff);
+        const int *__restrict__ ridx = (const int *)(base + grid_idx_off(N));
         const int gx = hdr->g[0], gy = hdr->g[1], gz = hdr->g[2];
         const float inv_h = hdr->inv_h;
         const int qx = cell_coord(cx, hdr->lo[0], inv_h, gx);
@@ -378,9 +384,9 @@ __global__ __launch_bounds__(256) void ball_grid_query_kernel(int B, int N, int 
             int pidx = 0;
             if (g < T) {
                 const float4 p = rec[j];
-                const float d = sqdist_expanded(cx, cy, cz, s1, p.x, p.y, p.z, sumsq3(p.x, p.y, p.z));
+                const float d = sqdist_expanded(cx, cy, cz, s1, p.x, p.y, p.z, p.w);
                 hit = !(d > r2);
-                pidx = __float_as_int(p.w);
+                pidx = ridx[j];
             }
             const unsigned long long mask = __ballot(hit);
             if (mask == 0) continue;
@@ -471,7 +477,7 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
     for (int t = 0; t < nquad; ++t) *(u32x4 *)&bm[(lane * nquad + t) * 4] = u32x4{0u, 0u, 0u, 0u};
     const long long total = (long long)B * S;
     const size_t cloud_bytes = grid_cloud_bytes(N);
-    const size_t rec_off = sizeof(GridHeader) + (size_t)((kGridCells + 1 + 3) / 4 * 4) * sizeof(int);
+    const size_t rec_off = kGridRecOff;
     const int dy = lane % 3 - 1, dz = lane / 3 - 1;   // lanes 0..8: the (dy, dz) x-run this lane looks up
     // XCD x (hardware block i runs on XCD i % 8) owns the contiguous query range [x*q_per_xcd, (x+1)*q_per_xcd) -- whole
     // clouds when there are at least 8 -- and its blocks, no more than are resident at a time, walk it together: a cloud's
@@ -532,6 +538,7 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
             continue;
         }
         const __amdgpu_buffer_rsrc_t rs_rec = ball_rsrc(ws + (size_t)cur.b * cloud_bytes + rec_off, (unsigned)N * 16u);
+        const __amdgpu_buffer_rsrc_t rs_idx = ball_rsrc(ws + (size_t)cur.b * cloud_bytes + grid_idx_off(N), (unsigned)N * 4u);
         const __amdgpu_buffer_rsrc_t rs_out = ball_rsrc(out + q * K, (unsigned)K * (unsigned)sizeof(IdxT));
         auto put = [&](int r, int v) {   // orow[r] = v
             if constexpr (sizeof(IdxT) == 8) {
@@ -565,11 +572,13 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
             return g + __shfl(delta, r);
         };
         u32x4 p[3];
+        int pi[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int g = 64 * i + lane;
             const int j = record_of(g);
             p[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, g < T ? (unsigned)j * 16u : 0xFFFFFFF0u, 0, 0);
+            pi[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_idx, g < T ? (unsigned)j * 4u : 0xFFFFFFF0u, 0, 0);
         }
         // the next query's cell-table look-ups go out behind them and land while this query is processed
         BallRuns nxt;
@@ -581,7 +590,7 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
         int H = 0;
         auto test = [&](const u32x4 &pp) -> bool {
             const float px = __uint_as_float(pp[0]), py = __uint_as_float(pp[1]), pz = __uint_as_float(pp[2]);
-            const float d = sqdist_expanded(cx, cy, cz, s1, px, py, pz, sumsq3(px, py, pz));
+            const float d = sqdist_expanded(cx, cy, cz, s1, px, py, pz, __uint_as_float(pp[3]));
             return !(d > r2);
         };
         auto record = [&](bool hit, int pidx) {   // pass 0: set the bit, list the hit
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
             H += __popcll(mask);
         };
 #pragma unroll
-        for (int i = 0; i < 3; ++i) record(64 * i + lane < T && test(p[i]), (int)p[i][3]);
+        for (int i = 0; i < 3; ++i) record(64 * i + lane < T && test(p[i]), pi[i]);
         // rank of index v = number of set bits below it (valid once gbase is up to date)
         auto rank_of = [&](int v) -> int {
             const unsigned g = (unsigned)v >> 7, wsel = ((unsigned)v >> 5) & 3u, below = (1u << (v & 31)) - 1u;
@@ -614,8 +623,8 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
                 const int g = g0 + lane;
                 const int j = record_of(g);
                 const u32x4 pp = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, g < T ? (unsigned)j * 16u : 0xFFFFFFF0u, 0, 0);
+                const int pidx = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_idx, g < T ? (unsigned)j * 4u : 0xFFFFFFF0u, 0, 0);
                 const bool hit = g < T && test(pp);
-                const int pidx = (int)pp[3];
                 if (pass == 0) {
                     record(hit, pidx);
                 } else if (hit) {
@@ -682,6 +691,304 @@ __global__ __launch_bounds__(256) void ball_grid_query_bitmap_kernel(int B, int 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// grid path, chunked bitmap kernel (round 6; clouds of up to 32 768 points -- the default)
+// ------------------------------------------------------------------------------------------------
+// ball_grid_query_bitmap_kernel issues ~370 vector instructions per query and runs at the VALU issue limit (one wave64 instruction
+// per 4 cycles and SIMD): every instruction removed is time.  Same cells, same test, same arithmetic, same results; what changed
+// is where the instructions go (profiles/r06_ball_sq_by_stage.txt):
+//   * ONE wave per workgroup, its LDS at fixed offsets: every LDS address is a register plus an instruction offset;
+//   * a wave takes CHUNKS of 16 consecutive queries of one cloud.  The per-query bookkeeping that was wave-uniform work on the
+//     vector ALU -- three cell coordinates, nine cell-table look-ups, the prefix sum of the nine run lengths -- is done once per
+//     chunk with a lane per (query, dy): 16 x 4 lanes, three passes (dz); ends and record offsets of the runs go to a 64-byte
+//     block per query in LDS, next to the query's coordinates and squared norm;
+//   * candidate g of the flattened list finds its run by a three-step binary search over that block's ends in LDS (three
+//     dependent ds_read_u16 + 8 vector instructions) plus one compare for the last run, instead of eight compare/add pairs on
+//     nine v_readlane'd ends per 64 candidates;
+//   * the record carries |p|^2 (ball_grid_build_kernel), the test is 3 fma + 3 add + 1 compare;
+//   * ranks come from a per-WORD exclusive prefix of the bitmap's popcounts (u16, built by the 64 word owners with chained
+//     v_bcnt + one wave scan): rank(v) = base[v >> 5] + bcnt(word & below(v)) -- two LDS reads and ~8 instructions per 64 hits,
+//     where the per-128-index bases needed four masked popcounts (~33).
+constexpr int kChunkQ = 16;            // queries per chunk
+constexpr int kQBlk = 64;              // bytes per query block: 9 run entries (end u16 | delta i16 << 16), pad, (cx, cy, cz, |c|^2) at +48
+
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int dpp_zero_i(int v) {   // lanes without a source / outside the masks receive 0
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+template <typename IdxT, int NQ>
+__global__ __launch_bounds__(64) void ball_grid_query_chunk_kernel(int B, int N, int S, int K, float r2,
+                                                                    const float *__restrict__ xyz,
+                                                                    const float *__restrict__ new_xyz,
+                                                                    const unsigned char *__restrict__ ws,
+                                                                    IdxT *__restrict__ out, int chunks_per_xcd) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    // LDS of the wave (bytes): bitmap | per-word base ranks (u16) | hit list (u16) | query blocks | pad value
+    constexpr int kOffBase = NQ * 1024, kOffHits = kOffBase + NQ * 512, kOffQ = kOffHits + kBmHitCap * 2,
+                  kOffFirst = kOffQ + kChunkQ * kQBlk, kLdsBytes = kOffFirst + 16;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
+    unsigned *bm = (unsigned *)lds;
+    unsigned short *wbase = (unsigned short *)(lds + kOffBase);
+    unsigned short *hits = (unsigned short *)(lds + kOffHits);
+    const int lane = threadIdx.x;
+    const int ql = lane >> 2, dyi = lane & 3;   // chunk stage: lane = (query of the chunk, dy + 1); dyi == 3 idles
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) *(u32x4 *)&bm[(lane * NQ + t) * 4] = u32x4{0u, 0u, 0u, 0u};
+    const size_t cloud_bytes = grid_cloud_bytes(N);
+    const int cpc = (S + kChunkQ - 1) / kChunkQ;          // chunks per cloud (a chunk never straddles two clouds)
+    const long long total_chunks = (long long)B * cpc;
+    // XCD x (hardware block i runs on XCD i % 8) owns the contiguous chunk range [x * chunks_per_xcd, (x + 1) * chunks_per_xcd) --
+    // whole clouds when there are at least 8 -- and its waves, no more than are resident at a time, walk it together: a cloud's
+    // grid (cell table + records, 0.55 MB at N = 24 000, read ~20 times over by its queries) is pulled into ONE L2 once
+    const unsigned xcd = blockIdx.x & 7u;
+    const int wstride = (int)(gridDim.x >> 3);
+    long long c_end = (long long)(xcd + 1) * chunks_per_xcd;
+    if (c_end > total_chunks) c_end = total_chunks;
+    long long c = (long long)xcd * chunks_per_xcd + (long long)(blockIdx.x >> 3);
+    if (c >= c_end) return;
+    int bcur = __builtin_amdgcn_readfirstlane((int)(c / cpc));
+    int ccur = __builtin_amdgcn_readfirstlane((int)(c - (long long)bcur * cpc));   // c = bcur * cpc + ccur
+    const int db = wstride / cpc, dc = wstride - db * cpc;
+
+    for (; c < c_end; c += wstride) {
+        const int b = bcur, q0 = ccur * kChunkQ;          // first query of the chunk within its cloud
+        bcur += db;
+        ccur += dc;
+        if (ccur >= cpc) {
+            ccur -= cpc;
+            ++bcur;
+        }
+        const int nq = min(kChunkQ, S - q0);
+        const long long qg0 = (long long)b * S + q0;      // global number of the chunk's first query
+        const unsigned char *base = ws + (size_t)b * cloud_bytes;
+        const GridHeader *hdr = (const GridHeader *)base;
+        const float *__restrict__ cloud = xyz + (size_t)b * N * 3;
+        // ---- chunk stage: the 16 queries' coordinates, cells, runs ------------------------------------------------------
+        const __amdgpu_buffer_rsrc_t rs_q = ball_rsrc(new_xyz + qg0 * 3, (unsigned)nq * 12u);
+        const float cx = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, (unsigned)ql * 12u + 0u, 0, 0));
+        const float cy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, (unsigned)ql * 12u + 4u, 0, 0));
+        const float cz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, (unsigned)ql * 12u + 8u, 0, 0));
+        const bool fin = fabsf(cx) <= 3.0e38f && fabsf(cy) <= 3.0e38f && fabsf(cz) <= 3.0e38f;
+        // queries that take the index-order scan: the cloud has no grid, or the query is not finite (bit 4 * query)
+        unsigned long long scanq = __builtin_amdgcn_ballot_w64(!fin && dyi == 0 && ql < nq);
+        if (hdr->use_scan) scanq = 0x1111111111111111ull;
+        {
+            const __amdgpu_buffer_rsrc_t rs_cells = ball_rsrc(base + sizeof(GridHeader), (kGridCells + 1) * 4u);
+            const int gx = hdr->g[0], gy = hdr->g[1], gz = hdr->g[2];
+            const float inv_h = hdr->inv_h;
+            const int qx = cell_coord(cx, hdr->lo[0], inv_h, gx);
+            const int qy = cell_coord(cy, hdr->lo[1], inv_h, gy);
+            const int qz = cell_coord(cz, hdr->lo[2], inv_h, gz);
+            const int x0 = max(qx - 1, 0), x1p = min(qx + 1, gx - 1) + 1;
+            const int yy = qy + dyi - 1;
+            const bool ok_l = fin && ql < nq && dyi < 3 && x0 < x1p && (unsigned)yy < (unsigned)gy && !hdr->use_scan;
+            int rs[3], len[3];
+#pragma unroll
+            for (int ps = 0; ps < 3; ++ps) {
+                const int zz = qz + ps - 1;
+                const bool ok = ok_l && (unsigned)zz < (unsigned)gz;
+                const unsigned c0 = (unsigned)((zz * gy + yy) * gx);
+                // lanes without a run read out of range: the hardware returns 0 for both ends -> an empty run
+                rs[ps] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_cells, ok ? (c0 + (unsigned)x0) * 4u : 0xFFFFFFF0u, 0, 0);
+                len[ps] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_cells, ok ? (c0 + (unsigned)x1p) * 4u : 0xFFFFFFF0u, 0, 0) - rs[ps];
+            }
+            // inclusive prefix of the nine run lengths of a query, run r = 3 * pass + dyi.  Inside the quad: the length one and
+            // two lanes to the left (lane 3 of a quad has no run, its length is 0: it stands in for "nothing to the left"),
+            // then the totals of the earlier passes (lane 2 of the quad holds a pass total)
+            int e[3];
+#pragma unroll
+            for (int ps = 0; ps < 3; ++ps)
+                e[ps] = len[ps] + dpp_zero_i<0x93, 0xF, 0xF>(len[ps])      // quad_perm [3,0,1,2]
+                        + dpp_zero_i<0x4F, 0xF, 0xF>(len[ps]);             // quad_perm [3,3,0,1]
+            const int t0 = dpp_zero_i<0xAA, 0xF, 0xF>(e[0]), t1 = dpp_zero_i<0xAA, 0xF, 0xF>(e[1]);   // quad_perm [2,2,2,2]
+            e[1] += t0;
+            e[2] += t0 + t1;
+            // the query block: entry r = end | (record of the run's first candidate - its position in the list) << 16; the
+            // ninth entry's end is T, the number of candidates
+            unsigned char *qb = lds + kOffQ + ql * kQBlk;
+#pragma unroll
+            for (int ps = 0; ps < 3; ++ps) {
+                const int delta = rs[ps] - (e[ps] - len[ps]);
+                const unsigned ent = ((unsigned)delta << 16) | (unsigned)e[ps];
+                *(unsigned *)(qb + (dyi < 3 ? (ps * 3 + dyi) * 4 : 40)) = ent;    // (lane 3 of the quad: a dummy word)
+            }
+            *(float4 *)(qb + 48) = make_float4(cx, cy, cz, sumsq3(cx, cy, cz));   // (the four lanes of a quad write the same words)
+        }
+        wave_lds_fence();
+        // ---- the queries of the chunk ---------------------------------------------------------------------------------------
+        const __amdgpu_buffer_rsrc_t rs_rec = ball_rsrc(base + kGridRecOff, (unsigned)N * 16u);
+        const __amdgpu_buffer_rsrc_t rs_idx = ball_rsrc(base + grid_idx_off(N), (unsigned)N * 4u);
+        for (int i = 0; i < nq; ++i) {
+            IdxT *__restrict__ orow = out + (qg0 + i) * K;
+            const unsigned char *qb = lds + kOffQ + i * kQBlk;            // wave-uniform
+            if ((scanq >> (4 * i)) & 1ull) {
+                const float4 qc = *(const float4 *)(qb + 48);
+                ball_scan_row<IdxT>(N, K, r2, cloud, qc.x, qc.y, qc.z, orow, lane);
+                continue;
+            }
+            const __amdgpu_buffer_rsrc_t rs_out = ball_rsrc(orow, (unsigned)K * (unsigned)sizeof(IdxT));
+            auto put = [&](int r, int v) {   // orow[r] = v
+                if constexpr (sizeof(IdxT) == 8)
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{(unsigned)v, 0u}, rs_out, (unsigned)r * 8u, 0, 0);   // indices are >= 0
+                else
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned)v, rs_out, (unsigned)r * 4u, 0, 0);
+            };
+            const float4 qc = *(const float4 *)(qb + 48);                 // broadcast read: (cx, cy, cz, |c|^2)
+            const int T = __builtin_amdgcn_readfirstlane((int)*(const unsigned short *)(qb + 32));
+            const int e3 = (int)*(const unsigned short *)(qb + 12), e7 = (int)*(const unsigned short *)(qb + 28);
+            const int d8 = (int)*(const short *)(qb + 34);
+            // flattened candidate g -> byte offset of its record.  run(g) = #{t < 8 : end[t] <= g}: three binary-search steps
+            // over ends 0..6 in the query block, one compare against end 7 for the last run.  Written for three candidates at a
+            // time, step by step, so that the three dependent LDS reads of each overlap (NB of three batches); the empty asm
+            // statements keep the compiler from sinking a batch's search into a branch of its own (it then runs them one
+            // after the other, each waiting for its own reads).
+            // Candidates beyond T compute an offset behind the last run: whatever they read is masked by `g < T`.
+            auto record_off3 = [&](const int (&g)[3], unsigned (&off)[3]) {
+                const unsigned qo = (unsigned)(kOffQ + i * kQBlk);
+                unsigned a[3];
+                int t[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) a[k] = g[k] >= e3 ? qo + 16u : qo;           // run in 4..7 | 0..3
+#pragma unroll
+                for (int k = 0; k < 3; ++k) t[k] = (int)*(const unsigned short *)(lds + a[k] + 4);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) a[k] += g[k] >= t[k] ? 8u : 0u;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) t[k] = (int)*(const unsigned short *)(lds + a[k]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) a[k] += g[k] >= t[k] ? 4u : 0u;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) t[k] = (int)*(const short *)(lds + a[k] + 2);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    asm volatile("" : "+v"(t[k]));
+                    off[k] = (unsigned)(g[k] + (g[k] >= e7 ? d8 : t[k])) << 4;
+                }
+            };
+            auto dist = [&](const u32x4 &pp) -> float {
+                float d = sqdist_expanded(qc.x, qc.y, qc.z, qc.w, __uint_as_float(pp[0]), __uint_as_float(pp[1]),
+                                          __uint_as_float(pp[2]), __uint_as_float(pp[3]));
+                asm volatile("" : "+v"(d));     // evaluated in every lane: no branch around six instructions
+                return d;
+            };
+            u32x4 p[3];
+            int pi[3];
+            {
+                const int g[3] = {lane, lane + 64, lane + 128};
+                unsigned off[3];
+                record_off3(g, off);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    p[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, off[k], 0, 0);
+                    pi[k] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_idx, off[k] >> 2, 0, 0);
+                }
+            }
+            int H = 0;
+            // (the hit mask is the AND of two compare results in scalar registers; a ballot of the combined predicate makes the
+            // compiler rebuild the mask from a 0/1 select)
+            auto record = [&](int g, float d, int pidx, bool capped) {   // set the bit, list the hit
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(g < T) & __builtin_amdgcn_ballot_w64(!(d > r2));
+                const bool hit = (g < T) & !(d > r2);
+                if (hit) {
+                    atomicOr(&bm[(unsigned)pidx >> 5], 1u << (pidx & 31));
+                    const int pos = H + mbcnt(mask);
+                    if (!capped || pos < kBmHitCap) hits[pos] = (unsigned short)pidx;
+                }
+                H += __popcll(mask);
+            };
+#pragma unroll
+            for (int k = 0; k < 3; ++k) record(64 * k + lane, dist(p[k]), pi[k], false);   // (192 <= kBmHitCap: no cap test)
+            // rank of index v = number of set bits below it (valid once the word bases are up to date)
+            auto rank_of = [&](int v) -> int {
+                const unsigned w = bm[(unsigned)v >> 5];
+                const unsigned below = (1u << ((unsigned)v & 31u)) - 1u;   // the low v % 32 bits
+                return (int)wbase[(unsigned)v >> 5] + __popc(w & below);
+            };
+            // the candidates beyond the first 192 (pass 0), or every candidate again (pass 1: the hit list overflowed and each
+            // hit is ranked straight from the bitmap)
+            auto walk = [&](const int pass) {
+                for (int g0 = pass == 0 ? 192 : 0; g0 < T; g0 += 3 * kWave) {
+                    const int g[3] = {g0 + lane, g0 + lane + 64, g0 + lane + 128};
+                    unsigned off[3];
+                    record_off3(g, off);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        if (g0 + 64 * k >= T) break;     // wave-uniform
+                        const u32x4 pp = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, off[k], 0, 0);
+                        const int pidx = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_idx, off[k] >> 2, 0, 0);
+                        const float d = dist(pp);
+                        if (pass == 0) {
+                            record(g[k], d, pidx, true);
+                        } else if ((g[k] < T) & !(d > r2)) {
+                            const int r = rank_of(pidx);
+                            if (r < K) put(r, pidx);
+                            if (r == 0) *(int *)(lds + kOffFirst) = pidx;
+                        }
+                    }
+                }
+            };
+            if (T > 192) walk(0);
+            if (H == 0) {   // wave-uniform; the bitmap is still clean
+                for (int j = lane; j < K; j += kWave) put(j, N);  // no hit at all -> N (pointnet2_utils.py:136-141)
+                continue;
+            }
+            wave_lds_fence();   // the bits were set by whichever lanes held the hits
+            {   // exclusive prefix of the popcounts of the bitmap's words: the owner of words [lane * 4 NQ, (lane + 1) * 4 NQ)
+                // chains its v_bcnt, a wave scan turns the lane totals into lane bases, the bases are written as u16 pairs
+                unsigned pre[4 * NQ];
+                unsigned run = 0;
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) {
+                    const u32x4 w = *(const u32x4 *)&bm[(lane * NQ + t) * 4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        pre[t * 4 + u] = run;
+                        run += (unsigned)__popc(w[u]);        // (one v_bcnt_u32_b32 with its accumulate operand)
+                    }
+                }
+                unsigned incl = run;   // inclusive scan over the 64 lanes
+                incl += dpp_or_zero<0x111, 0xF>(incl);
+                incl += dpp_or_zero<0x112, 0xF>(incl);
+                incl += dpp_or_zero<0x114, 0xF>(incl);
+                incl += dpp_or_zero<0x118, 0xF>(incl);
+                incl += dpp_or_zero<0x142, 0xA>(incl);   // row_bcast:15 into rows 1, 3
+                incl += dpp_or_zero<0x143, 0xC>(incl);   // row_bcast:31 into rows 2, 3
+                const unsigned lb = incl - run, lb2 = (lb << 16) | lb;
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) {
+                    const unsigned a = ((pre[t * 4 + 1] << 16) + pre[t * 4 + 0]) + lb2, bq = ((pre[t * 4 + 3] << 16) + pre[t * 4 + 2]) + lb2;
+                    *(u32x2 *)(lds + kOffBase + (lane * NQ + t) * 8) = u32x2{a, bq};
+                }
+            }
+            wave_lds_fence();   // the bases and the hit list cross lanes
+            const bool pad = H < K;   // wave-uniform: the row is padded with its first entry, the hit of rank 0
+            if (H <= kBmHitCap) {
+                for (int k = lane; k < H; k += kWave) {
+                    const int v = hits[k];
+                    const int r = rank_of(v);
+                    if (r < K) put(r, v);
+                    if (pad && r == 0) *(int *)(lds + kOffFirst) = v;
+                }
+            } else {
+                walk(1);
+            }
+            if (pad) {   // pad with the first hit = the smallest index (pointnet2_utils.py:138-141)
+                wave_lds_fence();
+                const int fv = *(const int *)(lds + kOffFirst);
+                for (int j = H + lane; j < K; j += kWave) put(j, fv);
+            }
+            wave_lds_fence();   // every rank has been read: the bitmap can be wiped for the next query
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) *(u32x4 *)&bm[(lane * NQ + t) * 4] = u32x4{0u, 0u, 0u, 0u};
+            wave_lds_fence();
+        }
+        wave_lds_fence();   // the query blocks are rewritten by the next chunk
+    }
+}
+
 static bool use_grid(int N, int S, int K) {
     // the grid pays off once the per-query scan (N/64 steps) clearly exceeds a neighbourhood visit
     return N >= 2048 && (long long)S * 8 >= N / 64 && K <= kGridMaxK;
@@ -724,7 +1031,31 @@ static int ball_query_impl(int B, int N, int S, int nsample, float r2, const flo
             if (int rc = check_launch("ball_grid_build_kernel")) return rc;
         }
         if (!query) return TGN_OK;
-        const int bitmap_ok = tuning(kTuneBallBitmap);   // 0: the rank-select kernel (experiments)
+        const int bitmap_ok = tuning(kTuneBallBitmap);   // 2: the chunked bitmap kernel; 1: round 2's bitmap kernel; 0: rank-select (experiments)
+        if (bitmap_ok >= 2 && N <= kBmMaxN) {
+            const int nquad = (N + 8191) >> 13;
+            const int cpc = (S + kChunkQ - 1) / kChunkQ;
+            const long long total_chunks = (long long)B * cpc;
+            const long long cpx = B >= 8 ? (long long)((B + 7) / 8) * cpc : (total_chunks + 7) / 8;
+            long long wpx = cpx < 1024 ? cpx : 1024;   // waves per XCD: what is resident at a time (32 CUs x <= 32), not more
+            const unsigned nblk = (unsigned)(wpx * 8);
+#define TGN_BALL_CHUNK(T_, NQ_)                                                                                            \
+    hipLaunchKernelGGL((ball_grid_query_chunk_kernel<T_, NQ_>), dim3(nblk), dim3(64), 0, st, B, N, S, nsample, r2, xyz, \
+                       new_xyz, (const unsigned char *)workspace, (T_ *)idx, (int)cpx)
+            if (idx_is_int64) {
+                if (nquad == 1) TGN_BALL_CHUNK(long long, 1);
+                else if (nquad == 2) TGN_BALL_CHUNK(long long, 2);
+                else if (nquad == 3) TGN_BALL_CHUNK(long long, 3);
+                else TGN_BALL_CHUNK(long long, 4);
+            } else {
+                if (nquad == 1) TGN_BALL_CHUNK(int, 1);
+                else if (nquad == 2) TGN_BALL_CHUNK(int, 2);
+                else if (nquad == 3) TGN_BALL_CHUNK(int, 3);
+                else TGN_BALL_CHUNK(int, 4);
+            }
+#undef TGN_BALL_CHUNK
+            return check_launch("ball_grid_query_chunk_kernel");
+        }
         if (bitmap_ok && N <= kBmMaxN) {
             const int nquad = (N + 8191) >> 13;
             const size_t lds = (size_t)4 * (nquad * 256 + nquad * 64 + kBmHitCap) * sizeof(unsigned);   // <= 24 KiB per workgroup

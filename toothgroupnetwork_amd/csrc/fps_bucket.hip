@@ -248,7 +248,9 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             bmeta[0][wave][s] = x[s];
             bmeta[1][wave][s] = y[s];
             bmeta[2][wave][s] = z[s];
-            bmeta[3][wave][s] = __uint_as_float(kl);
+            bmeta[3][wave][s] = __uint_as_float(o);   // the ORIGINAL index in every mode: tie keys are derived from it where a tie is
+                                                      // resolved (tree order: compat_key), nowhere else -- the common path of the tree
+                                                      // mode is then the default mode's (round 5: 0.90 against 0.81 us per iteration)
         }
     }
 
@@ -335,9 +337,8 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
                             const float mx = wave_max_f32_dpp(nd);
                             const unsigned long long eq = ballot64(nd == mx);
                             bool win = nd == mx;
-                            const unsigned ko = TREE ? compat_key((int)o, log2bs) : o;
                             if (__builtin_expect(__popcll(eq) != 1, 0)) {  // exact tie inside the bucket (rare): the smallest tie key wins
-                                const unsigned kl = win ? ko : 0xFFFFFFFFu;
+                                const unsigned kl = win ? (TREE ? compat_key((int)o, log2bs) : o) : 0xFFFFFFFFu;
                                 const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kl));
                                 win = win && kl == kmin;
                             }
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
                                 bmeta[0][wave][s] = x[s];
                                 bmeta[1][wave][s] = y[s];
                                 bmeta[2][wave][s] = z[s];
-                                bmeta[3][wave][s] = __uint_as_float(ko);
+                                bmeta[3][wave][s] = __uint_as_float(o);
                             }
                             {  // bmax[lane s] = mx: one v_writelane (a select would keep 48 hoisted lane masks alive in SGPRs)
                                 const int mxs = __builtin_amdgcn_readfirstlane(__float_as_int(mx));
@@ -370,14 +371,14 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             const float v = lane < P ? bmax : -1.0f;
             wm = wave_max_f32_dpp(v);
             const unsigned long long cm = wm >= 0.0f ? (ballot64(v == wm) & kSlotMask) : 0ull;
-            const bool cand = ((cm >> lane) & 1ull) != 0ull;
-            const unsigned kl = cand ? __float_as_uint(pm.w) : 0xFFFFFFFFu;
             int sl = cm ? __builtin_ctzll(cm) : 0;
             if (__builtin_expect(__popcll(cm) > 1, 0)) {
+                const bool cand = ((cm >> lane) & 1ull) != 0ull;
+                const unsigned kl = cand ? (TREE ? compat_key((int)__float_as_uint(pm.w), log2bs) : __float_as_uint(pm.w)) : 0xFFFFFFFFu;
                 const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kl));
                 sl = __builtin_ctzll(ballot64(kl == kmin));
             }
-            wkey = (unsigned)__builtin_amdgcn_readlane((int)kl, sl);
+            wkey = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(pm.w), sl);
             wslot = sl;
             wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pm.x), sl));
             wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pm.y), sl));
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             const unsigned long long wmask = ballot64(vb == mb) & ((1ull << NW) - 1ull);  // lanes 0..NW-1 hold the records
             int wl = __builtin_ctzll(wmask);
             if (__builtin_expect(__popcll(wmask) > 1, 0)) {  // equal maxima in several waves (rare): the smallest tie key wins
-                const unsigned kk = ((wmask >> lane) & 1ull) ? r0.y : 0xFFFFFFFFu;
+                const unsigned kk = ((wmask >> lane) & 1ull) ? (TREE ? compat_key((int)r0.y, log2bs) : r0.y) : 0xFFFFFFFFu;
                 const unsigned kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_shfl(kk));
                 wl = __builtin_ctzll(ballot64(kk == kmin));
             }
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(NT) void fps_bucket_kernel(FpsArgs a) {
             qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.y), wl));
             qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.z), wl));
         }
-        int k = kwin == 0xFFFFFFFFu ? 0 : (TREE ? compat_index(kwin, log2bs) : (int)kwin);
+        int k = kwin == 0xFFFFFFFFu ? 0 : (int)kwin;      // (records carry original indices in every mode)
         k = __builtin_amdgcn_readfirstlane(k);
         if (tid == 0) outbuf[j & (NT - 1)] = make_float4(__int_as_float(k), qx, qy, qz);
         if ((j & (NT - 1)) == NT - 1) {  // wave-uniform
@@ -938,6 +939,11 @@ static int bucket_launch_mode(int b, int n_max, const FpsArgs &a, hipStream_t st
     }
         TGN_FPS_BUCKET_CONFIGS(X)
 #undef X
+        // beside the ball queries of the phased schedule (TGN_FPS_LOW_VALU) a 2049..4096-point cloud is better off on EIGHT waves
+        // with half-empty slot sets than on four full ones: 0.81 against 0.86 ms for 4096 -> 1024 beside the level-1 query, and the
+        // step 4.51 against 4.55 ms (profiles/r06_phase2_experiments.txt; it lost in round 2, when the query beside it issued
+        // 2.4 times the vector instructions)
+        if ((a.flags & TGN_FPS_LOW_VALU) && nt == 256 && p == 16) nt = 512;
     }
     if constexpr (MODE == 0) {   // experiments: "fps_cell_bits" = 5 selects the 15-bit cell codes of round 1 (116 KiB of LDS)
         const int cell_bits = tuning(kTuneFpsCellBits);

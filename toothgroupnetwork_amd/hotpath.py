@@ -59,7 +59,7 @@ def algorithmic_bytes(n, npoint, nsample, d, fused=False, radius=None, mlp=None,
     return sum(l["total"] for l in levels), levels
 
 
-def plan_schedule(fps_l1_ms, group_ms, setup_ms, n_levels):
+def plan_schedule(fps_l1_ms, group_ms, setup_ms, n_levels, grid_ms=0.0):
     """The two decisions of the phased schedule, from three launches timed when a HotPath is first run:
       spacer_us         how long the gated groupings are held back behind the start of FPS level 1: most of that kernel's
                         set-up (it streams its cloud three times with latency-bound loads; a grouping launch saturating HBM
@@ -69,9 +69,11 @@ def plan_schedule(fps_l1_ms, group_ms, setup_ms, n_levels):
                         the groupings leave room there (Shape A: 3.05 of 3.33 ms -- with the 0.15 ms the query itself takes there it just fits;
                         measured 4.69 -> 4.62 ms per step) and costs
                         when they do not (Shape B, whose groupings take ten times the FPS launch: 2 % slower)."""
-    spacer_us = int(max(0.0, min(300.0, 600.0 * setup_ms)))
+    # (the groupings are gated behind the END of phase 2 -- its last query and its last FPS level; grid_ms is what still lies
+    #  between that point and the start of FPS level 1 on the FPS stream: the next step's level-1 grid build, when it is built there)
+    spacer_us = int(max(0.0, min(600.0, 600.0 * setup_ms + 1000.0 * grid_ms)))
     return dict(spacer_us=spacer_us, last_query_early=bool(n_levels >= 2 and group_ms + 0.15 <= fps_l1_ms),
-                fps_l1_ms=float(fps_l1_ms), group_ms=float(group_ms), setup_ms=float(setup_ms))
+                fps_l1_ms=float(fps_l1_ms), group_ms=float(group_ms), setup_ms=float(setup_ms), grid_ms=float(grid_ms))
 
 
 class HotPath:
@@ -104,7 +106,7 @@ class HotPath:
     kernels of step k on stream G."""
 
     def __init__(self, B, device, shape=SHAPE_A, index_dtype=torch.int32, pipeline=False, fps_prefix=False, fused=False,
-                 plan=None, group_max_blocks=None):
+                 plan=None, group_max_blocks=None, grid_stream="own", fps_low_valu=True, fps_ties="first"):
         self.B, self.device, self.shape = B, device, shape
         self.fused = bool(fused)
         # fps_prefix: hand every FPS level the certificate of the level that produced its input (FPS of an FPS result
@@ -115,6 +117,18 @@ class HotPath:
         self.L = lib()
         self.pipeline = bool(pipeline)
         self.phased = self.pipeline and not self.fused
+        # phase-2 placement of the NEXT step's level-1 grid build: "own" (default) on a stream of its own, released when the previous
+        # step's phase 2 starts -- it then runs beside FPS level 2 and the level-1 query instead of lengthening the FPS chain (4.55
+        # against 4.74 ms per step once the queries got cheap, profiles/r06_phase2_experiments.txt); "F" behind FPS level 3 on the FPS
+        # stream (rounds 2-5); "H" behind the last phase-2 ball query on the query stream.  fps_low_valu: FPS levels 2-3 on the bucket-skipping
+        # kernel (few vector instructions) or on the plain register-resident one (a shorter chain that issues ten times as many)
+        self.grid_stream = str(grid_stream)
+        self.fps_low_valu = bool(fps_low_valu)
+        # "first": first index wins a distance tie (pointnet2_utils.py:103-118, the default everywhere); "tree": the order of the
+        # reference CUDA kernel's shared-memory reduction tree (sampling_cuda_kernel.cu:5-10,64-123), pinned against oracle/_ref
+        if fps_ties not in ("first", "tree"):
+            raise ValueError("fps_ties must be 'first' or 'tree'")
+        self.fps_ties = fps_ties
         # the gated groupings run beside the FPS level-1 workgroups: 256 "blocks" = one wave per SIMD
         # (group_max_blocks: force the bound also on one stream -- counter passes that want the grouping's HBM traffic at the grid it
         # has in the phased schedule, tools/gpu_pmc.sh)
@@ -130,6 +144,7 @@ class HotPath:
             self.s_fps = torch.cuda.Stream(device=device, priority=-1)
             self.s_rest = torch.cuda.Stream(device=device, priority=0)
             self.s_ball = torch.cuda.Stream(device=device, priority=-1) if self.phased else None
+            self.s_grid = torch.cuda.Stream(device=device, priority=0) if (self.phased and self.grid_stream == "own") else None
             self.ev_ball = [[torch.cuda.Event() for _ in range(nl)] for _ in range(2)]
             self.ev_fps = [[torch.cuda.Event() for _ in range(nl)] for _ in range(2)]
             self.ev_grid = [torch.cuda.Event() for _ in range(2)]
@@ -281,10 +296,14 @@ class HotPath:
         flags were last read.  Synchronises the device (every stream's flag is read: _lib.take_index_error_device)."""
         return _lib.take_index_error_device()
 
-    def enable_kernel_timing(self, steps, stride=1):
+    def enable_kernel_timing(self, steps, stride=1, only=None):
         """HIP events on the launch stream around each kernel class (start/stop), on every `stride`-th step: a timing
-        event is a barrier packet in its queue, and a dozen of them per step cost the pipelined schedule ~5 %."""
+        event is a barrier packet in its queue, and a dozen of them per step cost the pipelined schedule ~4 % even at
+        stride 4 (4.55 against 4.37 ms per step, profiles/r06_timeline.txt).  only=("fps_l1",) times that kernel class alone
+        (two events per timed step between launches that are serialised anyway)."""
         names = [f"{k}_l{i + 1}" for i in range(len(self.levels)) for k in ("fps", "ball", "group")]
+        if only is not None:
+            names = [n for n in names if n in only]
         self.events = {n: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                            if s_ % stride == 0 else None for s_ in range(steps)] for n in names}
         self._step = 0
@@ -293,14 +312,14 @@ class HotPath:
         return {n: [e[0].elapsed_time(e[1]) for e in evs[:self._step] if e is not None] for n, evs in self.events.items()}
 
     def _timed(self, name, fn, stream=None):
-        if self.events is None or self._step >= len(self.events[name]) or self.events[name][self._step] is None:
+        if self.events is None or name not in self.events or self._step >= len(self.events[name]) or self.events[name][self._step] is None:
             return fn()
         a, b = self.events[name][self._step]
         a.record(stream)
         fn()
         b.record(stream)
 
-    def run(self, xyz, feats, inputs_on_current_stream=True):
+    def run(self, xyz, feats, inputs_on_current_stream=True, input_event=None):
         """xyz: (B, N, 3) fp32 contiguous; feats: list of per-level feature tensors (B, N_l, D_l).
         Results land in self.levels[l]['grouped'] etc. (pipelined: self.sets[step parity]).  Asynchronous.
         Pipelined mode: the results of a call live in one of two buffer sets and are overwritten by the call after
@@ -308,11 +327,14 @@ class HotPath:
         has enqueued there -- producing the inputs, reading earlier results.  inputs_on_current_stream=False drops
         that wait (the inputs were complete long ago, e.g. a resident dataset), so that this step does not wait for
         the previous step's results and consecutive steps overlap; the caller then has to make sure on its own that
-        its reads of step k's results are done before it issues call k+2 (tools/pipeline_stress.py)."""
+        its reads of step k's results are done before it issues call k+2 (tools/pipeline_stress.py).
+        input_event (pipelined mode): a torch.cuda.Event behind which this call's inputs are complete -- e.g. recorded on a copy
+        stream behind the host-to-device copy of this step's scans; the step's streams wait for it and for nothing else of the
+        caller's, so the copy of step k+1 overlaps step k."""
         if self.pipeline:
             if self.phased and self.plan is None:
                 self.plan = self._calibrate(xyz, feats)
-            return self._run_pipelined(xyz, feats, inputs_on_current_stream)
+            return self._run_pipelined(xyz, feats, inputs_on_current_stream, input_event)
         return self._run_one_stream(xyz, feats, self.levels, timed=True)
 
     def _run_one_stream(self, xyz, feats, levels, timed=False):
@@ -335,7 +357,7 @@ class HotPath:
         levels = self.sets[0]
         st = _lib.stream()
         self._run_one_stream(xyz, feats, levels)      # untimed: code objects loaded, caches and clocks warm
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
         lv0 = levels[0]
         ev[0].record()
         self._fps(0, lv0, xyz, levels, st)
@@ -358,15 +380,21 @@ class HotPath:
             self._consume(i, lv, cur, feats, levels, st)
             cur = lv["new_xyz"]
         ev[5].record()
-        ev[5].synchronize()
-        return plan_schedule(ev[0].elapsed_time(ev[1]), ev[4].elapsed_time(ev[5]), ev[2].elapsed_time(ev[3]), len(levels))
+        ev[6].record()
+        for br in lv0["branches"]:
+            self._ball_build(lv0, br, xyz, st)
+        ev[7].record()
+        ev[7].synchronize()
+        return plan_schedule(ev[0].elapsed_time(ev[1]), ev[4].elapsed_time(ev[5]), ev[2].elapsed_time(ev[3]), len(levels),
+                             grid_ms=ev[6].elapsed_time(ev[7]) if self.grid_stream == "F" else 0.0)
 
     def _fps(self, i, lv, cur_xyz, levels, st):
         L = self.L
         # phased schedule: FPS levels 2-3 run beside the ball queries, which are bound by vector-ALU issue -- the bucket-skipping
         # kernel issues a tenth of the plain kernel's vector instructions (0.86 vs 0.75 ms for level 2 itself, but the level-1
         # ball query beside it 1.10 instead of 1.28 ms)
-        flags = _lib.FPS_LOCAL_INDEX | (_lib.FPS_LOW_VALU if (self.phased and i > 0) else 0)
+        flags = (_lib.FPS_LOCAL_INDEX | (_lib.FPS_LOW_VALU if (self.phased and i > 0 and self.fps_low_valu) else 0)
+                 | (_lib.FPS_TREE_TIES if self.fps_ties == "tree" else 0))
         if not self.fps_prefix:
             return check(L.tgn_furthestsampling_dense(self.B, lv["N"], lv["S"], ptr(cur_xyz), None, ptr(lv["fps_idx"]),
                                                       ptr(lv["new_xyz"]), flags, st), "fps")
@@ -375,7 +403,7 @@ class HotPath:
                                                          ptr(lv["new_xyz"]), ptr(cert_in), None, ptr(lv["cert"]),
                                                          flags, st), "fps")
 
-    def _run_pipelined(self, xyz, feats, inputs_on_current_stream=True):
+    def _run_pipelined(self, xyz, feats, inputs_on_current_stream=True, input_event=None):
         p = self.step_no & 1
         levels = self.sets[p]
         nl = len(levels)
@@ -383,9 +411,13 @@ class HotPath:
         pf, pg = _lib.c_void_p(sf.cuda_stream), _lib.c_void_p(sg.cuda_stream)
         pb = _lib.c_void_p(sb.cuda_stream) if sb is not None else None
         cur = torch.cuda.current_stream()
-        if inputs_on_current_stream or self.step_no == 0:
+        if input_event is not None:
+            for s_ in (sf, sg, sb, getattr(self, "s_grid", None)):
+                if s_ is not None:
+                    s_.wait_event(input_event)
+        elif inputs_on_current_stream or self.step_no == 0:
             self.ev_start.record(cur)      # inputs produced on the caller's stream
-            for s_ in (sf, sg, sb):
+            for s_ in (sf, sg, sb, getattr(self, "s_grid", None)):
                 if s_ is not None:
                     s_.wait_event(self.ev_start)
         if self.step_no >= 2:
@@ -396,9 +428,18 @@ class HotPath:
             early = nl - 1 if self.plan.get("last_query_early") else nl
             # the level-1 grid depends on the input cloud only: it goes onto stream F BEFORE the fence below, i.e. behind
             # the previous step's FPS level 3, where stream F would otherwise idle until that step's ball queries are done
+            if self.grid_stream == "F" or self.step_no == 0:
+                sx, px = sf, pf
+            elif self.grid_stream == "H":
+                sx, px = sb, pb                                  # behind the previous step's phase-2 queries, already enqueued there
+            else:
+                sx, px = self.s_grid, _lib.c_void_p(self.s_grid.cuda_stream)
+                sx.wait_event(self.ev_fps[1 - p][0])             # released when the previous step's phase 2 starts
             for br in levels[0]["branches"]:
-                self._ball_build(levels[0], br, xyz, pf)
-            self.ev_grid[p].record(sf)
+                self._ball_build(levels[0], br, xyz, px)
+            self.ev_grid[p].record(sx)
+            if sx is not sf:
+                sf.wait_event(self.ev_grid[p])                   # (a grid build cannot share a CU with an FPS level-1 workgroup)
             if self.step_no >= 1:
                 sf.wait_event(self.ev_ball[1 - p][early - 1])   # the previous step's phase-2 queries are through
             for i, lv in enumerate(levels):
@@ -413,8 +454,7 @@ class HotPath:
                 self.ev_ball[p][i].record(sb)
             # all of this step's groupings run beside the NEXT step's FPS level 1: released by the last phase-2 query
             sg.wait_event(self.ev_ball[p][early - 1])
-            if early < nl:
-                sg.wait_event(self.ev_fps[p][nl - 1])
+            sg.wait_event(self.ev_fps[p][nl - 1])     # ... and by the last FPS level: the end of phase 2, whichever chain is longer
             if self.plan.get("spacer_us"):
                 check(self.L.tgn_stream_delay(int(self.plan["spacer_us"]), pg), "stream_delay")
             for j in range(early, nl):
