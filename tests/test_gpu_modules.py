@@ -415,3 +415,23 @@ def test_feature_propagation_commuted_first_layer_equals_the_plain_form(dev, mon
         assert float(((ya - yb).abs() / (1.0 + yb.abs())).max()) <= 2e-5, mode                  # outputs: elementwise
         for a, b in zip(res[True][1:], res[False][1:]):                                          # gradients (BatchNorm's backward
             assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()), mode              # subtracts batch means: conditioning)
+
+
+def test_linear_relu_private_epilogue_equals_the_public_fallback(dev, monkeypatch):
+    """pointnet2_utils.linear_relu uses torch._addmm_activation (a private ATen entry point: the ReLU in the GEMM's epilogue) where it
+    exists; without it -- a torch that dropped or renamed it -- the public F.linear + relu_ path must give the same bits"""
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    g = torch.Generator().manual_seed(5)
+    for rows, cin, cout in [(24000, 131, 128), (777, 64, 17), (8, 515, 256)]:
+        x = torch.randn(2, rows, cin, generator=g).to(dev)
+        W, b = torch.randn(cout, cin, generator=g).to(dev), torch.randn(cout, generator=g).to(dev)
+        with torch.no_grad():
+            fast = U.linear_relu(x, W, b)
+            with monkeypatch.context() as m:
+                if hasattr(torch, "_addmm_activation"):
+                    m.delattr(torch, "_addmm_activation")
+                slow = U.linear_relu(x, W, b)
+            ref = torch.relu(torch.nn.functional.linear(x, W, b))
+        assert fast.shape == slow.shape == ref.shape
+        assert torch.equal(slow, ref)
+        assert torch.equal(fast, slow), (rows, cin, cout, float((fast - slow).abs().max()))

@@ -92,6 +92,47 @@ def test_fps_low_valu_hint_changes_the_kernel_not_the_result(dev, oracle):
         assert np.array_equal(outs[1][0], oracle.farthest_point_sample(xyz_np, m)), (n, m)
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_fps_lean_kernel_every_shape_ties_nan_ragged(dev, oracle, mode):
+    """fps_lean_kernel (csrc/fps.hip: packed-pair arithmetic, value-only arg-max, coordinates in the wave records) at every
+    shape it has -- 64x8, 256x4, 256x8, 512x8 -- on one ragged packed batch: lattices with duplicated vertices (exact ties
+    inside a lane, across lanes and across waves), NaN coordinates, a cloud sampled to exhaustion, exact-capacity sizes;
+    plain and FMA arithmetic; against the oracle, against the kernel it replaces, and the coordinates it emits."""
+    from toothgroupnetwork_amd import _lib
+    flags = _lib.FPS_FMA if mode & 1 else 0
+    clouds = [synth.lattice_cloud(7, dup=90, seed=1),             # 433 points -> 64 x 8
+              synth.lattice_cloud(9, dup=250, seed=2),            # 979       -> 256 x 4
+              synth.arch_cloud(1024, 5, False),                   # exact capacity of 256 x 4
+              synth.lattice_cloud(12, dup=300, seed=3),           # 2028      -> 256 x 8
+              synth.arch_cloud(3000, 6, False),                   # 512 x 8, NaN below
+              synth.uniform_cloud(300, 7),                        # sampled to exhaustion and beyond
+              synth.arch_cloud(4096, 8, False),                   # exact capacity of 512 x 8
+              np.repeat(synth.uniform_cloud(37, 9), 8, 0)]        # 296 points, every vertex eight times
+    clouds[4][[0, 17, 2999]] = np.nan
+    clouds[1][500] = np.nan
+    ms = [433, 600, 256, 1500, 700, 340, 1024, 100]
+    for n_max_only, sel in ((512, [0, 5, 7]), (1024, [1, 2, 0]), (2048, [3, 1, 5]), (4096, [4, 6, 3, 0, 7])):
+        xyz_np = np.concatenate([clouds[i] for i in sel])
+        off_np = np.cumsum([clouds[i].shape[0] for i in sel]).astype(np.int32)
+        noff_np = np.cumsum([ms[i] for i in sel]).astype(np.int32)
+        n_max = max(clouds[i].shape[0] for i in sel)
+        assert n_max <= n_max_only
+        xyz, off, noff = T(xyz_np, dev), T(off_np, dev), T(noff_np, dev)
+        outs = {}
+        for lean in (2, 0):
+            idx = torch.full((int(noff_np[-1]),), -7, dtype=torch.int32, device=dev)
+            nx = torch.full((int(noff_np[-1]), 3), -7.0, device=dev)
+            with _lib.tuning(fps_lean=lean, fps_bucket_min=1000000):
+                _lib.check(_lib.lib().tgn_furthestsampling(len(sel), n_max, _lib.ptr(xyz), _lib.ptr(off), _lib.ptr(noff), None,
+                                                           _lib.ptr(idx), _lib.ptr(nx), flags, _lib.stream()))
+            outs[lean] = (idx.cpu().numpy(), nx.cpu().numpy())
+        want = oracle.furthestsampling(xyz_np, off_np, noff_np, mode=mode)
+        assert np.array_equal(outs[2][0], want), (n_max_only, mode)
+        assert np.array_equal(outs[0][0], want), (n_max_only, mode)
+        assert np.array_equal(outs[2][1], xyz_np[want.astype(np.int64)], equal_nan=True), (n_max_only, mode)
+        assert np.array_equal(outs[2][1], outs[0][1], equal_nan=True)
+
+
 def test_fps_packed_ragged_batch_and_modes(dev, oracle, regression):
     from toothgroupnetwork_amd import _lib, pointops as P
     r = regression

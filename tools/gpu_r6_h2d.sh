@@ -3,7 +3,6 @@ set -u
 export TMPDIR=/tmp
 O=gpurun_out/r6_h2d
 mkdir -p $O
-timeout 600 python tools/h2d_trace.py tree 2>$O/tree.err | tail -1 | cut -c1-1500
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/tr -o h -- python $GRAFT_REPO_ROOT/tools/h2d_trace.py h2d > $GRAFT_REPO_ROOT/$O/h2d.log 2>&1)
 tail -1 $O/h2d.log | cut -c1-600
 python - <<'PY'
@@ -22,11 +21,10 @@ if m:
 rows.sort()
 t0 = rows[0][0]
 sel = [x for x in rows if x[2] == "fps_l1"]
-lo, hi = sel[-4][0], sel[-2][1]
+print("fps_l1 launches:", len(sel), "copy rows:", sum(1 for x in rows if x[2].startswith("COPY")), "copy csv:", m)
+lo, hi = sel[9][0], sel[11][1]
 for s, e, n, st in rows:
     if lo - 200000 <= s <= hi:
         print(f"{(s - t0) / 1e6:10.3f} {(e - t0) / 1e6:10.3f} {(e - s) / 1e6:8.3f} {n:28s} {st}")
 PY
 rm -rf $O/tr
-for V in 0 1 3 5 7 8 9 0; do echo "sa_dephase=$V"; TGN_SA_DEPHASE=$V TGN_SA_TIME_ONLY=bf16x3 timeout 300 python tools/sa_direct_time.py 2>&1 | tail -3; done
-TGN_SA_TIME_ONLY="fp32 MFMA" timeout 300 python tools/sa_direct_time.py 2>&1 | tail -3

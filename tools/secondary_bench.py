@@ -136,10 +136,12 @@ def hot_path_tree_ties(make_inputs, device, B=256, steps=8, warmup=3):
         torch.cuda.empty_cache()
     t, f = res["tree"], res["first"]
     return dict(value=t["value"], unit="meshes/s", ms=t["ms"], steps=steps, fps_l1_ms=t["fps_l1_ms"], us_per_fps_iteration=t["us_per_fps_iteration"],
-                first_index_ties=f, slowdown_vs_first_index=t["ms"] / f["ms"],
+                kernel_ms=t["kernel_ms"], first_index_ties=f, slowdown_vs_first_index=t["ms"] / f["ms"],
                 config=f"shape_A materialised, {B} scans per step, phased schedule, FPS with TGN_FPS_TREE_TIES at every level",
                 note="the tie key of the tree order is (bit-reversed reference thread, position within it) instead of the point index: one more "
-                     "compare per candidate where distances tie exactly, nothing else; the prefix-identity shortcut is off in this mode "
+                     "compare per candidate where distances tie exactly, nothing else at levels 1-2; level 3 (1024 points) runs on "
+                     "fps_resident_kernel in this mode (~0.25 ms) because the lean kernel (~0.12 ms) implements the first-index order only -- that "
+                     "is the whole difference (profiles/r06_hw_queues.txt); the prefix-identity shortcut is off in this mode "
                      "(include/tgn_pointops.h) and is not part of the headline either")
 
 
@@ -163,8 +165,9 @@ def hot_path_with_h2d(make_inputs, device, B=256, steps=8, warmup=3):
     xyzs = [torch.empty_like(xyz_d) for _ in range(NB)]
     ev_in = [torch.cuda.Event() for _ in range(NB)]
     ev_after = [torch.cuda.Event() for _ in range(NB)]       # on the caller's stream behind run(): that step's results are complete
+    marks = {}
 
-    def step(k):
+    def step(k, mark=False):
         p = k % NB
         with torch.cuda.stream(s_copy):
             if k >= NB:
@@ -174,22 +177,27 @@ def hot_path_with_h2d(make_inputs, device, B=256, steps=8, warmup=3):
             ev_in[p].record(s_copy)
         hp.run(xyzs[p], [pts[p]] + feats_d[1:], inputs_on_current_stream=False, input_event=ev_in[p])
         ev_after[p].record(torch.cuda.current_stream())
+        if mark:
+            marks[k] = torch.cuda.Event(enable_timing=True)
+            marks[k].record(torch.cuda.current_stream())
 
-    def timed(fn, n):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(n):
-            fn(k)
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0
+    # steady state: `steps` consecutive steps in the middle of a longer run, between two events on the caller's stream (each
+    # is complete when its step's results are); no synchronisation in between -- the copy of step k+1 runs under step k
+    lead = 6
+    for k in range(lead + steps + 2):
+        step(k, mark=k in (lead - 1, lead + steps - 1))
+    torch.cuda.synchronize()
+    dt = 1e-3 * marks[lead - 1].elapsed_time(marks[lead + steps - 1])
 
-    for k in range(6):
-        step(k)
-    dt = timed(lambda k: step(k + 6), steps)
     hp2 = hotpath.HotPath(B, device, shape=shape, pipeline=True)
-    for _ in range(warmup):
+    m2 = {}
+    for k in range(lead + steps + 2):                                   # the same measurement with resident inputs
         hp2.run(xyz_d, feats_d, inputs_on_current_stream=False)
-    dt_res = timed(lambda k: hp2.run(xyz_d, feats_d, inputs_on_current_stream=False), steps)
+        if k in (lead - 1, lead + steps - 1):
+            m2[k] = torch.cuda.Event(enable_timing=True)
+            m2[k].record(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    dt_res = 1e-3 * m2[lead - 1].elapsed_time(m2[lead + steps - 1])
     # the copy alone: pinned and pageable
     copy_ms = _events(lambda: pts[0].copy_(host, non_blocking=True), 5, 1)
     pageable = torch.from_numpy(scans.copy())
@@ -199,10 +207,33 @@ def hot_path_with_h2d(make_inputs, device, B=256, steps=8, warmup=3):
                 bytes_per_step=nbytes, resident_inputs={"value": B * steps / dt_res, "ms": 1e3 * dt_res / steps},
                 slowdown_vs_resident=dt / dt_res,
                 copy_alone={"pinned_ms": copy_ms, "pinned_GBs": nbytes / copy_ms / 1e6, "pageable_ms": page_ms, "pageable_GBs": nbytes / page_ms / 1e6},
-                config=f"shape_A materialised, {B} scans per step staged from pinned host memory on a copy stream (double-buffered), "
-                       "overlapped with the previous step",
+                config=f"shape_A materialised, {B} scans per step staged from pinned host memory on a copy stream (three input buffers), "
+                       f"overlapped with the previous step; {steps} consecutive steps in steady state between two events",
                 roofline=_roof("pcie", nbytes * steps / dt / 1e9, 64.0, "GB/s",
                                note="PCIe Gen5 x16 = 64 GB/s per direction (raw); the step needs bytes_per_step / ms_resident"))
+
+
+def _valu_counts():
+    """committed instruction counts of the issue-bound scans and the measured issue ceiling (profiles/r06_valu_counts.json:
+    rocprofv3 --pmc SQ_INSTS_VALU passes and tools/valu_bench.hip)"""
+    try:
+        return json.load(open(os.path.join(REPO, "profiles", "r06_valu_counts.json")))
+    except Exception:
+        return None
+
+
+def _valu_roof(entry, ms, note):
+    """fraction of the vector-issue ceiling: (wave-instructions per launch / SIMDs) x ceiling ns per instruction / measured time"""
+    vc = _valu_counts()
+    if not vc or entry not in vc:
+        return _roof("valu", None, None, "ms", note="profiles/r06_valu_counts.json is missing: no instruction count to price against")
+    c = vc["issue_ceiling"]
+    floor_ms = vc[entry]["sq_insts_valu"] / c["simds"] * c["ns_per_wave_instruction_per_simd"] * 1e-6
+    return _roof("valu", ms, floor_ms, "ms per launch (lower is better; frac = time at the vector-issue ceiling / achieved)",
+                 wave_instructions_per_launch=vc[entry]["sq_insts_valu"], valu_per_query=vc[entry]["sq_insts_valu"] / vc[entry]["queries"],
+                 ceiling_ns_per_wave_instruction_per_simd=c["ns_per_wave_instruction_per_simd"], simds=c["simds"],
+                 counts_source="profiles/r06_valu_counts.json (committed rocprofv3 --pmc SQ_INSTS_VALU pass of the same workload, not this run)",
+                 note=note) | {"frac": floor_ms / ms}
 
 
 def knn(device):
@@ -216,9 +247,33 @@ def knn(device):
     ms = _events(run, 10, 2)
     nbytes = 12 * 24000 * 2 + 8 * 24000 * 36
     return dict(value=1e3 / ms, unit="calls/s", ms=ms, config="pointops.knnquery(36, xyz, xyz) on one 24 000-point scan (grid kernel)",
-                roofline=_roof("valu", nbytes / ms / 1e6, HBM_PEAK_GBS, "GB/s", algorithmic_bytes=nbytes,
-                               pair_evaluations_brute_force=24000 * 24000,
-                               note="bound by vector-ALU issue of the sorted-insertion lists, not by HBM; one workgroup wave owns 4 queries"))
+                roofline=_valu_roof("knn_24000_k36", ms,
+                                    "one call = grid build + query + heap replay launches on one scan; the query kernel keeps 36-entry sorted "
+                                    "lists per lane and waits on dependent record loads for 46 % of its wave cycles (SQ_WAIT_INST_ANY / "
+                                    "SQ_WAVE_CYCLES): latency of a batch-1 call, not issue -- which is what a fraction of 0.15 says"),
+                hbm_view=dict(algorithmic_bytes=nbytes, GBs=nbytes / ms / 1e6, pair_evaluations_brute_force=24000 * 24000))
+
+
+def ball_l1(make_inputs, device, B=256):
+    """The level-1 ball query of the headline alone (1 048 576 queries over 256 grids, K = 32): vector instructions per launch from the
+    committed counter pass, against the measured vector-issue ceiling."""
+    shape = hotpath.SHAPE_A
+    xyz, feats, _ = make_inputs(B, device, 100, shape)
+    hp = hotpath.HotPath(B, device, shape=shape, pipeline=False)
+    hp.run(xyz, feats)
+    torch.cuda.synchronize()
+    lv = hp.levels[0]
+    st = _lib.stream()
+    ms = _events(lambda: [hp._ball(lv, br, xyz, st, prebuilt=True) for br in lv["branches"]], 10, 2)
+    ms_build = _events(lambda: [hp._ball_build(lv, br, xyz, st) for br in lv["branches"]], 10, 2)
+    q = B * shape["npoint"][0]
+    out = dict(value=q / ms / 1e3, unit="M queries/s", ms=ms, grid_build_ms=ms_build,
+               config=f"query_ball_point(0.05, 32) of {B} x 24 000-point scans, 4096 queries each, grid prebuilt (chunked bitmap kernel)",
+               roofline=_valu_roof("ball_l1", ms, "bound by vector-ALU issue and the latency of its dependent LDS / L2 reads; 185 vector "
+                                                  "instructions per query (round 2's kernel: 367), profiles/r06_ball_sq_by_stage.txt"))
+    del hp
+    torch.cuda.empty_cache()
+    return out
 
 
 def fps_large(device):
@@ -422,7 +477,7 @@ def atomic_floor():
         return {"error": f"atomic_floor unavailable: {type(e).__name__}: {str(e)[:100]}"}
 
 
-def measure_all(make_inputs, device, budget_s=240.0, checkpoint=None):
+def measure_all(make_inputs, device, budget_s=270.0, checkpoint=None):
     """checkpoint(out): called after every entry (bench.py's child process rewrites its result file there)"""
     t0 = time.perf_counter()
     out = {}
@@ -432,6 +487,7 @@ def measure_all(make_inputs, device, budget_s=240.0, checkpoint=None):
             ("fused_shape_A", lambda: hot_path(make_inputs, device, "A", True, steps=10, warmup=3)),
             ("fused_shape_B", lambda: hot_path(make_inputs, device, "B", True, steps=8, warmup=3)),
             ("gather_family", lambda: gather_family(device)),
+            ("ball_l1", lambda: ball_l1(make_inputs, device)),
             ("knn_24000_k36", lambda: knn(device)),
             ("fps_100k_to_24k", lambda: fps_large(device)),
             ("pnpp_forward_8x24000", lambda: pnpp_forward(device)),

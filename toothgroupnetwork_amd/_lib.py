@@ -8,7 +8,14 @@ import ctypes
 import os
 import threading
 
-import torch
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams that share a
+# queue run one after the other.  The phased HotPath schedule alone keeps four streams busy; with the caller's own stream and a
+# copy stream that is six, and a second HotPath in the process used to lose its overlap entirely (7.7 instead of 4.9 ms per
+# step, profiles/r06_hw_queues.txt).  The runtime reads the variable once, when the first HIP call initialises it -- after this
+# import in every entry point of the package.  An explicit setting of the caller's wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
 
 from . import config
 

@@ -1021,10 +1021,14 @@ static int ball_query_impl(int B, int N, int S, int nsample, float r2, const flo
     if (grid) {
         if (build) {
             const size_t perm_bytes = N <= kGridPermCap ? ((size_t)N * 2 + 15) / 16 * 16 : 0;   // the LDS permutation of step 4
-            static bool attr_set = false;
-            if (!attr_set) {   // 64 KiB cell table + up to 64 KiB permutation: past the 64-KiB default of dynamic + static LDS
-                (void)hipFuncSetAttribute((const void *)ball_grid_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kGridPermCap * 2);
-                attr_set = true;
+            // 64 KiB cell table + up to 64 KiB permutation: past the 64-KiB default of dynamic + static LDS.  The attribute belongs to
+            // the (function, device) pair, so it is set on every launch (a host-side table look-up; a once-per-process flag would
+            // leave a second GPU of the process without it)
+            if (perm_bytes && hipFuncSetAttribute((const void *)ball_grid_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  kGridPermCap * 2) != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("tgn_ball_query: cannot raise the grid build kernel's dynamic LDS limit to %d bytes", kGridPermCap * 2);
+                return TGN_ERR_LAUNCH;
             }
             hipLaunchKernelGGL(ball_grid_build_kernel, dim3(B), dim3(kGridThreads), perm_bytes, st, N, r2, xyz,
                                (unsigned char *)workspace);

@@ -74,7 +74,7 @@ static const TuneEntry kTune[kTuneCount] = {
     {"fps_plain", "TGN_FPS_V1", 0},           {"fps_config", "TGN_FPS_CONFIG", 0},       {"fps_bucket_config", "TGN_FPS_BUCKET_CONFIG", 0},
     {"fps_cell_bits", "TGN_FPS_CELL_BITS", 4}, {"fps_bucket_min", "TGN_FPS_BUCKET_MIN", -1}, {"ball_bitmap", "TGN_BALL_BITMAP", 2},
     {"knn_memset", "TGN_KNN_MEMSET", 0},      {"knn_grid_scale", "TGN_KNN_GRID_SCALE", 1000}, {"sa_tile", "TGN_SA_TILE", 0},
-    {"gather_v4", "TGN_GATHER_V4", 5},        {"sa_dephase", "TGN_SA_DEPHASE", 0},
+    {"gather_v4", "TGN_GATHER_V4", 5},        {"fps_lean", "TGN_FPS_LEAN", 1},
 };
 static std::atomic<int> g_tune[kTuneCount];
 static const bool g_tune_seeded = [] {   // runs once, at load time, before any launch can read the table

@@ -122,6 +122,189 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(FpsArgs a) {
     if (a.prefix_out && tid == 0) a.prefix_out[blockIdx.x] = CERT ? cert.value(m) : 1;  // not tracked: no claim
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Lean register-resident kernel for small clouds (round 6): the same operator, arithmetic and tie order as fps_resident_kernel
+// (canonical first-index ties; the tree order stays with that kernel), written for the two things that bound these launches in
+// the phased HotPath schedule: a lone wave issues about one instruction per 5 cycles WHATEVER its kind, so an iteration costs
+// what the wave that holds the winner ISSUES (fps_resident_kernel<64,16>: ~350 instructions per iteration); and the ball
+// queries that run beside FPS levels 2-3 are occupancy-bound by LDS (6 KB per wave), so every KB this kernel holds is theirs.
+//   * two points per instruction: the coordinates and running minima are fp32 PAIRS (v_pk_add_f32 / v_pk_mul_f32: each half an
+//     ordinary IEEE fp32 operation, nothing fused unless TGN_FPS_FMA asks for it);
+//   * the loop tracks the VALUE of the lane's maximum only (one v_max3_f32 per pair).  Points are dealt lane-major (lane t owns
+//     points t P .. t P + P - 1), so "first index wins" = first lane, then first slot inside it: a ballot finds the lane, and every
+//     lane looks up the first slot equal to its own maximum AND that slot's coordinates with a compare + four selects per slot --
+//     once per iteration, not per point, and independent of the wave reduction, whose DPP wait states they fill (the reduction
+//     is written with update_dpp builtins on the integer view of the non-negative distances so that the compiler schedules it);
+//   * one 32-byte record per wave (value, key, x, y, z), one barrier, one LDS round trip: the winner's coordinates come with the
+//     record -- no copy of the cloud in LDS (fps_resident_kernel keeps 12 B per point there: 48 KB at 4096 points, which cost
+//     the level-1 ball query beside it a third of its waves, profiles/r06_fps_lean.txt);
+//   * result rows parked in a 64-row LDS buffer that wave 0 flushes by itself (no block barrier).
+// LDS: 1.5 KB whatever the cloud.  profiles/r06_fps_lean.txt has the timings.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float vmax3_f32(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// one step of a wave reduction as v_mov_dpp(identity) + max: the compiler folds the pair into v_max_*_dpp (the identity as `old`
+// is the pattern its DPP combiner knows), keeps the wait states the hazard needs and fills them with independent work
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_max_i32(int v) {
+    const int t = __builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, ROW_MASK, 0xf, false);
+    return t > v ? t : v;
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
+    const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+    return t > v ? t : v;
+}
+
+template <int NT, int P, int MODE>
+__global__ __launch_bounds__(NT) void fps_lean_kernel(FpsArgs a) {
+    static_assert(P % 2 == 0 && P >= 2, "points come in pairs");
+    constexpr bool FMA = (MODE & 1) != 0, CERT = (MODE & kFpsModeCert) != 0;
+    constexpr int NW = NT / kWave, H = P / 2;
+    static_assert(NW == 1 || NW == 2 || NW == 4 || NW == 8 || NW == 16, "wave count");
+    __shared__ uint4 rec[2][NW][2];     // {value bits, key, x, y} {z, -, -, -}
+    __shared__ float4 outbuf[kWave];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    int start_n, n, start_m, m;
+    fps_segment(a, blockIdx.x, start_n, n, start_m, m);
+    if (m <= 0) return;
+    if (fps_prefix_shortcut<NT>(a, blockIdx.x, start_n, n, start_m, m)) return;
+    const float *__restrict__ base = a.xyz + (size_t)start_n * 3;
+    FpsPrefixCert cert;
+
+    f32x2 x[H], y[H], z[H], d[H];
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = tid * P + 2 * i + u;
+            const bool valid = k < n;
+            x[i][u] = valid ? base[(size_t)k * 3 + 0] : 0.0f;
+            y[i][u] = valid ? base[(size_t)k * 3 + 1] : 0.0f;
+            z[i][u] = valid ? base[(size_t)k * 3 + 2] : 0.0f;
+            d[i][u] = valid ? 1e10f : -1.0f;   // pointops.py:22 ; padding can never win (real distances are >= 0)
+        }
+    }
+    float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+    if (n > 0) {
+        qx = base[0];
+        qy = base[1];
+        qz = base[2];
+    }
+    if (tid == 0) outbuf[0] = make_float4(__int_as_float(0), qx, qy, qz);   // row 0: sampling_cuda_kernel.cu:39
+
+    for (int j = 1; j < m; ++j) {
+        const f32x2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+        float best = -1.0f;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const f32x2 dx = x[i] - q2x, dy = y[i] - q2y, dz = z[i] - q2z;
+            f32x2 dd;
+            if constexpr (FMA)
+                dd = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+            else
+                dd = ((dx * dx) + (dy * dy)) + (dz * dz);
+            const float n0 = vmin_f32(dd[0], d[i][0]), n1 = vmin_f32(dd[1], d[i][1]);   // min(d, tmp[k]) sampling_cuda_kernel.cu:55
+            d[i][0] = n0;
+            d[i][1] = n1;
+            best = vmax3_f32(best, n0, n1);
+        }
+        // every lane: the first slot that holds ITS maximum, and that point's coordinates (descending chain: the smallest slot is
+        // written last).  `best` is -1 or a non-negative, non-NaN float: its bit pattern orders like a signed integer.  The six
+        // reduction steps and the P - 1 selection steps are independent chains, written interleaved: the selects sit in the wait
+        // states the DPP hazard asks for.
+        int slot = P - 1;
+        float cx = x[H - 1][1], cy = y[H - 1][1], cz = z[H - 1][1];
+        int wv = __float_as_int(best);
+        auto select_step = [&](int s2) {
+            const bool c = d[s2 >> 1][s2 & 1] == best;
+            slot = c ? s2 : slot;
+            cx = c ? x[s2 >> 1][s2 & 1] : cx;
+            cy = c ? y[s2 >> 1][s2 & 1] : cy;
+            cz = c ? z[s2 >> 1][s2 & 1] : cz;
+        };
+        constexpr int kSel = P - 1;                       // selection steps, dealt over the six reduction steps
+        int s2 = P - 2;
+#define TGN_LEAN_STEP(CTRL, MASK, STEP)                                                    \
+        wv = dpp_max_i32<CTRL, MASK>(wv);                                                  \
+        __builtin_amdgcn_sched_barrier(0);   /* (the scheduler otherwise moves the whole selection behind the reduction) */ \
+        _Pragma("unroll") for (int t = (kSel * (STEP)) / 6; t < (kSel * ((STEP) + 1)) / 6; ++t) select_step(s2--);       \
+        __builtin_amdgcn_sched_barrier(0);
+        TGN_LEAN_STEP(0x111, 0xf, 0)   // row_shr:1
+        TGN_LEAN_STEP(0x112, 0xf, 1)   // row_shr:2
+        TGN_LEAN_STEP(0x114, 0xf, 2)   // row_shr:4
+        TGN_LEAN_STEP(0x118, 0xf, 3)   // row_shr:8
+        TGN_LEAN_STEP(0x142, 0xa, 4)   // row_bcast:15 into rows 1 and 3
+        TGN_LEAN_STEP(0x143, 0xc, 5)   // row_bcast:31 into rows 2 and 3
+#undef TGN_LEAN_STEP
+        const int wmi = __builtin_amdgcn_readlane(wv, 63);
+        // the lanes that hold the wave's maximum (none if the wave has no point at all); no branch on `eq` or on the sign: the
+        // selection chain above would sink into it, behind the reduction
+        const unsigned long long eq = ballot64(__float_as_int(best) == wmi) & (wmi >= 0 ? ~0ull : 0ull);
+        const int L = eq ? (int)__builtin_ctzll(eq) : 0;   // lane-major points: the first lane holds the smallest index
+        const int sL = __builtin_amdgcn_readlane(slot, L);
+        const int ix = __builtin_amdgcn_readlane(__float_as_int(cx), L), iy = __builtin_amdgcn_readlane(__float_as_int(cy), L),
+                  iz = __builtin_amdgcn_readlane(__float_as_int(cz), L);
+        unsigned key = eq ? (unsigned)((wave * kWave + L) * P + sL) : 0xFFFFFFFFu;
+        float kx = __int_as_float(eq ? ix : 0), ky = __int_as_float(eq ? iy : 0), kz = __int_as_float(eq ? iz : 0);
+        unsigned vbits = wmi < 0 ? 0u : (unsigned)wmi;   // distances are >= 0: their bit patterns order like unsigned integers
+        if constexpr (NW > 1) {
+            // (every lane writes the same 20 bytes: no exec juggling before the barrier)
+            rec[j & 1][wave][0] = make_uint4(vbits, key, __float_as_uint(kx), __float_as_uint(ky));
+            rec[j & 1][wave][1].x = __float_as_uint(kz);
+            __syncthreads();
+            const uint4 r0 = rec[j & 1][lane & (NW - 1)][0];
+            const unsigned r1 = rec[j & 1][lane & (NW - 1)][1].x;
+            unsigned mb = r0.x;
+            mb = dpp_max_u32<0x111>(mb);
+            if constexpr (NW >= 4) mb = dpp_max_u32<0x112>(mb);
+            if constexpr (NW >= 8) mb = dpp_max_u32<0x114>(mb);
+            if constexpr (NW >= 16) mb = dpp_max_u32<0x118>(mb);
+            mb = (unsigned)__builtin_amdgcn_readlane((int)mb, NW - 1);
+            // waves own ascending index ranges: of several waves with the same maximum the first holds the smallest index
+            const unsigned long long wmask = ballot64(r0.x == mb) & ((1ull << NW) - 1ull);
+            const int w = (int)__builtin_ctzll(wmask);
+            key = (unsigned)__builtin_amdgcn_readlane((int)r0.y, w);
+            kx = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)r0.z, w));
+            ky = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)r0.w, w));
+            kz = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)r1, w));
+            vbits = mb;
+        }
+        if constexpr (CERT) cert.update(vbits);
+        const int k = key == 0xFFFFFFFFu ? 0 : (int)key;   // (no candidate: an empty cloud; its rows are index 0, coordinates 0)
+        qx = kx;
+        qy = ky;
+        qz = kz;
+        if (wave == 0) outbuf[j & (kWave - 1)] = make_float4(__int_as_float(k), qx, qy, qz);   // every lane of wave 0: the same 16 bytes
+        if ((j & (kWave - 1)) == kWave - 1 && wave == 0) {   // wave-uniform: wave 0 flushes a full chunk of 64 rows by itself
+            wave_lds_fence();
+            const float4 o = outbuf[lane];
+            fps_emit(a, start_m + j - (kWave - 1) + lane, start_n, __float_as_int(o.x), o.y, o.z, o.w);
+            wave_lds_fence();
+        }
+    }
+    if (wave == 0 && ((m - 1) & (kWave - 1)) != kWave - 1) {   // rows of the last, partial chunk
+        wave_lds_fence();
+        const int cb = ((m - 1) / kWave) * kWave;
+        if (cb + lane <= m - 1) {
+            const float4 o = outbuf[lane];
+            fps_emit(a, start_m + cb + lane, start_n, __float_as_int(o.x), o.y, o.z, o.w);
+        }
+    }
+    if (a.prefix_out && tid == 0) a.prefix_out[blockIdx.x] = CERT ? cert.value(m) : 1;   // not tracked: no claim
+}
+
+// lean shapes: (threads, points per lane), ordered by capacity
+#define TGN_FPS_LEAN_CONFIGS(X) X(64, 8) X(256, 4) X(256, 8) X(512, 8)
+
 // ---------------------------------------------------------------------------------------------
 // Streaming fallback for clouds larger than the register file of one CU: coordinates and the
 // running minimum are re-read from memory (L2 / Infinity Cache resident) every iteration, as the
@@ -234,6 +417,19 @@ static int fps_launch(int b, int n_max, const FpsArgs &a, hipStream_t stream) {
         if (!tuning(kTuneFpsPlain)) {   // experiments: "fps_plain" forces the plain (no skipping) kernels
             const int rc = fps_bucket_launch(MODE, b, n_max, a, stream);
             if (rc >= 0) return rc;
+        }
+    }
+    if constexpr ((MODE & 2) == 0) {
+        // small clouds, canonical tie order: the lean kernel ("fps_lean": 0 = off, 1 = clouds of 257 .. 2048 points, 2 = up to 4096)
+        const int lean = tuning(kTuneFpsLean);
+        if (lean && n_max > 256 && n_max <= (lean >= 2 ? 4096 : 2048) && !tuning(kTuneFpsConfig)) {
+#define X(NT_, P_)                                                                                      \
+    if (n_max <= NT_ * P_) {                                                                            \
+        hipLaunchKernelGGL((fps_lean_kernel<NT_, P_, MODE>), dim3(b), dim3(NT_), 0, stream, a);       \
+        return check_launch("fps_lean_kernel");                                                         \
+    }
+            TGN_FPS_LEAN_CONFIGS(X)
+#undef X
         }
     }
     if (fps_pick(n_max, cfg)) {

@@ -305,8 +305,6 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void sa_mlp2_max_split_k
     const IdxT *__restrict__ idx, const unsigned char *__restrict__ W2s,   // split image of W2 (128-column tiles)
     const float *__restrict__ b2, float *__restrict__ out, int *__restrict__ err) {
     constexpr int MT = WM * 64, NTL = TN * 64, THREADS = WM * 128;
-    const int xflags = ostride >> 28;      // experiment switches ride in the top bits of the row stride ("sa_dephase", capi.hip)
-    ostride &= 0x0FFFFFFF;
     constexpr int kAPlane = MT * 32, kATile = 3 * kAPlane;          // bytes
     constexpr int kBTile = (NTL / 128) * kSplitTile;                // one or two 128-column tiles of the image, back to back
     constexpr int kPieces = kBTile / 1024 / (2 * WM);               // LDS-DMA pieces per wave and K tile
@@ -485,15 +483,6 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void sa_mlp2_max_split_k
     fetch(last < 1 ? last : 1);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the LDS-DMA pieces have landed (hipcc orders no ds_read behind them)
     __syncthreads();
-    if (DIRECT && (xflags & 9)) {
-        // experiment: the two workgroups of a CU run their trips in phase (first-layer arithmetic together, then matrix instructions
-        // together).  The one whose waves sit in odd hardware wave slots (HW_ID[3:0]) starts its K loop half a trip late.
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        if ((xflags & 1) && (hwid & 1u))
-            for (int z = 0; z < 2 + ((xflags >> 1) & 3); ++z) __builtin_amdgcn_s_sleep(8);   // 512 cycles each
-        if ((xflags & 8) && (hwid & 1u)) __builtin_amdgcn_s_setprio(2);   // ... or simply wins every arbitration on its SIMD
-    }
     if constexpr (DIRECT) {
         // (255 registers: this read order and this product order are the ones the form does not spill in)
         auto tile = [&](int buf) {
@@ -812,7 +801,7 @@ static int sa_mlp2_launch(const char *who, int B, int N, int S, int K, int D, in
         (void)hipFuncSetAttribute((const void *)sa_mlp2_max_split_kernel<IT, DIR, WM_, TN_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)(LDS_));                                                                                    \
     hipLaunchKernelGGL((sa_mlp2_max_split_kernel<IT, DIR, WM_, TN_>), dim3((unsigned)(BLOCKS_)), dim3(WM_ * 128), (LDS_), st, Q, N, S, K, D, \
-                       C1p, C2, out_stride | ((DIR) ? (tuning(kTuneSaDephase) & 15) << 28 : 0), A1, xyz, points, new_xyz, W1, b1, (const IT *)idx, (const unsigned char *)W2f, b2, out, err)
+                       C1p, C2, out_stride, A1, xyz, points, new_xyz, W1, b1, (const IT *)idx, (const unsigned char *)W2f, b2, out, err)
     if (split) {
         if (ntiles * (long long)(C1p / kMlpKT) * kSplitTile > 0x7FFFFFFFLL || ((uintptr_t)W2f & 15)) {
             set_error("%s: split weight image too large or misaligned", who);

@@ -35,7 +35,7 @@ enum Tuning {
     kTuneSaTile,            // "sa_tile": 0 = pick, 128 / 256 = force the workgroup tile of tgn_sa_mlp2_max_bf16x3
     kTuneGatherV4,          // "gather_v4": gather-family variants, bit 0: forward kernels with 16-byte lanes; bit 1: backward kernels with
                             // 16-byte lanes; bit 2: subtraction / aggregation backward with dword lanes and owner-side sums (wins over bit 1)
-    kTuneSaDephase,         // "sa_dephase": experiment switches of the direct-form chained set-abstraction kernel (0 = off)
+    kTuneFpsLean,           // "fps_lean": 0 = fps_resident_kernel for small clouds too, 1 = fps_lean_kernel for 257 .. 2048 points, 2 = up to 4096
     kTuneCount
 };
 int tuning(Tuning t);

@@ -25,6 +25,19 @@ SHAPE_B = dict(n=24000, npoint=[1024, 512, 256], radius=[[0.025, 0.05], [0.05, 0
 #                branches of a level (pointnet_pp.py:13-15, scale 4); the branches' outputs sit side by side: D of the next level
 
 
+# One set of side streams per (device, role) for the whole process: every HotPath launches on the same four.  Streams are not
+# free -- the runtime maps them onto a handful of hardware queues (_lib.py: GPU_MAX_HW_QUEUES) and two streams on one queue
+# serialise -- and two HotPath objects never need to overlap EACH OTHER.
+_STREAMS = {}
+
+
+def _side_stream(device, role, priority):
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), role)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
+    return _STREAMS[key]
+
+
 def _branch_mlps(mlp_level, nbranches):
     """shape['mlp'][level]: one list of widths for every branch, or one list per branch"""
     if isinstance(mlp_level[0], (list, tuple)):
@@ -141,10 +154,10 @@ class HotPath:
         self.plan = dict(plan) if plan is not None else None
         if self.pipeline:
             nl = len(shape["npoint"])
-            self.s_fps = torch.cuda.Stream(device=device, priority=-1)
-            self.s_rest = torch.cuda.Stream(device=device, priority=0)
-            self.s_ball = torch.cuda.Stream(device=device, priority=-1) if self.phased else None
-            self.s_grid = torch.cuda.Stream(device=device, priority=0) if (self.phased and self.grid_stream == "own") else None
+            self.s_fps = _side_stream(device, "fps", -1)
+            self.s_rest = _side_stream(device, "rest", 0)
+            self.s_ball = _side_stream(device, "ball", -1) if self.phased else None
+            self.s_grid = _side_stream(device, "grid", 0) if (self.phased and self.grid_stream == "own") else None
             self.ev_ball = [[torch.cuda.Event() for _ in range(nl)] for _ in range(2)]
             self.ev_fps = [[torch.cuda.Event() for _ in range(nl)] for _ in range(2)]
             self.ev_grid = [torch.cuda.Event() for _ in range(2)]
@@ -319,7 +332,7 @@ class HotPath:
         fn()
         b.record(stream)
 
-    def run(self, xyz, feats, inputs_on_current_stream=True, input_event=None):
+    def run(self, xyz, feats, inputs_on_current_stream=True, input_event=None, more=True):
         """xyz: (B, N, 3) fp32 contiguous; feats: list of per-level feature tensors (B, N_l, D_l).
         Results land in self.levels[l]['grouped'] etc. (pipelined: self.sets[step parity]).  Asynchronous.
         Pipelined mode: the results of a call live in one of two buffer sets and are overwritten by the call after
@@ -328,13 +341,16 @@ class HotPath:
         that wait (the inputs were complete long ago, e.g. a resident dataset), so that this step does not wait for
         the previous step's results and consecutive steps overlap; the caller then has to make sure on its own that
         its reads of step k's results are done before it issues call k+2 (tools/pipeline_stress.py).
+        more=False (pipelined mode): no further call follows this one.  The groupings of a step normally run beside the NEXT step's
+        FPS level 1, their grids bounded to the one wave per SIMD it leaves free; the last step of a batch has nothing beside it
+        and lets them use the whole chip (1.8 instead of 3.0 ms of tail).
         input_event (pipelined mode): a torch.cuda.Event behind which this call's inputs are complete -- e.g. recorded on a copy
         stream behind the host-to-device copy of this step's scans; the step's streams wait for it and for nothing else of the
         caller's, so the copy of step k+1 overlaps step k."""
         if self.pipeline:
             if self.phased and self.plan is None:
                 self.plan = self._calibrate(xyz, feats)
-            return self._run_pipelined(xyz, feats, inputs_on_current_stream, input_event)
+            return self._run_pipelined(xyz, feats, inputs_on_current_stream, input_event, more)
         return self._run_one_stream(xyz, feats, self.levels, timed=True)
 
     def _run_one_stream(self, xyz, feats, levels, timed=False):
@@ -403,7 +419,7 @@ class HotPath:
                                                          ptr(lv["new_xyz"]), ptr(cert_in), None, ptr(lv["cert"]),
                                                          flags, st), "fps")
 
-    def _run_pipelined(self, xyz, feats, inputs_on_current_stream=True, input_event=None):
+    def _run_pipelined(self, xyz, feats, inputs_on_current_stream=True, input_event=None, more=True):
         p = self.step_no & 1
         levels = self.sets[p]
         nl = len(levels)
@@ -461,8 +477,12 @@ class HotPath:
                 lj = levels[j]
                 self._timed(f"ball_l{j + 1}", lambda: [self._ball(lj, br, clouds[j], pg) for br in lj["branches"]], sg)
                 self.ev_ball[p][j].record(sg)
+            bound = self.group_max_blocks
+            if not more:
+                self.group_max_blocks = 0                 # the last step of a batch: nothing runs beside its groupings
             for i, lv in enumerate(levels):
                 self._timed(f"group_l{i + 1}", lambda: self._consume(i, lv, clouds[i], feats, levels, pg), sg)
+            self.group_max_blocks = bound
         else:
             for i, lv in enumerate(levels):
                 self._timed(f"fps_l{i + 1}", lambda: self._fps(i, lv, clouds[i], levels, pf), sf)
