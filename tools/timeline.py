@@ -11,7 +11,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ks = []
 for r in rows:
     n = r["Kernel_Name"]
-    short = ("fps_l1" if "fps_bucket_kernel<512, 48" in n else "fps_l2" if "fps_bucket" in n else "fps_l3" if "fps_resident" in n
+    short = ("fps_l1" if "fps_bucket_kernel<512, 48" in n else "fps_l2" if "fps_bucket" in n else "fps_l3" if ("fps_resident" in n or "fps_lean" in n)
              else "grid" if "grid_build" in n else "query" if ("ball_grid_query" in n or "ball_query_scan" in n)
              else "group_l1" if "pairs" in n else "group_l23" if "rows_kernel" in n else "spacer" if "delay" in n
              else "group" if "group_points" in n else None)

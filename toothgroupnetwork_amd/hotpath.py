@@ -468,20 +468,31 @@ class HotPath:
                     sb.wait_event(self.ev_grid[p])
                 self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, clouds[i], pb, prebuilt=(i == 0)) for br in lv["branches"]], sb)
                 self.ev_ball[p][i].record(sb)
-            # all of this step's groupings run beside the NEXT step's FPS level 1: released by the last phase-2 query
-            sg.wait_event(self.ev_ball[p][early - 1])
-            sg.wait_event(self.ev_fps[p][nl - 1])     # ... and by the last FPS level: the end of phase 2, whichever chain is longer
-            if self.plan.get("spacer_us"):
-                check(self.L.tgn_stream_delay(int(self.plan["spacer_us"]), pg), "stream_delay")
-            for j in range(early, nl):
-                lj = levels[j]
-                self._timed(f"ball_l{j + 1}", lambda: [self._ball(lj, br, clouds[j], pg) for br in lj["branches"]], sg)
-                self.ev_ball[p][j].record(sg)
             bound = self.group_max_blocks
-            if not more:
-                self.group_max_blocks = 0                 # the last step of a batch: nothing runs beside its groupings
-            for i, lv in enumerate(levels):
-                self._timed(f"group_l{i + 1}", lambda: self._consume(i, lv, clouds[i], feats, levels, pg), sg)
+            if more:
+                # all of this step's groupings run beside the NEXT step's FPS level 1: released by the last phase-2 query
+                sg.wait_event(self.ev_ball[p][early - 1])
+                sg.wait_event(self.ev_fps[p][nl - 1])     # ... and by the last FPS level: the end of phase 2, whichever chain is longer
+                if self.plan.get("spacer_us"):
+                    check(self.L.tgn_stream_delay(int(self.plan["spacer_us"]), pg), "stream_delay")
+                for j in range(early, nl):
+                    lj = levels[j]
+                    self._timed(f"ball_l{j + 1}", lambda: [self._ball(lj, br, clouds[j], pg) for br in lj["branches"]], sg)
+                    self.ev_ball[p][j].record(sg)
+                for i, lv in enumerate(levels):
+                    self._timed(f"group_l{i + 1}", lambda: self._consume(i, lv, clouds[i], feats, levels, pg), sg)
+            else:
+                # the last step of a batch: nothing follows, nothing to keep clear of -- each grouping starts when its own query is
+                # through, on the whole chip (the queries of levels >= early run here, each behind its FPS level)
+                self.group_max_blocks = 0
+                for i, lv in enumerate(levels):
+                    if i < early:
+                        sg.wait_event(self.ev_ball[p][i])
+                    else:
+                        sg.wait_event(self.ev_fps[p][i])
+                        self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, clouds[i], pg) for br in lv["branches"]], sg)
+                        self.ev_ball[p][i].record(sg)
+                    self._timed(f"group_l{i + 1}", lambda: self._consume(i, lv, clouds[i], feats, levels, pg), sg)
             self.group_max_blocks = bound
         else:
             for i, lv in enumerate(levels):
