@@ -47,6 +47,12 @@ typedef void *tgn_stream_t; /* a hipStream_t; NULL = the null stream */
                                  Alone it is ~15 % slower there than the plain register-resident kernel, but it issues a tenth of
                                  the vector instructions -- the right choice when the launch runs beside ALU-bound work */
 
+#define TGN_FPS_THROUGHPUT 32 /* scheduling hint, same results: clouds of 4 097 - 32 768 points run the owner-wave kernel out of a
+                                 cell-sorted, L2-resident workspace (tgn_fps_throughput_workspace_bytes; the *_ws / *_prefix entry
+                                 points) instead of out of registers: 58 VGPRs per lane, so FOUR workgroups share a CU where the
+                                 register-resident kernel allows one.  A single cloud takes 1.5x as long; a batch of several
+                                 clouds per CU finishes sooner (profiles/r06_fps_throughput.txt).  Ignored without a workspace. */
+
 const char *tgn_version(void);
 const char *tgn_last_error(void);     /* per host thread */
 /* Stream of the section-1 entry points (which have no stream argument); per host thread, default NULL. */
@@ -132,6 +138,8 @@ int tgn_fps_resident_capacity(void);
  * buffer used as the reference's tmp array, which then must hold 4 B per point of the batch).
  */
 size_t tgn_fps_workspace_bytes(int b, int n_max);
+/* Workspace of the TGN_FPS_THROUGHPUT form (20 B per point, whatever the cloud size up to 32 768 points; 0 above). */
+size_t tgn_fps_throughput_workspace_bytes(int b, int n_max);
 int tgn_furthestsampling_ws(int b, int n_max, const float *xyz, const int *offset, const int *new_offset,
                             void *workspace, size_t workspace_bytes, void *idx, float *new_xyz, int flags,
                             tgn_stream_t stream);

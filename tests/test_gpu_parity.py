@@ -133,6 +133,56 @@ def test_fps_lean_kernel_every_shape_ties_nan_ragged(dev, oracle, mode):
         assert np.array_equal(outs[2][1], outs[0][1], equal_nan=True)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_fps_throughput_form_equals_the_register_resident_kernel_and_the_oracle(dev, oracle, mode):
+    """TGN_FPS_THROUGHPUT (include/tgn_pointops.h): clouds of 4 097 - 32 768 points on the owner-wave kernel out of the L2-resident
+    workspace, four workgroups per CU -- a scheduling choice for large batches.  Ragged packed batch with exact ties (lattice +
+    duplicated vertices), NaN coordinates, a cloud at the 32 768-point limit; all four arithmetic / tie-order modes; the result must be
+    the oracle's and the register-resident kernel's, indices and coordinates."""
+    from toothgroupnetwork_amd import _lib
+    L = _lib.lib()
+    flags = (_lib.FPS_FMA if mode & 1 else 0) | (_lib.FPS_TREE_TIES if mode & 2 else 0)
+    lat = synth.lattice_cloud(18, dup=400, seed=7)                 # 6232 points, many exact ties
+    arch = synth.arch_cloud(24000, 3, False)
+    arch[[5, 4000, 23999]] = np.nan
+    big = synth.arch_cloud(32768, 4, False)
+    small = synth.uniform_cloud(4500, 9)
+    clouds, ms = [lat, arch, big, small], [1500, 4096, 700, 4500]
+    xyz_np = np.concatenate(clouds)
+    off_np = np.cumsum([c.shape[0] for c in clouds]).astype(np.int32)
+    noff_np = np.cumsum(ms).astype(np.int32)
+    n_max = max(c.shape[0] for c in clouds)
+    xyz, off, noff = T(xyz_np, dev), T(off_np, dev), T(noff_np, dev)
+    nbytes = int(L.tgn_fps_throughput_workspace_bytes(len(clouds), n_max))
+    assert nbytes >= 20 * len(clouds) * n_max
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    outs = {}
+    for name, extra in (("l2", _lib.FPS_THROUGHPUT), ("plain", 0)):
+        idx = torch.full((int(noff_np[-1]),), -7, dtype=torch.int32, device=dev)
+        nx = torch.full((int(noff_np[-1]), 3), -7.0, device=dev)
+        _lib.check(L.tgn_furthestsampling_ws(len(clouds), n_max, _lib.ptr(xyz), _lib.ptr(off), _lib.ptr(noff), _lib.ptr(ws), nbytes,
+                                             _lib.ptr(idx), _lib.ptr(nx), flags | extra, _lib.stream()))
+        outs[name] = (idx.cpu().numpy(), nx.cpu().numpy())
+    want = oracle.furthestsampling(xyz_np, off_np, noff_np, mode=mode)
+    assert np.array_equal(outs["l2"][0], want), mode
+    assert np.array_equal(outs["plain"][0], want), mode
+    assert np.array_equal(outs["l2"][1], xyz_np[want.astype(np.int64)], equal_nan=True)
+    assert np.array_equal(outs["l2"][1], outs["plain"][1], equal_nan=True)
+    assert int(L.tgn_fps_throughput_workspace_bytes(4, 4096)) == 0 and int(L.tgn_fps_throughput_workspace_bytes(4, 32769)) == 0
+
+
+def test_farthest_point_sample_takes_the_throughput_form_for_large_batches(dev, oracle):
+    """pointnet2_utils.farthest_point_sample with three or more clouds per CU: the L2-resident form (same indices as the oracle)"""
+    from toothgroupnetwork_amd import pointnet2_utils as U
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    B = 3 * cus
+    base = np.stack([synth.arch_cloud(4200, 60 + i, False) for i in range(4)])
+    xyz_np = np.tile(base, (B // 4 + 1, 1, 1))[:B]
+    got = U.farthest_point_sample(T(xyz_np, dev), 96).cpu().numpy()
+    want = oracle.farthest_point_sample(base, 96)
+    assert np.array_equal(got, want[np.arange(B) % 4])
+
+
 def test_fps_packed_ragged_batch_and_modes(dev, oracle, regression):
     from toothgroupnetwork_amd import _lib, pointops as P
     r = regression

@@ -55,6 +55,7 @@ SIGNATURES = {
     "tgn_furthestsampling_dense": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "tgn_fps_resident_capacity": (c_int, []),
     "tgn_fps_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "tgn_fps_throughput_workspace_bytes": (c_size_t, [c_int, c_int]),
     "tgn_furthestsampling_ws": (c_int, [c_int, c_int, _P, _P, _P, _P, c_size_t, _P, _P, c_int, _P]),
     "tgn_furthestsampling_dense_ws": (c_int, [c_int, c_int, c_int, _P, _P, c_size_t, _P, _P, c_int, _P]),
     "tgn_furthestsampling_prefix": (c_int, [c_int, c_int, _P, _P, _P, _P, c_size_t, _P, _P, _P, _P, _P, c_int, _P]),
@@ -126,6 +127,7 @@ ERR_INVALID_ARGUMENT, ERR_LAUNCH, ERR_UNSUPPORTED = 1, 2, 3     # TGN_ERR_* of i
 FPS_FMA = 1
 FPS_LOCAL_INDEX = 2
 FPS_INDEX64 = 4
+FPS_THROUGHPUT = 32   # scheduling hint: 4 097 - 32 768-point clouds out of an L2-resident workspace, four workgroups per CU
 FPS_LOW_VALU = 16   # scheduling hint (include/tgn_pointops.h): small clouds on the bucket-skipping kernel too
 FPS_TREE_TIES = 8
 FPS_CUDA_COMPAT = FPS_FMA | FPS_TREE_TIES

@@ -413,6 +413,10 @@ static bool fps_pick(int n_max, FpsConfig &out) {
 template <int MODE>
 static int fps_launch(int b, int n_max, const FpsArgs &a, hipStream_t stream) {
     FpsConfig cfg;
+    if ((a.flags & TGN_FPS_THROUGHPUT) && a.ws && n_max > 4096) {   // several workgroups per CU out of the L2-resident workspace
+        const int rc = fps_bucket_owner_small_launch(MODE, b, n_max, a, stream);
+        if (rc >= 0) return rc;
+    }
     {
         if (!tuning(kTuneFpsPlain)) {   // experiments: "fps_plain" forces the plain (no skipping) kernels
             const int rc = fps_bucket_launch(MODE, b, n_max, a, stream);
@@ -499,6 +503,11 @@ TGN_API int tgn_furthestsampling(int b, int n_max, const float *xyz, const int *
     }
     FpsArgs a{xyz, offset, new_offset, 0, 0, idx, new_xyz, tmp, nullptr, 0, n_max, flags, 0};
     return fps_dispatch(b, n_max, a, (hipStream_t)stream);
+}
+
+TGN_API size_t tgn_fps_throughput_workspace_bytes(int b, int n_max) {
+    if (n_max <= 4096 || n_max > 32768) return 0;
+    return fps_stream_workspace_bytes(b, n_max);
 }
 
 TGN_API size_t tgn_fps_workspace_bytes(int b, int n_max) {

@@ -920,6 +920,22 @@ int fps_bucket_stream_launch(int mode, int b, int n_max, const FpsArgs &a, hipSt
     return check_launch("fps_bucket_owner_kernel");
 }
 
+// TGN_FPS_THROUGHPUT: 8 waves x 64 bucket lanes = 512 buckets = 32 768 points, 4096 Z-order cells (16 KiB of LDS), 58 VGPRs:
+// four workgroups per CU
+constexpr int kOwnerSmallThreads = 512, kOwnerSmallMax = kOwnerSmallThreads / kWave * kWave * kWave;
+int fps_bucket_owner_small_launch(int mode, int b, int n_max, const FpsArgs &a, hipStream_t stream) {
+    if (!a.ws || n_max > kOwnerSmallMax || n_max <= 0 || a.ws_bytes < fps_stream_workspace_bytes(b, n_max)) return -1;
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((fps_bucket_owner_kernel<0, 1, kOwnerSmallThreads, 4>), dim3(b), dim3(kOwnerSmallThreads), 0, stream, a); break;
+        case 1: hipLaunchKernelGGL((fps_bucket_owner_kernel<1, 1, kOwnerSmallThreads, 4>), dim3(b), dim3(kOwnerSmallThreads), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((fps_bucket_owner_kernel<2, 1, kOwnerSmallThreads, 4>), dim3(b), dim3(kOwnerSmallThreads), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((fps_bucket_owner_kernel<3, 1, kOwnerSmallThreads, 4>), dim3(b), dim3(kOwnerSmallThreads), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((fps_bucket_owner_kernel<4, 1, kOwnerSmallThreads, 4>), dim3(b), dim3(kOwnerSmallThreads), 0, stream, a); break;
+        default: hipLaunchKernelGGL((fps_bucket_owner_kernel<5, 1, kOwnerSmallThreads, 4>), dim3(b), dim3(kOwnerSmallThreads), 0, stream, a); break;
+    }
+    return check_launch("fps_bucket_owner_kernel<small>");
+}
+
 #define TGN_FPS_BUCKET_CONFIGS(X) X(256, 8) X(256, 16) X(512, 16) X(512, 24) X(512, 32) X(512, 48) X(512, 56)
 
 template <int MODE>

@@ -232,5 +232,8 @@ int fps_bucket_launch(int mode, int b, int n_max, const FpsArgs &a, hipStream_t 
 // large clouds through a cell-sorted workspace; -1 if the workspace is missing / too small / cloud too large
 int fps_bucket_stream_launch(int mode, int b, int n_max, const FpsArgs &a, hipStream_t stream);
 size_t fps_stream_workspace_bytes(int b, int n_max);
+// TGN_FPS_THROUGHPUT: the owner-wave kernel with 8 waves and one metadata group for clouds of up to 32 768 points; -1 if the
+// workspace is missing / too small or the cloud too large
+int fps_bucket_owner_small_launch(int mode, int b, int n_max, const FpsArgs &a, hipStream_t stream);
 
 }  // namespace tgn
