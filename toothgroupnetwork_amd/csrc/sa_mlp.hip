@@ -298,8 +298,11 @@ __global__ __launch_bounds__(256) void sa_mlp2_split_weights_kernel(int C1p, int
 // the memory system, not the matrix cores: every 128 rows re-read the whole weight image (4.7 MB at 784 x 1024: more than an XCD's
 // L2) and every 128 columns re-gather the rows -- 26 flop per byte, 7.8 TB/s of L2 / Infinity-Cache traffic at 200 TFLOP/s
 // (profiles/r04_sa_split_counters.txt).  The 256 x 256 tile halves both streams.
+#ifndef TGN_SA_SPLIT_BLOCKS
+#define TGN_SA_SPLIT_BLOCKS 2   // workgroups per CU the 128 x 128 form is compiled for (A/B builds: 3 = 168 VGPRs, spills; tools/ab_build.sh)
+#endif
 template <typename IdxT, bool DIRECT, int WM, int TN>
-__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void sa_mlp2_max_split_kernel(
+__global__ __launch_bounds__(WM * 128, WM == 2 ? TGN_SA_SPLIT_BLOCKS : 1) void sa_mlp2_max_split_kernel(
     long long Q, int N, int S, int K, int D, int C1p, int C2, int ostride, const float *__restrict__ A1, const float *__restrict__ xyz,
     const float *__restrict__ points, const float *__restrict__ new_xyz, const float *__restrict__ W1, const float *__restrict__ b1,
     const IdxT *__restrict__ idx, const unsigned char *__restrict__ W2s,   // split image of W2 (128-column tiles)
