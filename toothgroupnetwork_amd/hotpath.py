@@ -466,8 +466,13 @@ class HotPath:
                 sb.wait_event(self.ev_fps[p][i])
                 if i == 0:
                     sb.wait_event(self.ev_grid[p])
-                self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, clouds[i], pb, prebuilt=(i == 0)) for br in lv["branches"]], sb)
+                # (levels > 0: the grid was built on this stream behind the previous level's query -- its cloud, the previous level's
+                #  samples, was complete then; only the queries wait for this level's FPS)
+                self._timed(f"ball_l{i + 1}", lambda: [self._ball(lv, br, clouds[i], pb, prebuilt=True) for br in lv["branches"]], sb)
                 self.ev_ball[p][i].record(sb)
+                if i + 1 < early:
+                    for br in levels[i + 1]["branches"]:
+                        self._ball_build(levels[i + 1], br, clouds[i + 1], pb)
             bound = self.group_max_blocks
             if more:
                 # all of this step's groupings run beside the NEXT step's FPS level 1: released by the last phase-2 query
