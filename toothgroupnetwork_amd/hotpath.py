@@ -172,11 +172,11 @@ class HotPath:
         pl = self.plan or {}
         nl = len(self.shape["npoint"])
         early = pl.get("last_query_early")
-        return ("3 HIP streams, 2 phases per step: FPS level 1 of step k beside the groupings of step k-1" +
+        return (("4" if self.s_grid is not None else "3") + " HIP streams, 2 phases per step: FPS level 1 of step k beside the groupings of step k-1" +
                 (f" (held back {pl['spacer_us']} us)" if "spacer_us" in pl else "") +
                 (f", then FPS levels 2-{nl} beside the ball queries of levels 1-{nl - 1} (level {nl}: in front of the groupings)"
                  if early else f", then FPS levels 2-{nl} beside the {nl} ball queries") +
-                " and the next step's level-1 ball-query grid" +
+                " and the next step's level-1 ball-query grid" + (" (on a stream of its own)" if self.s_grid is not None else "") +
                 ("" if pl else " [plan measured on the first run]") +
                 (f"; calibration: FPS level 1 {pl['fps_l1_ms']:.2f} ms, its set-up {pl['setup_ms']:.3f} ms, groupings {pl['group_ms']:.2f} ms"
                  if "fps_l1_ms" in pl else ""))
