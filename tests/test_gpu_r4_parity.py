@@ -228,10 +228,12 @@ def test_training_step_gradients_match_the_reference_network(dev, golden_r4):
     # on the same entries and 2 % of the parameter's gradient (the reference's own median relative distance is 1 %); the floor is
     # fp32 resolution at the scale of the network's gradient -- the biases in front of a BatchNorm have an EXACT gradient of zero
     # (2.6e-15 in float64) and what either fp32 run holds there is the rounding residue of a sum over all rows
-    floor = 1e-6 * (1.0 + tot_ref)
+    # (4e-6: 1e-6 failed about one run in 25 on 'enc3.2.transformer2.linear_p.0.bias' -- exact gradient 2e-14, residue 3.2e-5 at a
+    #  gradient scale of 15 with the atomic scatters of the backward in a different order; the reference's own fp32 run holds 5.9e-6 there)
+    floor = 4e-6 * (1.0 + tot_ref)
     for n, n64, ng, d_got, d_own, s_ref in rows:
         assert d_got <= max(4.0 * d_own, 0.02 * s_ref, floor), (n, d_got, d_own, s_ref)
-        assert abs(ng - n64) <= max(4.0 * abs(norms[names.index(n), 1] - n64), 0.02 * n64, 8 * floor), (n, ng, n64)
+        assert abs(ng - n64) <= max(4.0 * abs(norms[names.index(n), 1] - n64), 0.02 * n64, 2 * floor), (n, ng, n64)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
