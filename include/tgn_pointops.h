@@ -259,6 +259,9 @@ int tgn_ball_query(int B, int N, int S, int nsample, float r2, const float *xyz,
  * not on the queries -- it can run while the sampling that produces new_xyz is still in flight), _prebuilt answers the
  * queries from a workspace filled by _build with the same (B, N, S, nsample, r2, xyz).  Same results as tgn_ball_query.
  */
+/* out[r, 0..ncols) = in[r, first..first+ncols) for `rows` rows of `stride` floats: the xyz block of (N, 6) scan rows
+ * (gen_utils.py:138, pointnet_pp_model.py:16-20) without torch's strided-copy kernel (10x slower beside a running FPS launch) */
+int tgn_slice_columns(long long rows, int stride, int first, int ncols, const float *in, float *out, tgn_stream_t stream);
 /* scheduling spacer: a one-wave kernel that idles for about `microseconds` on `stream` (planners: hold one stream's work
  * back behind another's start without a host round trip) */
 int tgn_stream_delay(int microseconds, tgn_stream_t stream);

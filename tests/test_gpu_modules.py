@@ -436,3 +436,19 @@ def test_linear_relu_private_epilogue_equals_the_public_fallback(dev, monkeypatc
         assert fast.shape == slow.shape == ref.shape
         assert torch.equal(slow, ref)
         assert torch.equal(fast, slow), (rows, cin, cout, float((fast - slow).abs().max()))
+
+
+def test_slice_columns_equals_torch_slicing(dev):
+    """tgn_slice_columns (the xyz block of (N, 6) scan rows on a side stream) against torch indexing, incl. a middle block and bad arguments"""
+    from toothgroupnetwork_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    for rows, stride, first, ncols in [(24000 * 5 + 7, 6, 0, 3), (1000, 6, 3, 3), (77, 9, 2, 5), (0, 6, 0, 3)]:
+        x = torch.randn(rows, stride, generator=g).to(dev)
+        out = torch.full((rows, ncols), -7.0, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        _lib.check(L.tgn_slice_columns(rows, stride, first, ncols, _lib.ptr(x), _lib.ptr(out), _lib.c_void_p(side.cuda_stream)), "slice")
+        side.synchronize()
+        assert torch.equal(out, x[:, first:first + ncols])
+    assert L.tgn_slice_columns(10, 6, 4, 3, _lib.ptr(x), _lib.ptr(out), _lib.stream()) != 0      # columns [4, 7) of 6

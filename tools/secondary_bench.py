@@ -173,7 +173,10 @@ def hot_path_with_h2d(make_inputs, device, B=256, steps=8, warmup=3):
             if k >= NB:
                 s_copy.wait_event(ev_after[p])                         # buffer p's last readers: step k-3's groupings
             pts[p].copy_(host, non_blocking=True)
-            xyzs[p].copy_(pts[p][:, :, :3])                             # the (B, N, 3) coordinate block the samplers read
+            # the (B, N, 3) coordinate block the samplers read (torch's strided copy_ takes 0.7-1.6 ms in the one wave slot beside
+            # a running FPS level 1 -- its 256-thread blocks of 4 elements per thread; the row kernel 0.1-0.2 ms)
+            _lib.check(_lib.lib().tgn_slice_columns(B * shape["n"], 6, 0, 3, _lib.ptr(pts[p]), _lib.ptr(xyzs[p]),
+                                                    _lib.c_void_p(s_copy.cuda_stream)), "slice_columns")
             ev_in[p].record(s_copy)
         hp.run(xyzs[p], [pts[p]] + feats_d[1:], inputs_on_current_stream=False, input_event=ev_in[p])
         ev_after[p].record(torch.cuda.current_stream())

@@ -80,6 +80,7 @@ SIGNATURES = {
     "tgn_ball_query_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "tgn_ball_query": (c_int, [c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "tgn_stream_delay": (c_int, [c_int, _P]),
+    "tgn_slice_columns": (c_int, [ctypes.c_longlong, c_int, c_int, c_int, _P, _P, _P]),
     "tgn_ball_query_build": (c_int, [c_int, c_int, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
     "tgn_ball_query_prebuilt": (c_int, [c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "tgn_group_points": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P]),

@@ -172,6 +172,43 @@ __global__ void delay_kernel(unsigned ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 }  // namespace tgn
+namespace tgn {
+// out[r, 0 .. ncols) = in[r, first .. first + ncols) for rows of `stride` floats: the coordinate block of a scan's (N, 6) rows
+// (gen_utils.py:138 / pointnet_pp_model.py:16-20 slice it with torch indexing).  Rows are dealt to lanes in quads: a lane moves
+// whole rows, consecutive lanes consecutive rows -- the reads of a wave cover one contiguous range, the writes another.
+__global__ __launch_bounds__(256) void slice_columns_kernel(long long rows, int stride, int first, int ncols,
+                                                            const float *__restrict__ in, float *__restrict__ out) {
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += nthreads) {
+        const float *__restrict__ src = in + r * stride + first;
+        float *__restrict__ dst = out + r * ncols;
+        if (ncols == 3) {   // (the case that matters: unrolled)
+            const float a = src[0], b = src[1], c = src[2];
+            dst[0] = a;
+            dst[1] = b;
+            dst[2] = c;
+        } else {
+            for (int c = 0; c < ncols; ++c) dst[c] = src[c];
+        }
+    }
+}
+}  // namespace tgn
+TGN_API int tgn_slice_columns(long long rows, int stride, int first, int ncols, const float *in, float *out, tgn_stream_t stream) {
+    if (rows < 0 || stride <= 0 || first < 0 || ncols < 0 || first + ncols > stride) {
+        tgn::set_error("tgn_slice_columns: rows %lld, stride %d, columns [%d, %d)", rows, stride, first, first + ncols);
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    if (rows == 0 || ncols == 0) return TGN_OK;
+    if (!in || !out) {
+        tgn::set_error("tgn_slice_columns: null pointer");
+        return TGN_ERR_INVALID_ARGUMENT;
+    }
+    long long blocks = (rows + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(tgn::slice_columns_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, stride, first, ncols, in, out);
+    return tgn::check_launch("slice_columns_kernel");
+}
+
 TGN_API int tgn_stream_delay(int microseconds, tgn_stream_t stream) {
     if (microseconds <= 0) return TGN_OK;
     hipLaunchKernelGGL(tgn::delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned)microseconds * 100u);
