@@ -92,14 +92,15 @@ def test_fps_low_valu_hint_changes_the_kernel_not_the_result(dev, oracle):
         assert np.array_equal(outs[1][0], oracle.farthest_point_sample(xyz_np, m)), (n, m)
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_fps_lean_kernel_every_shape_ties_nan_ragged(dev, oracle, mode):
     """fps_lean_kernel (csrc/fps.hip: packed-pair arithmetic, value-only arg-max, coordinates in the wave records) at every
     shape it has -- 64x8, 256x4, 256x8, 512x8 -- on one ragged packed batch: lattices with duplicated vertices (exact ties
     inside a lane, across lanes and across waves), NaN coordinates, a cloud sampled to exhaustion, exact-capacity sizes;
-    plain and FMA arithmetic; against the oracle, against the kernel it replaces, and the coordinates it emits."""
+    plain and FMA arithmetic, first-index and tree tie order; against the oracle, against the kernel it replaces, and the
+    coordinates it emits."""
     from toothgroupnetwork_amd import _lib
-    flags = _lib.FPS_FMA if mode & 1 else 0
+    flags = (_lib.FPS_FMA if mode & 1 else 0) | (_lib.FPS_TREE_TIES if mode & 2 else 0)
     clouds = [synth.lattice_cloud(7, dup=90, seed=1),             # 433 points -> 64 x 8
               synth.lattice_cloud(9, dup=250, seed=2),            # 979       -> 256 x 4
               synth.arch_cloud(1024, 5, False),                   # exact capacity of 256 x 4

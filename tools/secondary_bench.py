@@ -139,9 +139,8 @@ def hot_path_tree_ties(make_inputs, device, B=256, steps=8, warmup=3):
                 kernel_ms=t["kernel_ms"], first_index_ties=f, slowdown_vs_first_index=t["ms"] / f["ms"],
                 config=f"shape_A materialised, {B} scans per step, phased schedule, FPS with TGN_FPS_TREE_TIES at every level",
                 note="the tie key of the tree order is (bit-reversed reference thread, position within it) instead of the point index: one more "
-                     "compare per candidate where distances tie exactly, nothing else at levels 1-2; level 3 (1024 points) runs on "
-                     "fps_resident_kernel in this mode (~0.25 ms) because the lean kernel (~0.12 ms) implements the first-index order only -- that "
-                     "is the whole difference (profiles/r06_hw_queues.txt); the prefix-identity shortcut is off in this mode "
+                     "compare per candidate where distances tie exactly, nothing else at levels 1-2; at level 3 the lean kernel keeps a tree "
+                     "key per point and pays two more instructions per selection step; the prefix-identity shortcut is off in this mode "
                      "(include/tgn_pointops.h) and is not part of the headline either")
 
 

@@ -123,8 +123,9 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(FpsArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Lean register-resident kernel for small clouds (round 6): the same operator, arithmetic and tie order as fps_resident_kernel
-// (canonical first-index ties; the tree order stays with that kernel), written for the two things that bound these launches in
+// Lean register-resident kernel for small clouds (round 6): the same operator, arithmetic and tie orders as fps_resident_kernel
+// (first-index ties; the tree order costs it a key per point and two more instructions per selection step, and resolves ties
+// between lanes / waves in rare wave-uniform branches), written for the two things that bound these launches in
 // the phased HotPath schedule: a lone wave issues about one instruction per 5 cycles WHATEVER its kind, so an iteration costs
 // what the wave that holds the winner ISSUES (fps_resident_kernel<64,16>: ~350 instructions per iteration); and the ball
 // queries that run beside FPS levels 2-3 are occupancy-bound by LDS (6 KB per wave), so every KB this kernel holds is theirs.
@@ -165,7 +166,7 @@ __device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
 template <int NT, int P, int MODE>
 __global__ __launch_bounds__(NT) void fps_lean_kernel(FpsArgs a) {
     static_assert(P % 2 == 0 && P >= 2, "points come in pairs");
-    constexpr bool FMA = (MODE & 1) != 0, CERT = (MODE & kFpsModeCert) != 0;
+    constexpr bool FMA = (MODE & 1) != 0, TREE = (MODE & 2) != 0, CERT = (MODE & kFpsModeCert) != 0;
     constexpr int NW = NT / kWave, H = P / 2;
     static_assert(NW == 1 || NW == 2 || NW == 4 || NW == 8 || NW == 16, "wave count");
     __shared__ uint4 rec[2][NW][2];     // {value bits, key, x, y} {z, -, -, -}
@@ -192,6 +193,14 @@ __global__ __launch_bounds__(NT) void fps_lean_kernel(FpsArgs a) {
             z[i][u] = valid ? base[(size_t)k * 3 + 2] : 0.0f;
             d[i][u] = valid ? 1e10f : -1.0f;   // pointops.py:22 ; padding can never win (real distances are >= 0)
         }
+    }
+    // tree tie order (sampling_cuda_kernel.cu:5-10,64-123): the smallest compat_key wins among equal distances, not the smallest
+    // index -- the keys of a lane's points are kept beside them (P more registers, this mode only)
+    const int log2bs = a.ref_log2_block;
+    unsigned tk[TREE ? P : 1];
+    if constexpr (TREE) {
+#pragma unroll
+        for (int s = 0; s < P; ++s) tk[s] = compat_key(tid * P + s, log2bs);
     }
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
     if (n > 0) {
@@ -223,9 +232,15 @@ __global__ __launch_bounds__(NT) void fps_lean_kernel(FpsArgs a) {
         // states the DPP hazard asks for.
         int slot = P - 1;
         float cx = x[H - 1][1], cy = y[H - 1][1], cz = z[H - 1][1];
+        unsigned ksel = 0xFFFFFFFFu;   // (tree order) the key of the selected slot
+        if constexpr (TREE) ksel = d[H - 1][1] == best ? tk[P - 1] : 0xFFFFFFFFu;
         int wv = __float_as_int(best);
         auto select_step = [&](int s2) {
-            const bool c = d[s2 >> 1][s2 & 1] == best;
+            bool c = d[s2 >> 1][s2 & 1] == best;
+            if constexpr (TREE) {
+                c = c && tk[s2] < ksel;
+                ksel = c ? tk[s2] : ksel;
+            }
             slot = c ? s2 : slot;
             cx = c ? x[s2 >> 1][s2 & 1] : cx;
             cy = c ? y[s2 >> 1][s2 & 1] : cy;
@@ -249,7 +264,14 @@ __global__ __launch_bounds__(NT) void fps_lean_kernel(FpsArgs a) {
         // the lanes that hold the wave's maximum (none if the wave has no point at all); no branch on `eq` or on the sign: the
         // selection chain above would sink into it, behind the reduction
         const unsigned long long eq = ballot64(__float_as_int(best) == wmi) & (wmi >= 0 ? ~0ull : 0ull);
-        const int L = eq ? (int)__builtin_ctzll(eq) : 0;   // lane-major points: the first lane holds the smallest index
+        int L = eq ? (int)__builtin_ctzll(eq) : 0;   // lane-major points: the first lane holds the smallest index
+        if constexpr (TREE) {
+            if (__builtin_expect(__popcll(eq) > 1, 0)) {   // (wave-uniform, rare) several lanes tie: the smallest tree key among them
+                const unsigned kl = ((eq >> lane) & 1ull) ? ksel : 0xFFFFFFFFu;
+                const unsigned kmin = wave_min_u32_dpp(kl);
+                L = (int)__builtin_ctzll(ballot64(kl == kmin) | (1ull << 63));
+            }
+        }
         const int sL = __builtin_amdgcn_readlane(slot, L);
         const int ix = __builtin_amdgcn_readlane(__float_as_int(cx), L), iy = __builtin_amdgcn_readlane(__float_as_int(cy), L),
                   iz = __builtin_amdgcn_readlane(__float_as_int(cz), L);
@@ -271,7 +293,14 @@ __global__ __launch_bounds__(NT) void fps_lean_kernel(FpsArgs a) {
             mb = (unsigned)__builtin_amdgcn_readlane((int)mb, NW - 1);
             // waves own ascending index ranges: of several waves with the same maximum the first holds the smallest index
             const unsigned long long wmask = ballot64(r0.x == mb) & ((1ull << NW) - 1ull);
-            const int w = (int)__builtin_ctzll(wmask);
+            int w = (int)__builtin_ctzll(wmask);
+            if constexpr (TREE) {
+                if (__builtin_expect(__popcll(wmask) > 1, 0)) {   // (rare) equal maxima in several waves: the smallest tree key
+                    const unsigned kk = (((wmask >> lane) & 1ull) && r0.y != 0xFFFFFFFFu) ? compat_key((int)r0.y, log2bs) : 0xFFFFFFFFu;
+                    const unsigned kmin = wave_min_u32_dpp(kk);
+                    if (kmin != 0xFFFFFFFFu) w = (int)__builtin_ctzll(ballot64(kk == kmin) | (1ull << 63));
+                }
+            }
             key = (unsigned)__builtin_amdgcn_readlane((int)r0.y, w);
             kx = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)r0.z, w));
             ky = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)r0.w, w));
@@ -423,8 +452,8 @@ static int fps_launch(int b, int n_max, const FpsArgs &a, hipStream_t stream) {
             if (rc >= 0) return rc;
         }
     }
-    if constexpr ((MODE & 2) == 0) {
-        // small clouds, canonical tie order: the lean kernel ("fps_lean": 0 = off, 1 = clouds of 257 .. 2048 points, 2 = up to 4096)
+    {
+        // small clouds: the lean kernel ("fps_lean": 0 = off, 1 = clouds of 257 .. 2048 points, 2 = up to 4096)
         const int lean = tuning(kTuneFpsLean);
         if (lean && n_max > 256 && n_max <= (lean >= 2 ? 4096 : 2048) && !tuning(kTuneFpsConfig)) {
 #define X(NT_, P_)                                                                                      \
