@@ -156,27 +156,38 @@ def hot_path_with_h2d(make_inputs, device, B=256, steps=8, warmup=3):
     nbytes = host.numel() * 4
     hp = hotpath.HotPath(B, device, shape=shape, pipeline=True)
     s_copy = torch.cuda.Stream(device=device)
-    # THREE input buffers: step k's scans are copied while step k-1 samples its own (FPS level 1 reads them for 3.3 ms) and step
-    # k-2's groupings still gather from theirs -- with two, the copy could only start when those groupings are through, one
+    # FOUR input buffers: step k's scans are copied while step k-1 samples its own (FPS level 1 reads them for 3.3 ms), step
+    # k-2's groupings still gather from theirs, and the copy has to be through one phase earlier than the step needs it (the
+    # split waits for a phase-2 start) -- with two, the copy could only start when those groupings are through, one
     # millisecond before its step begins (measured: 10.4 ms per step, the copy fully exposed)
-    NB = 3
+    NB = 4
     pts = [torch.empty_like(feats_d[0]) for _ in range(NB)]
     xyzs = [torch.empty_like(xyz_d) for _ in range(NB)]
     ev_in = [torch.cuda.Event() for _ in range(NB)]
     ev_after = [torch.cuda.Event() for _ in range(NB)]       # on the caller's stream behind run(): that step's results are complete
     marks = {}
 
+    s_split = torch.cuda.Stream(device=device, priority=-1)  # the split has a stream of its own: a gated split must not hold back the next copy
+    ev_copied = [torch.cuda.Event() for _ in range(NB)]
+
     def step(k, mark=False):
         p = k % NB
         with torch.cuda.stream(s_copy):
             if k >= NB:
-                s_copy.wait_event(ev_after[p])                         # buffer p's last readers: step k-3's groupings
+                s_copy.wait_event(ev_after[p])                         # buffer p's last readers: step k-4's groupings
             pts[p].copy_(host, non_blocking=True)
-            # the (B, N, 3) coordinate block the samplers read (torch's strided copy_ takes 0.7-1.6 ms in the one wave slot beside
-            # a running FPS level 1 -- its 256-thread blocks of 4 elements per thread; the row kernel 0.1-0.2 ms)
+            ev_copied[p].record(s_copy)
+        with torch.cuda.stream(s_split):
+            s_split.wait_event(ev_copied[p])
+            # the (B, N, 3) coordinate block the samplers read: split off when the running step's phase 2 starts (beside FPS level 1
+            # the split shares one wave slot per SIMD with the groupings -- 2-3 ms, torch's strided copy_ or a row kernel alike --
+            # and a wave of more than 48 VGPRs keeps a CU from starting its FPS workgroup: profiles/r06_h2d.txt)
+            gate = hp.phase2_event()
+            if gate is not None:
+                s_split.wait_event(gate)
             _lib.check(_lib.lib().tgn_slice_columns(B * shape["n"], 6, 0, 3, _lib.ptr(pts[p]), _lib.ptr(xyzs[p]),
-                                                    _lib.c_void_p(s_copy.cuda_stream)), "slice_columns")
-            ev_in[p].record(s_copy)
+                                                    _lib.c_void_p(s_split.cuda_stream)), "slice_columns")
+            ev_in[p].record(s_split)
         hp.run(xyzs[p], [pts[p]] + feats_d[1:], inputs_on_current_stream=False, input_event=ev_in[p])
         ev_after[p].record(torch.cuda.current_stream())
         if mark:
@@ -209,7 +220,7 @@ def hot_path_with_h2d(make_inputs, device, B=256, steps=8, warmup=3):
                 bytes_per_step=nbytes, resident_inputs={"value": B * steps / dt_res, "ms": 1e3 * dt_res / steps},
                 slowdown_vs_resident=dt / dt_res,
                 copy_alone={"pinned_ms": copy_ms, "pinned_GBs": nbytes / copy_ms / 1e6, "pageable_ms": page_ms, "pageable_GBs": nbytes / page_ms / 1e6},
-                config=f"shape_A materialised, {B} scans per step staged from pinned host memory on a copy stream (three input buffers), "
+                config=f"shape_A materialised, {B} scans per step staged from pinned host memory on a copy stream (four input buffers), "
                        f"overlapped with the previous step; {steps} consecutive steps in steady state between two events",
                 roofline=_roof("pcie", nbytes * steps / dt / 1e9, 64.0, "GB/s",
                                note="PCIe Gen5 x16 = 64 GB/s per direction (raw); the step needs bytes_per_step / ms_resident"))

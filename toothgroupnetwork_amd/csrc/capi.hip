@@ -174,22 +174,30 @@ __global__ void delay_kernel(unsigned ticks) {
 }  // namespace tgn
 namespace tgn {
 // out[r, 0 .. ncols) = in[r, first .. first + ncols) for rows of `stride` floats: the coordinate block of a scan's (N, 6) rows
-// (gen_utils.py:138 / pointnet_pp_model.py:16-20 slice it with torch indexing).  Rows are dealt to lanes in quads: a lane moves
-// whole rows, consecutive lanes consecutive rows -- the reads of a wave cover one contiguous range, the writes another.
+// (gen_utils.py:138 / pointnet_pp_model.py:16-20 slice it with torch indexing).
 __global__ __launch_bounds__(256) void slice_columns_kernel(long long rows, int stride, int first, int ncols,
                                                             const float *__restrict__ in, float *__restrict__ out) {
     const long long nthreads = (long long)gridDim.x * blockDim.x;
     for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += nthreads) {
         const float *__restrict__ src = in + r * stride + first;
         float *__restrict__ dst = out + r * ncols;
-        if (ncols == 3) {   // (the case that matters: unrolled)
-            const float a = src[0], b = src[1], c = src[2];
-            dst[0] = a;
-            dst[1] = b;
-            dst[2] = c;
-        } else {
-            for (int c = 0; c < ncols; ++c) dst[c] = src[c];
-        }
+        for (int c = 0; c < ncols; ++c) dst[c] = src[c];
+    }
+}
+// The case that matters -- xyz out of (x, y, z, nx, ny, nz) rows, 16-byte aligned: a lane moves FOUR rows with six 16-byte loads
+// and three 16-byte stores (a wave: 6 KB in, 3 KB out, both contiguous).  This runs on a copy stream beside whatever the GPU is
+// doing -- typically in the one wave per SIMD an FPS level-1 workgroup leaves free, where a dword-per-lane copy is bound by
+// the latency of its few loads in flight (2.8 ms for 256 scans against 0.1 ms).
+__global__ __launch_bounds__(256) void slice_xyz_of_6_kernel(long long quads, const float4 *__restrict__ in, float4 *__restrict__ out) {
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += nthreads) {
+        const float4 *__restrict__ src = in + q * 6;
+        const float4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4], f = src[5];
+        // rows: (a.x a.y a.z | a.w b.x b.y) (b.z b.w c.x | c.y c.z c.w) (d.x d.y d.z | ...) (e.z e.w f.x | ...)
+        float4 *__restrict__ dst = out + q * 3;
+        dst[0] = make_float4(a.x, a.y, a.z, b.z);
+        dst[1] = make_float4(b.w, c.x, d.x, d.y);
+        dst[2] = make_float4(d.z, e.z, e.w, f.x);
     }
 }
 }  // namespace tgn
@@ -203,9 +211,22 @@ TGN_API int tgn_slice_columns(long long rows, int stride, int first, int ncols, 
         tgn::set_error("tgn_slice_columns: null pointer");
         return TGN_ERR_INVALID_ARGUMENT;
     }
-    long long blocks = (rows + 255) / 256;
+    long long done = 0;
+    if (stride == 6 && first == 0 && ncols == 3 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0 && rows >= 4) {
+        const long long quads = rows / 4;
+        long long blocks = (quads + 255) / 256;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hipLaunchKernelGGL(tgn::slice_xyz_of_6_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, quads, (const float4 *)in,
+                           (float4 *)out);
+        if (int rc = tgn::check_launch("slice_xyz_of_6_kernel")) return rc;
+        done = quads * 4;
+        if (done == rows) return TGN_OK;
+    }
+    const long long rest = rows - done;
+    long long blocks = (rest + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(tgn::slice_columns_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, stride, first, ncols, in, out);
+    hipLaunchKernelGGL(tgn::slice_columns_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rest, stride, first, ncols,
+                       in + done * stride, out + done * ncols);
     return tgn::check_launch("slice_columns_kernel");
 }
 

@@ -303,6 +303,16 @@ class HotPath:
             return [self._sa(lv, br, cur_xyz, pts, st) for br in lv["branches"]]
         return [self._group(lv, br, cur_xyz, feats[i], st) for br in lv["branches"]]
 
+    def phase2_event(self):
+        """(pipelined, phased mode) the event recorded behind FPS level 1 of the most recently issued step -- the start of its phase
+        2, the one stretch of a step in which the whole chip takes short kernels (beside FPS level 1 anything larger than 48 VGPRs
+        keeps a CU from starting its FPS workgroup and anything smaller shares ONE wave slot per SIMD with the groupings).  A
+        caller that prepares the next inputs on a stream of its own -- tools/secondary_bench.py: hot_path_with_h2d splits the
+        coordinate block off behind it -- waits for this event first.  None before the first step."""
+        if not self.phased or self.step_no < 1:
+            return None
+        return self.ev_fps[(self.step_no - 1) & 1][0]
+
     def take_index_error(self):
         """HotPath launches unchecked on streams of its own (the ball queries it runs produce valid indices by construction;
         a caller-supplied index tensor would not): True if any of its kernels latched an out-of-range gather index since the
