@@ -3,13 +3,13 @@
   fps   fps_lean_kernel in all four arithmetic / tie-order modes on ragged packed batches of 257 .. 4096-point clouds (quantised
         coordinates: exact ties inside lanes, across lanes and across waves; NaN rows; over-sampled clouds), `fps_lean` = 2;
   ball  the chunked ball-query kernel on clouds of 2 049 .. 24 000 points (clustered sheets, quantised lattices, duplicates).
-    python tools/random_stress.py [--fps 200] [--ball 60] [--seed 0]
-Test infrastructure: imports oracle/ (never shipped code)."""
+    python tests/random_stress.py [--fps 200] [--ball 60] [--seed 0]
+Test infrastructure (lives under tests/: it imports oracle/)."""
 import argparse
 import os
 import sys
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (tests/ is one level below the repository root)
 sys.path.insert(0, REPO)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
